@@ -1,0 +1,214 @@
+/* transit_hip.h -- C ABI of the MI355X line-by-line spectrum core.
+ *
+ * Drop-in boundary for the spectrum-computation path of exosports/transit
+ * (reference transit/src/transit.c:125-214, do_transit(): interpcs -> extwn ->
+ * tau -> emergent_intens/flux | modulation, plus the Voigt-table build of
+ * opacity.c:219-277 done once per handle).
+ *
+ * The reference dispatches this path through a per-ray plugin vtable
+ *   ray_solution { name, file, monospace, optdepth(tr,b,ex), spectrum(tr,tau,w,last,toomuch,r) }
+ *   (transit/include/structures_tr.h:68-83; instances eclipse.c:408, slantpath.c:573;
+ *    selected by name in argum.c:752-765)
+ * and through per-layer operators
+ *   int computemolext(struct transit*, PREC_RES **kiso, PREC_ATM temp,
+ *                     PREC_ATM *density, double *Z, int permol)   (extinction.h:25)
+ * which are one-scalar-per-call and cannot feed a GPU.  This ABI keeps the same
+ * selection surface (solution = "eclipse" | "transit") and the same data
+ * contract, batched: one create (static data: line list, grids, Voigt grid,
+ * CIA tables) and one run per atmosphere.  Plain pointers and sizes only; the
+ * caller owns every host buffer, the library owns device memory.
+ *
+ * All functions return 0 on success and a negative trx_status on failure; they
+ * never exit()/abort (reference: fw() macro transit.h:91-98 exits).
+ */
+#ifndef TRANSIT_HIP_H
+#define TRANSIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRX_ABI_VERSION 1
+
+typedef enum {
+  TRX_OK            =  0,
+  TRX_E_ARG         = -1,   /* bad argument / inconsistent sizes               */
+  TRX_E_NOMEM       = -2,   /* host or device allocation failed                */
+  TRX_E_HIP         = -3,   /* a HIP runtime call failed (see trx_last_error)  */
+  TRX_E_NODEVICE    = -4,   /* no usable gfx950 device                         */
+  TRX_E_RANGE       = -5,   /* layer temperature outside CIA / table range     */
+  TRX_E_UNSUPPORTED = -6,   /* option combination not implemented              */
+  TRX_E_ORDER       = -7,   /* line list not sorted as the TLI format requires */
+  TRX_E_NOTREACHED  = -8    /* modlevel -1 and tau never reached toomuch       */
+} trx_status;
+
+typedef enum { TRX_SOL_ECLIPSE = 0, TRX_SOL_TRANSIT = 1 } trx_solution;
+
+/* One collision-induced-absorption / cross-section table
+ * (reference struct cross, structures_tr.h:296-307; file grammar crosssec.c:87-233). */
+typedef struct {
+  int32_t nspec;          /* 1 or 2 species                                    */
+  int32_t mol[2];         /* indices into the atmosphere species list          */
+  int32_t nwave, ntemp;
+  const double *wn;       /* [nwave] cm-1                                      */
+  const double *temp;     /* [ntemp] K                                         */
+  const double *cs;       /* [nwave][ntemp] cm-1 amagat^-nspec                 */
+} trx_cia;
+
+/* Everything that does not change between spectra
+ * (reference: transit_init(), transit.c:25-74). */
+typedef struct {
+  int32_t abi_version;    /* TRX_ABI_VERSION                                   */
+  int32_t device;         /* HIP device ordinal                                */
+
+  /* wavenumber sampling (makewnsample, makesample.c:309-400)                 */
+  double  wn_i;           /* wns.i  first coarse wavenumber, cm-1              */
+  double  wn_d;           /* wns.d  coarse spacing, cm-1                       */
+  int64_t nwn;            /* wns.n  coarse samples                             */
+  int32_t osamp;          /* owns.o oversampling factor (wnosamp)              */
+  int64_t nown;           /* owns.n fine samples = (nwn-1)*osamp+1             */
+  /* this handle computes coarse bins [wn_lo, wn_hi) only (wavenumber shard of
+   * a multi-GPU job); 0, nwn for the whole grid                               */
+  int64_t wn_lo, wn_hi;
+
+  /* Voigt-profile grid (opacity.c:219-277; hint fields are float,
+   * structures_tr.h:326-333)                                                  */
+  int32_t ndop, nlor;
+  float   dmin, dmax, lmin, lmax;
+  float   timesalpha;     /* nwidth                                            */
+
+  /* line transitions, SoA as in struct line_transition (structures_tr.h:95-102);
+   * TLI order: isotope blocks, ascending wavelength inside a block            */
+  int64_t nlines;
+  const double  *wl_um;   /* [nlines] wavelength, microns                      */
+  const int16_t *isoid;   /* [nlines] cumulative isotope index                 */
+  const double  *elow;    /* [nlines] lower-state energy, cm-1                 */
+  const double  *gf;      /* [nlines]                                          */
+
+  /* isotopes (struct isotopes, structures_tr.h)                               */
+  int32_t niso;
+  const double  *iso_mass;   /* [niso] amu                                     */
+  const double  *iso_ratio;  /* [niso]                                         */
+  const int32_t *iso_imol;   /* [niso] index into the species list             */
+
+  /* atmosphere species (struct molecules)                                     */
+  int32_t nmol;
+  const double  *mol_mass;   /* [nmol] amu                                     */
+  const double  *mol_radius; /* [nmol] cm                                      */
+  const double  *mol_pol;    /* [nmol] polarizability A^3 (scattering flag 2)  */
+  const int32_t *mol_is_h2;  /* [nmol] 1 for the species named "H2" (cloud P19)*/
+
+  /* CIA tables                                                                */
+  int32_t ncia;
+  const trx_cia *cia;
+} trx_static;
+
+/* Per-spectrum atmosphere, already on transit's layer grid, bottom layer first
+ * (reference: makeradsample(), makesample.c:409-549; the density[]/Z[] vectors
+ * handed to computemolext at tau.c:164-167, 254-257). */
+typedef struct {
+  int32_t nlayer;
+  double  rad_fct;        /* rads.fct: radius units -> cm                      */
+  const double *radius;   /* [nlayer] rads.v, units of rad_fct                 */
+  const double *temp;     /* [nlayer] K (atm.t * tfct; the reference's Planck
+                             and scattering terms read atm.t without tfct,
+                             eclipse.c:155 -- identical when ut = 1)            */
+  const double *press;    /* [nlayer] atm.p as the reference stores it, i.e. in
+                             atmosphere-file units; its cloud and scattering
+                             models (extinction.c:608,661) assume these are bar */
+  const double *density;  /* [nmol][nlayer] g cm-3                             */
+  const double *abund;    /* [nmol][nlayer] mixing ratio q (cloud/scatter only; may be NULL) */
+  const double *zpart;    /* [niso][nlayer] partition function Z_i(T_layer)    */
+} trx_atm;
+
+/* Per-spectrum options (reference: struct transithint fields accepted in
+ * argum.c:774-911 and tau.c:12-52). */
+typedef struct {
+  int32_t solution;       /* trx_solution                                      */
+  double  toomuch;        /* optical-depth cut (tau.c:277)                     */
+  double  ethresh;        /* line-strength threshold (extinction.c:467)        */
+  double  wn_fct;         /* wns.fct (output wavenumber units factor)          */
+  /* eclipse */
+  int32_t nangles;
+  const double *angles_deg;   /* raygrid                                       */
+  /* transit */
+  double  starrad_cm;     /* sg->starrad * sg->starradfct                      */
+  int32_t transparent;    /* sg->transpplanet                                  */
+  int32_t modlevel;       /* 1 or -1                                           */
+  /* clouds (struct extcloud) and scattering (struct extscat)                  */
+  int32_t cloud_flag;     /* 0 none, 1 ext, 2 opa, 3 B17, 4 F18, 5 P19         */
+  double  cloud_ext, cloud_top, cloud_bot, cloud_gamma, cloud_Q, cloud_r,
+          cloud_sig, cloud_refwn;
+  int32_t scat_flag;      /* 0 none, 1 Lecavelier, 2 polarizability            */
+  double  scat_logext;
+  /* execution knobs (no effect on results)                                    */
+  int32_t layer_chunk;    /* layers swept per top-down step; 0 = default       */
+  int32_t eager;          /* 1 = sweep every layer (debug dumps of all layers) */
+} trx_opts;
+
+/* Optional intermediate outputs (host buffers, any may be NULL).  They mirror
+ * the reference's --savefiles dumps (tau.c:180-190, 293-329). */
+typedef struct {
+  double  *e;             /* [nlayer][nwn_shard] molecular extinction          */
+  double  *e_cs;          /* [nlayer][nwn_shard] CIA extinction (ref: [wn][layer]) */
+  double  *tau;           /* [nwn_shard][nlayer] optical depth                 */
+  int64_t *last;          /* [nwn_shard]                                       */
+  double  *intens;        /* [nangles][nwn_shard] (eclipse)                    */
+  uint8_t *computed;      /* [nlayer] 1 if the layer was swept                 */
+} trx_debug;
+
+/* Counters and device timings of the last trx_run (reference DEBUG counters
+ * extinction.c:513-518; stage timers transitstd.c:359-374). */
+typedef struct {
+  int64_t nlines_inrange; /* lines passing the range test (extinction.c:410)   */
+  int64_t ngroups;        /* co-added groups (anchors), layer independent      */
+  int64_t nadd;           /* co-added lines per layer (layer independent)      */
+  int64_t layers_swept;
+  int64_t neval;          /* evaluated groups, summed over swept layers        */
+  int64_t nskip;          /* groups below ethresh*kmax, summed over layers     */
+  int64_t sum_bins;       /* accumulated (group,layer,bin) triples             */
+  int64_t table_floats;   /* Voigt table size                                  */
+  double  ms_create_table;/* device time of the Voigt-table build              */
+  double  ms_run_total;   /* device time of the last run, first to last kernel */
+  double  ms_sweep;       /* line-sweep kernels (pass 1 + pass 2 + accumulate) */
+  double  ms_sweep_kernel_avg; /* mean duration of the dominant sweep kernel   */
+  int64_t sweep_launches;
+  double  ms_tau;         /* optical-depth kernels                             */
+  double  ms_cia;
+  double  ms_spectrum;    /* intensity/flux or modulation                      */
+} trx_stats;
+
+typedef struct trx_handle trx_handle;
+
+int  trx_abi_version(void);
+int  trx_device_count(void);
+
+int  trx_create (const trx_static *st, trx_handle **out);
+int  trx_run    (trx_handle *h, const trx_atm *atm, const trx_opts *opts,
+                 double *spectrum /* [wn_hi-wn_lo], host */, trx_debug *dbg /* may be NULL */);
+/* Same as trx_run but leaves the spectrum in device memory (d_spectrum is a
+ * device pointer on the handle's device, e.g. a torch tensor for an RCCL
+ * gather); work is enqueued on the handle's stream and synchronised on return. */
+int  trx_run_device(trx_handle *h, const trx_atm *atm, const trx_opts *opts,
+                    void *d_spectrum, trx_debug *dbg);
+void trx_destroy(trx_handle *h);
+
+int  trx_get_stats(const trx_handle *h, trx_stats *out);
+
+/* Voigt table access for parity tests (reference struct opacity.profile /
+ * .profsize, structures_tr.h:154-171). */
+int  trx_table_info(const trx_handle *h, int64_t *profsize /* [ndop*nlor] */,
+                    int64_t *offset /* [ndop*nlor] float offset of each profile */,
+                    int64_t *total_floats);
+int  trx_table_copy(const trx_handle *h, float *out /* [total_floats] */);
+int  trx_width_grids(const trx_handle *h, double *adop /* [ndop] */, double *alor /* [nlor] */);
+
+const char *trx_strerror(int status);
+const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSIT_HIP_H */

@@ -1,0 +1,53 @@
+/* transit_host.h -- C ABI of the host side of the drop-in: everything the
+ * reference does in transit_init() *before* the spectrum path
+ * (transit/src/transit.c:25-74: processparameters, acceptgenhints,
+ * makewnsample, getatm, readlineinfo, makeradsample, readcs) and the writers
+ * after it (printflux eclipse.c:356-380, printmod slantpath.c:511-555,
+ * printtoomuch tau.c:612-640), restated in C++ with the reference's CLI/cfg
+ * option names and file formats.  It produces the plain structs that
+ * include/transit_hip.h consumes; it contains no GPU code and no spectrum
+ * arithmetic.
+ */
+#ifndef TRANSIT_HOST_H
+#define TRANSIT_HOST_H
+#include "transit_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trh_problem trh_problem;
+
+/* Parse argv exactly like `transit [options]` (-c file | --config_file file,
+ * --name value, cfg lines "name value" with the reference's prefix matching,
+ * procopt.c:651-705), read every input file and build the samplings.
+ * On failure returns a negative code and, if err != NULL, a message. */
+int  trh_load(int argc, const char *const *argv, trh_problem **out, char *err, int errlen);
+void trh_free(trh_problem *p);
+
+const trx_static *trh_static(const trh_problem *p);
+const trx_atm    *trh_atm   (const trh_problem *p);
+const trx_opts   *trh_opts  (const trh_problem *p);
+
+int64_t trh_nwn(const trh_problem *p);                       /* get_no_samples()  transit.c:77 */
+void    trh_wavenumbers(const trh_problem *p, double *out);  /* get_waveno_arr()  transit.c:82 */
+
+/* restrict the static description to coarse bins [lo,hi) (one GPU's shard) */
+void trh_set_shard(trh_problem *p, int64_t lo, int64_t hi);
+
+/* BART-style re-entry (run_transit -> reloadatm, readatm.c:722-784):
+ * input = [T(nlayer), q_0(nlayer), ..., q_{nmol-1}(nlayer)] */
+int  trh_reload_atm(trh_problem *p, const double *input, int n);
+void trh_set_radius(trh_problem *p, double refradius);       /* transit.c:98  */
+void trh_set_cloudtop(trh_problem *p, double cloudtop);      /* transit.c:103 */
+void trh_set_scattering(trh_problem *p, int flag, double logext); /* transit.c:112 */
+
+/* writers in the reference's formats */
+int  trh_write_spectrum(const trh_problem *p, const double *spectrum, const char *path /* NULL = cfg outspec */);
+int  trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *last, const char *path);
+const char *trh_option(const trh_problem *p, const char *name);  /* accepted value of an option */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

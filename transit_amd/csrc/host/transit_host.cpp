@@ -1,0 +1,783 @@
+// transit_host.cpp -- host side of the drop-in (see include/transit_host.h).
+//
+// Restates, in C++, what the reference does before and after its spectrum path:
+//   options ............ transit/src/argum.c:112-320 (table), :361-739 (parse),
+//                        pu/src/procopt.c:651-705 (cfg lines, prefix match)
+//   wavenumber grids ... transit/src/makesample.c:28-120, 309-400
+//   atmosphere ......... transit/src/readatm.c:24-118, 277-428, 444-620, 626-717
+//   TLI line list ...... transit/src/readlineinfo.c:17-77, 88-244, 250-278, 416-537
+//   layer resampling ... transit/src/makesample.c:409-549 (+ pu/src/spline.c)
+//   CIA tables ......... transit/src/crosssec.c:10-268
+//   writers ............ eclipse.c:356-380, slantpath.c:511-555, tau.c:612-640
+// No spectrum arithmetic lives here; the output is the POD description that
+// include/transit_hip.h consumes.
+#include "../../../include/transit_host.h"
+#include "../trx_numerics.h"
+
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct OptDef { const char *name; char shortc; bool has_arg; const char *def; };
+
+// Same names, order and defaults as the reference's table (argum.c:112-320);
+// order matters because cfg tokens are matched as prefixes, first hit wins.
+const OptDef kOptions[] = {
+  {"version", 'V', false, nullptr}, {"help", 'h', false, nullptr},
+  {"quiet", 'q', false, nullptr}, {"verb", 'v', true, "2"},
+  {"config_file", 'c', true, nullptr},
+  {"atm", 0, true, nullptr}, {"linedb", 0, true, nullptr},
+  {"outtoomuch", 0, true, nullptr}, {"outsample", 0, true, nullptr},
+  {"outspec", 0, true, "outspectrum"}, {"outintens", 0, true, nullptr},
+  {"molfile", 0, true, "../inputs/molecules.dat"}, {"savefiles", 0, true, nullptr},
+  {"raddelt", 0, true, "-1"}, {"radlow", 0, true, "0"}, {"radhigh", 0, true, "0"},
+  {"radfct", 0, true, "0"},
+  {"allowq", 0, true, "0.00001"}, {"refpress", 0, true, nullptr},
+  {"refradius", 0, true, nullptr}, {"gsurf", 0, true, nullptr},
+  {"qmol", 0, true, nullptr}, {"qscale", 0, true, nullptr},
+  {"wllow", 0, true, nullptr}, {"wlhigh", 0, true, nullptr}, {"wlfct", 0, true, "1e-4"},
+  {"wnlow", 0, true, nullptr}, {"wnhigh", 0, true, nullptr}, {"wndelt", 0, true, "0"},
+  {"wnosamp", 0, true, "2160"}, {"wnfct", 0, true, "0"},
+  {"ndop", 0, true, "60"}, {"nlor", 0, true, "60"},
+  {"dmin", 0, true, "1e-3"}, {"dmax", 0, true, "0.25"},
+  {"lmin", 0, true, "1e-4"}, {"lmax", 0, true, "10.0"},
+  {"nwidth", 'a', true, "20"},
+  {"ethreshold", 0, true, "1e-8"}, {"cloud", 0, true, nullptr},
+  {"cloudtop", 0, true, nullptr}, {"scattering", 0, true, nullptr},
+  {"detailext", 0, true, nullptr}, {"detailcia", 0, true, nullptr},
+  {"csfile", 0, true, nullptr}, {"saveext", 0, true, nullptr},
+  {"opacityfile", 0, true, nullptr}, {"tlow", 0, true, "500"}, {"thigh", 0, true, "3000"},
+  {"tempdelt", 0, true, "100.0"}, {"justOpacity", 0, false, nullptr},
+  {"shareOpacity", 0, false, nullptr},
+  {"solution", 's', true, "eclipse"}, {"toomuch", 0, true, "20"},
+  {"taulevel", 0, true, "1"}, {"modlevel", 0, true, "1"}, {"detailtau", 0, true, nullptr},
+  {"starrad", 0, true, "1.125"}, {"gorbpar", 0, true, nullptr},
+  {"gorbparfct", 0, true, nullptr}, {"transparent", 0, false, nullptr},
+  {"raygrid", 0, true, "0 20 40 60 80"},
+};
+constexpr int kNumOptions = sizeof(kOptions) / sizeof(kOptions[0]);
+
+struct Fail : std::runtime_error { int code; Fail(int c, const std::string &m) : std::runtime_error(m), code(c) {} };
+
+std::string join_path(const std::string &dir, const std::string &f)
+{
+  if (f.empty() || f[0] == '/' || dir.empty()) return f;
+  return dir + "/" + f;
+}
+std::string rstrip(std::string s)
+{
+  while (!s.empty() && (s.back() == '\n' || s.back() == '\r' || s.back() == ' ' || s.back() == '\t')) s.pop_back();
+  return s;
+}
+std::vector<std::string> split_ws(const std::string &s)
+{
+  std::vector<std::string> out; std::istringstream is(s); std::string t;
+  while (is >> t) out.push_back(t);
+  return out;
+}
+
+// natural cubic spline resampling, pu/src/spline.c:97-128 (splinterp -> tri + spline3)
+void splinterp(const std::vector<double> &xi, const std::vector<double> &yi,
+               const std::vector<double> &xo, std::vector<double> &yo)
+{
+  const long n = (long)xi.size();
+  std::vector<double> z(n), u(n), v(n);
+  trx::spline_second_derivs(z.data(), xi.data(), yi.data(), n, u.data(), v.data());
+  yo.resize(xo.size());
+  for (size_t k = 0; k < xo.size(); k++)
+    yo[k] = trx::spline_eval_pow(z.data(), n, xi.data(), yi.data(), xo[k]);
+}
+
+struct CiaTable { int nspec = 0; int mol[2] = {0, 0}; std::vector<double> wn, temp, cs; };
+
+}  // namespace
+
+struct trh_problem {
+  std::map<std::string, std::string> opt;     // accepted option values
+  std::string base_dir = ".";                 // relative paths resolve against the working directory, as in the reference
+
+  // wavenumber sampling
+  double wn_i = 0, wn_f = 0, wn_d = 0; int64_t nwn = 0, nown = 0; int osamp = 1;
+
+  // atmosphere file (struct atm_data)
+  std::vector<std::string> species;
+  std::vector<double> a_rad, a_p, a_t, a_mm;            // [nlayer], file units
+  std::vector<std::vector<double>> a_q, a_d;            // [nmol][nlayer]
+  double rad_fct = 1, p_fct = 1, t_fct = 1, zerorad = 0; bool by_mass = true;
+  float allowq = 1e-5f;
+  // molecules
+  std::vector<int> mol_id; std::vector<double> mol_mass, mol_radius, mol_pol; std::vector<int32_t> mol_is_h2;
+  // line list
+  std::vector<double> wl, elow, gf; std::vector<int16_t> isoid;
+  std::vector<std::string> iso_name; std::vector<double> iso_mass, iso_ratio; std::vector<int32_t> iso_imol;
+  std::vector<int> iso_db;
+  struct Db { std::string name, molname; std::vector<double> T; int first = 0, niso = 0; };
+  std::vector<Db> dbs;
+  std::vector<std::vector<double>> iso_z;               // [niso][nT(db)]
+  double tli_tmin = 0, tli_tmax = 70000;
+  // sampled layers (makeradsample)
+  std::vector<double> rad, t, p, mm, dens, q, zpart, t_k;
+  // CIA
+  std::vector<CiaTable> cia; std::vector<trx_cia> cia_pod;
+  // eclipse angles
+  std::vector<double> angles;
+  // BART re-entry
+  double p0 = 0, r0 = 0, gsurf = 0;
+
+  trx_static st{}; trx_atm atm{}; trx_opts opts{};
+  std::string err;
+};
+
+namespace {
+
+const OptDef *match_option(const std::string &token)
+{
+  for (int i = 0; i < kNumOptions; i++)
+    if (std::strncmp(kOptions[i].name, token.c_str(), token.size()) == 0) return &kOptions[i];
+  return nullptr;
+}
+
+void read_cfg(trh_problem &P, const std::string &path);
+
+void accept(trh_problem &P, const OptDef *o, const std::string &value, const std::string &ctx_dir)
+{
+  if (std::strcmp(o->name, "config_file") == 0) { read_cfg(P, join_path(ctx_dir, value)); return; }
+  if (std::strcmp(o->name, "quiet") == 0) { P.opt["verb"] = "1"; return; }
+  P.opt[o->name] = o->has_arg ? value : "1";
+}
+
+// pu/src/procopt.c:651-705: "name value" lines; '#' starts a comment line
+void read_cfg(trh_problem &P, const std::string &path)
+{
+  std::ifstream f(path);
+  if (!f) throw Fail(TRX_E_ARG, "cannot open configuration file '" + path + "'");
+  std::string line;
+  while (std::getline(f, line)) {
+    line = rstrip(line);
+    if (line.empty() || line[0] == '#') continue;
+    size_t k = 0;
+    while (k < line.size() && line[k] != ' ' && line[k] != '\t') k++;
+    const std::string token = line.substr(0, k);
+    while (k < line.size() && (line[k] == ' ' || line[k] == '\t')) k++;
+    const OptDef *o = match_option(token);
+    if (!o) throw Fail(TRX_E_ARG, "unknown option '" + token + "' in " + path);
+    if (o->has_arg && k >= line.size()) throw Fail(TRX_E_ARG, "option '" + token + "' needs a value");
+    accept(P, o, line.substr(k), ".");
+  }
+}
+
+void parse_args(trh_problem &P, int argc, const char *const *argv)
+{
+  for (int i = 0; i < kNumOptions; i++)
+    if (kOptions[i].def) P.opt[kOptions[i].name] = kOptions[i].def;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    const OptDef *o = nullptr; std::string val; bool have_val = false;
+    if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+      std::string name = a.substr(2);
+      const size_t eq = name.find('=');
+      if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); have_val = true; }
+      o = match_option(name);
+    } else if (a.size() >= 2 && a[0] == '-') {
+      for (int k = 0; k < kNumOptions; k++) if (kOptions[k].shortc == a[1]) o = &kOptions[k];
+      if (a.size() > 2) { val = a.substr(2); have_val = true; }
+    }
+    if (!o) throw Fail(TRX_E_ARG, "unknown argument '" + a + "'");
+    if (o->has_arg && !have_val) {
+      if (i + 1 >= argc) throw Fail(TRX_E_ARG, "missing value for '" + a + "'");
+      val = argv[++i];
+    }
+    accept(P, o, val, ".");
+  }
+}
+
+bool has(const trh_problem &P, const char *k) { return P.opt.count(k) != 0; }
+double num(const trh_problem &P, const char *k, double dflt = 0)
+{ auto it = P.opt.find(k); return it == P.opt.end() ? dflt : std::atof(it->second.c_str()); }
+std::string str(const trh_problem &P, const char *k)
+{ auto it = P.opt.find(k); return it == P.opt.end() ? std::string() : it->second; }
+
+// makesample.c:28-120 (makesample1): number of points of an equispaced grid
+int64_t sample_count(double ini, double fin, double d, int o)
+{
+  double excess = 1e-8;
+  if (d < 0) excess = -excess;
+  int64_t n = (int64_t)(((1.0 + excess) * fin - ini) / d + 1);
+  if (n < 0) n = -n;
+  return (n - 1) * o + 1;
+}
+
+// makesample.c:309-400 (makewnsample)
+void make_wn_sampling(trh_problem &P)
+{
+  const double wni = num(P, "wnlow"), wnf = num(P, "wnhigh"), wnfct = num(P, "wnfct");
+  const double wli = num(P, "wllow"), wlf = num(P, "wlhigh"), wlfct = num(P, "wlfct");
+  double ri, rf;
+  if (wni > 0) {
+    if (wnfct <= 0) throw Fail(TRX_E_ARG, "wnlow given but wnfct is not positive");
+    ri = wni * wnfct;
+  } else if (wlf > 0) {
+    if (wlfct <= 0) throw Fail(TRX_E_ARG, "wlfct is not positive");
+    ri = 1.0 / (wlf * wlfct);
+  } else throw Fail(TRX_E_ARG, "initial wavenumber (nor final wavelength) provided");
+  if (wnf > 0) {
+    if (wnfct < 0) throw Fail(TRX_E_ARG, "wnfct is negative");
+    rf = wnf * wnfct;
+  } else if (wli > 0) {
+    if (wlfct < 0) throw Fail(TRX_E_ARG, "wlfct is negative");
+    rf = 1.0 / (wli * wlfct);
+  } else throw Fail(TRX_E_ARG, "final wavenumber (nor initial wavelength) provided");
+  const double d = num(P, "wndelt");
+  if (d <= 0) throw Fail(TRX_E_ARG, "wndelt must be positive");
+  const int o = (int)num(P, "wnosamp");
+  if (o <= 0) throw Fail(TRX_E_ARG, "wnosamp must be positive");
+  if (rf < ri) throw Fail(TRX_E_ARG, "final wavenumber smaller than initial");
+  P.wn_i = ri; P.wn_f = rf; P.wn_d = d; P.osamp = o;
+  P.nown = sample_count(ri, rf, d, o);
+  P.nwn  = sample_count(ri, rf, d, 1);
+}
+
+// molecules.dat, readatm.c:626-717
+void read_molfile(trh_problem &P, const std::string &path)
+{
+  std::ifstream f(path);
+  if (!f) throw Fail(TRX_E_ARG, "cannot open molecule file '" + path + "'");
+  std::map<std::string, std::vector<double>> tab;   // name -> {id, mass, radius, pol}
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty() || line[0] == '#' || line[0] == '\n') { if (!tab.empty()) break; continue; }
+    auto w = split_ws(line);
+    if (w.size() < 6) continue;
+    tab[w[1]] = {(double)std::strtol(w[0].c_str(), nullptr, 10), std::strtod(w[2].c_str(), nullptr),
+                 std::strtod(w[3].c_str(), nullptr) / 2.0, std::strtod(w[5].c_str(), nullptr)};
+  }
+  const size_t nm = P.species.size();
+  P.mol_id.resize(nm); P.mol_mass.resize(nm); P.mol_radius.resize(nm); P.mol_pol.resize(nm);
+  P.mol_is_h2.resize(nm);
+  for (size_t i = 0; i < nm; i++) {
+    auto it = tab.find(P.species[i]);
+    if (it == tab.end()) throw Fail(TRX_E_ARG, "species '" + P.species[i] + "' not in " + path);
+    P.mol_id[i] = (int)it->second[0];
+    P.mol_mass[i] = it->second[1];
+    P.mol_radius[i] = it->second[2] * 1e-8;            // Angstrom -> cm
+    P.mol_pol[i] = it->second[3];
+    P.mol_is_h2[i] = (P.species[i] == "H2");
+  }
+}
+
+// readatm.c:121-158 (checkaddmm) + transit.h:58-69 (stateeqnford)
+void layer_state(trh_problem &P, size_t r)
+{
+  const size_t nm = P.species.size();
+  double mm = 0, sumq = 0;
+  for (size_t i = 0; i < nm; i++) {
+    if (P.by_mass) mm += P.a_q[i][r] / P.mol_mass[i];
+    else           mm += P.a_q[i][r] * P.mol_mass[i];
+    sumq += P.a_q[i][r];
+  }
+  if (P.by_mass) mm = 1.0 / mm;
+  if (sumq > 1.001) throw Fail(TRX_E_ARG, "abundances add up to more than 1");
+  P.a_mm[r] = mm;
+  const double p = P.a_p[r] * P.p_fct, t = P.a_t[r] * P.t_fct;
+  for (size_t i = 0; i < nm; i++) {
+    const double rho = trx::kAmu * P.a_q[i][r] * p / trx::kKb / t;
+    P.a_d[i][r] = P.by_mass ? rho * mm : rho * P.mol_mass[i];
+  }
+}
+
+// atmosphere file, readatm.c:277-428 (keywords) and :444-620 (rows)
+void read_atmosphere(trh_problem &P, const std::string &path, const std::string &molpath)
+{
+  std::ifstream f(path);
+  if (!f) throw Fail(TRX_E_ARG, "cannot open atmosphere file '" + path + "'");
+  std::string line;
+  std::vector<std::vector<double>> rows;
+  bool in_data = false;
+  while (std::getline(f, line)) {
+    line = rstrip(line);
+    if (line.empty()) continue;
+    if (!in_data) {
+      if (line[0] == '#') {
+        auto w = split_ws(line.substr(1));
+        if (!w.empty() && w[0] == "SPECIES") {
+          if (!std::getline(f, line)) throw Fail(TRX_E_ARG, "EOF after #SPECIES");
+          P.species = split_ws(line);
+        }
+        continue;
+      }
+      if (line[0] == 'q') {
+        size_t k = 1; while (k < line.size() && line[k] == ' ') k++;
+        const char c = (char)(line[k] | 0x20);
+        if (c == 'n') P.by_mass = false; else if (c == 'm') P.by_mass = true;
+        continue;
+      }
+      if (line[0] == 'z') { P.zerorad = std::atof(line.c_str() + 1); continue; }
+      if (line[0] == 'u') {
+        const double v = std::atof(line.c_str() + 2);
+        if (line[1] == 'r') P.rad_fct = v; else if (line[1] == 'p') P.p_fct = v;
+        else if (line[1] == 't') P.t_fct = v; else throw Fail(TRX_E_ARG, "bad unit line in atmosphere file");
+        continue;
+      }
+      if (line[0] == 'n') continue;
+      in_data = true;
+    }
+    if (line[0] == '#') continue;
+    auto w = split_ws(line);
+    std::vector<double> v; for (auto &s : w) v.push_back(std::strtod(s.c_str(), nullptr));
+    rows.push_back(v);
+  }
+  if (P.species.empty()) throw Fail(TRX_E_ARG, "no #SPECIES header in atmosphere file");
+  if (rows.empty()) throw Fail(TRX_E_ARG, "no layers in atmosphere file");
+  const size_t nm = P.species.size(), nr = rows.size();
+  read_molfile(P, molpath);
+  P.a_rad.resize(nr); P.a_p.resize(nr); P.a_t.resize(nr); P.a_mm.resize(nr);
+  P.a_q.assign(nm, std::vector<double>(nr)); P.a_d.assign(nm, std::vector<double>(nr));
+  for (size_t r = 0; r < nr; r++) {
+    if (rows[r].size() < 3 + nm) throw Fail(TRX_E_ARG, "atmosphere row with too few columns");
+    P.a_rad[r] = rows[r][0] + P.zerorad; P.a_p[r] = rows[r][1]; P.a_t[r] = rows[r][2];
+    for (size_t i = 0; i < nm; i++) P.a_q[i][r] = rows[r][3 + i];
+    layer_state(P, r);
+  }
+  bool sorted = true, reversed = true;                     // readatm.c:583-617
+  for (size_t i = 0; i + 1 < nr; i++) {
+    if (P.a_rad[i] >= P.a_rad[i+1] || P.a_p[i] <= P.a_p[i+1]) sorted = false;
+    if (P.a_rad[i] <= P.a_rad[i+1] || P.a_p[i] >= P.a_p[i+1]) reversed = false;
+  }
+  if (!sorted && !reversed && nr > 1) throw Fail(TRX_E_ARG, "atmosphere layers are not monotonic");
+  if (reversed && nr > 1) {
+    auto rev = [](std::vector<double> &v) { for (size_t i = 0, j = v.size() - 1; i < j; i++, j--) std::swap(v[i], v[j]); };
+    rev(P.a_rad); rev(P.a_p); rev(P.a_t); rev(P.a_mm);
+    for (size_t i = 0; i < nm; i++) { rev(P.a_q[i]); rev(P.a_d[i]); }
+  }
+}
+
+// readlineinfo.c:17-77 (datafileBS) on an in-memory ascending array
+int64_t tli_search(const double *w, int64_t n, double target, bool up)
+{
+  int64_t lo = 0, hi = n - 1, loc;
+  do {
+    loc = (hi + lo) / 2;
+    if (target > w[loc]) lo = loc; else hi = loc;
+  } while (hi - lo > 1);
+  if (up) { loc = lo; while (loc < n - 1) { if (w[loc+1] > target) break; loc++; } }
+  else    { loc = hi; while (loc > 0)     { if (w[loc-1] < target) break; loc--; } }
+  return loc;
+}
+
+// TLI v6: readlineinfo.c:88-244 (header), :416-537 (range selection)
+void read_tli(trh_problem &P, const std::string &path)
+{
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) throw Fail(TRX_E_ARG, "cannot open TLI file '" + path + "'");
+  std::fseek(fp, 0, SEEK_END); const long fsz = std::ftell(fp); std::fseek(fp, 0, SEEK_SET);
+  std::vector<unsigned char> buf((size_t)fsz);
+  if (std::fread(buf.data(), 1, (size_t)fsz, fp) != (size_t)fsz) { std::fclose(fp); throw Fail(TRX_E_ARG, "short read on TLI file"); }
+  std::fclose(fp);
+  size_t pos = 0;
+  auto need = [&](size_t n) { if (pos + n > buf.size()) throw Fail(TRX_E_ARG, "TLI file truncated"); };
+  auto rd = [&](void *dst, size_t n) { need(n); std::memcpy(dst, buf.data() + pos, n); pos += n; };
+  auto rstr = [&]() { uint16_t n; rd(&n, 2); need(n); std::string s((const char *)buf.data() + pos, n); pos += n; return s; };
+  unsigned char magic[4]; rd(magic, 4);
+  uint16_t ver[3]; rd(ver, 6);
+  if (ver[0] != 6) throw Fail(TRX_E_ARG, "TLI version is not 6");
+  double wli, wlf; rd(&wli, 8); rd(&wlf, 8);
+  uint16_t ndb; rd(&ndb, 2);
+  int cum = 0;
+  for (int d = 0; d < ndb; d++) {
+    trh_problem::Db db; db.name = rstr(); db.molname = rstr();
+    uint16_t nT, nI; rd(&nT, 2); rd(&nI, 2);
+    db.T.resize(nT); rd(db.T.data(), 8 * (size_t)nT);
+    P.tli_tmin = std::fmax(P.tli_tmin, db.T[0]);
+    P.tli_tmax = std::fmin(P.tli_tmax, db.T[nT-1]);
+    db.first = cum; db.niso = nI;
+    for (int k = 0; k < nI; k++) {
+      P.iso_name.push_back(rstr());
+      double m, r; rd(&m, 8); rd(&r, 8);
+      P.iso_mass.push_back(m); P.iso_ratio.push_back(r); P.iso_db.push_back(d);
+      std::vector<double> z(nT); rd(z.data(), 8 * (size_t)nT); P.iso_z.push_back(z);
+    }
+    cum += nI; P.dbs.push_back(db);
+  }
+  // range check, readlineinfo.c:306-352 (checkrange)
+  {
+    const double wlmin = 1.0 / P.wn_f, wlmax = 1.0 / P.wn_i;
+    if (wli * trx::kTliWfct > wlmax) throw Fail(TRX_E_ARG, "spectrum ends below the TLI wavelength range");
+    if (wlf * trx::kTliWfct < wlmin) throw Fail(TRX_E_ARG, "spectrum starts above the TLI wavelength range");
+  }
+  // setimol, readlineinfo.c:250-278
+  for (size_t i = 0; i < P.iso_name.size(); i++) {
+    int im = -1;
+    for (size_t m = 0; m < P.species.size(); m++) if (P.species[m] == P.dbs[P.iso_db[i]].molname) { im = (int)m; break; }
+    if (im < 0) throw Fail(TRX_E_ARG, "TLI molecule '" + P.dbs[P.iso_db[i]].molname + "' is not an atmosphere species");
+    P.iso_imol.push_back(im);
+  }
+  int64_t nlines; int32_t nisol; rd(&nlines, 8); rd(&nisol, 4);
+  std::vector<int64_t> cnt((size_t)nisol); rd(cnt.data(), 8 * (size_t)nisol);
+  const size_t wl0 = pos, iso0 = wl0 + 8 * (size_t)nlines, el0 = iso0 + 2 * (size_t)nlines, gf0 = el0 + 8 * (size_t)nlines;
+  if (gf0 + 8 * (size_t)nlines > buf.size()) throw Fail(TRX_E_ARG, "TLI line blocks truncated");
+  const double iniw = 1.0 / (P.wn_f * 1.0) / trx::kTliWfct, finw = 1.0 / (P.wn_i * 1.0) / trx::kTliWfct;
+  int64_t off = 0;
+  for (int k = 0; k < nisol; k++) {
+    if (cnt[k] > 0) {
+      std::vector<double> w((size_t)cnt[k]);
+      std::memcpy(w.data(), buf.data() + wl0 + 8 * (size_t)off, 8 * (size_t)cnt[k]);
+      const int64_t a = tli_search(w.data(), cnt[k], iniw, false);
+      const int64_t b = tli_search(w.data(), cnt[k], finw, true);
+      const int64_t nread = b - a + 1;
+      if (nread > 0) {
+        const size_t o0 = P.wl.size();
+        P.wl.resize(o0 + nread); P.elow.resize(o0 + nread); P.gf.resize(o0 + nread); P.isoid.resize(o0 + nread);
+        std::memcpy(&P.wl[o0],    buf.data() + wl0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
+        std::memcpy(&P.isoid[o0], buf.data() + iso0 + 2 * (size_t)(off + a), 2 * (size_t)nread);
+        std::memcpy(&P.elow[o0],  buf.data() + el0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
+        std::memcpy(&P.gf[o0],    buf.data() + gf0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
+      }
+    }
+    off += cnt[k];
+  }
+}
+
+// makesample.c:409-549 (makeradsample): layer grid + per-layer T, p, mm, q, rho, Z
+void make_layer_sampling(trh_problem &P)
+{
+  const size_t nm = P.species.size(), na = P.a_rad.size();
+  const double raddelt = num(P, "raddelt", -1);
+  if (na == 1 || raddelt == -1) P.rad = P.a_rad;
+  else {
+    // makesample.c:144-300 (makesample) with the atmosphere sampling as reference
+    double ini = num(P, "radlow"), fin = num(P, "radhigh");
+    if (ini <= 0) ini = P.a_rad.front();
+    if (fin <= 0) fin = P.a_rad.back();
+    if (raddelt <= 0) throw Fail(TRX_E_ARG, "raddelt must be -1 or positive");
+    if (fin <= ini) throw Fail(TRX_E_ARG, "radhigh must exceed radlow");
+    const int64_t n = sample_count(ini, fin, raddelt, 1);
+    P.rad.resize((size_t)n);
+    for (int64_t k = 0; k < n; k++) P.rad[(size_t)k] = ini + (double)k * raddelt;
+  }
+  const size_t nr = P.rad.size();
+  if (na == 1) {
+    P.t = P.a_t; P.p = P.a_p; P.mm = P.a_mm;
+    P.dens.resize(nm); P.q.resize(nm);
+    for (size_t i = 0; i < nm; i++) { P.dens[i] = P.a_d[i][0]; P.q[i] = P.a_q[i][0]; }
+  } else {
+    splinterp(P.a_rad, P.a_t, P.rad, P.t);
+    splinterp(P.a_rad, P.a_p, P.rad, P.p);
+    splinterp(P.a_rad, P.a_mm, P.rad, P.mm);
+    P.dens.resize(nm * nr); P.q.resize(nm * nr);
+    std::vector<double> tmp;
+    for (size_t i = 0; i < nm; i++) {
+      splinterp(P.a_rad, P.a_d[i], P.rad, tmp); std::copy(tmp.begin(), tmp.end(), P.dens.begin() + i * nr);
+      splinterp(P.a_rad, P.a_q[i], P.rad, tmp); std::copy(tmp.begin(), tmp.end(), P.q.begin() + i * nr);
+    }
+  }
+  for (size_t r = 0; r < nr; r++)
+    if (P.t[r] < P.tli_tmin || P.t[r] > P.tli_tmax)
+      throw Fail(TRX_E_RANGE, "layer temperature outside the TLI partition-function range");
+  const size_t ni = P.iso_name.size();
+  P.zpart.resize(ni * nr);
+  std::vector<double> tmp;
+  for (size_t i = 0; i < ni; i++) {                        // makesample.c:534-544 (T without tfct)
+    splinterp(P.dbs[P.iso_db[i]].T, P.iso_z[i], P.t, tmp);
+    std::copy(tmp.begin(), tmp.end(), P.zpart.begin() + i * nr);
+  }
+  P.t_k.resize(nr);
+  for (size_t r = 0; r < nr; r++) P.t_k[r] = P.t[r] * P.t_fct;
+}
+
+// crosssec.c:87-233
+void read_cia(trh_problem &P, const std::string &path)
+{
+  std::ifstream f(path);
+  if (!f) throw Fail(TRX_E_ARG, "cannot read cross-section file '" + path + "'");
+  CiaTable c; std::string line; bool header = true;
+  while (std::getline(f, line)) {
+    line = rstrip(line);
+    if (line.empty() || line[0] == '#') continue;
+    if (header && line[0] == 'i') {
+      auto w = split_ws(line.substr(1));
+      if (w.size() != 1 && w.size() != 2) throw Fail(TRX_E_ARG, "bad 'i' line in " + path);
+      c.nspec = (int)w.size();
+      for (int k = 0; k < c.nspec; k++) {
+        int im = -1;
+        for (size_t m = 0; m < P.species.size(); m++) if (P.species[m] == w[k]) im = (int)m;
+        if (im < 0) throw Fail(TRX_E_ARG, "CIA species '" + w[k] + "' is not an atmosphere species");
+        c.mol[k] = im;
+      }
+      continue;
+    }
+    if (header && line[0] == 't') {
+      const char *s = line.c_str() + 1; char *e;
+      while (true) {
+        const double v = std::strtod(s, &e);
+        if (e == s) break;
+        c.temp.push_back(v);
+        if ((*e | 0x20) == 'k') e++;
+        s = e;
+      }
+      if (c.temp.empty()) throw Fail(TRX_E_ARG, "no temperatures in " + path);
+      continue;
+    }
+    header = false;
+    const char *s = line.c_str(); char *e;
+    const double w = std::strtod(s, &e);
+    if (e == s) throw Fail(TRX_E_ARG, "bad wavenumber row in " + path);
+    c.wn.push_back(w); s = e;
+    for (size_t k = 0; k < c.temp.size(); k++) {
+      const double v = std::strtod(s, &e);
+      if (e == s) throw Fail(TRX_E_ARG, "short row in " + path);
+      c.cs.push_back(v); s = e;
+    }
+  }
+  if (c.wn.empty() || c.nspec == 0) throw Fail(TRX_E_ARG, "empty cross-section file " + path);
+  const double wlast = P.wn_i + (double)(P.nwn - 1) * P.wn_d;
+  if (c.wn.front() > P.wn_i || c.wn.back() < wlast)          // crosssec.c:251-259
+    throw Fail(TRX_E_RANGE, "cross-section file does not cover the wavenumber range: " + path);
+  P.cia.push_back(std::move(c));
+}
+
+// readatm.c:787-865 (radpress): hydrostatic radii around the reference level
+// (p0 in atmosphere-file pressure units, r0 in radius units, gsurf in cm s-2).
+void hydrostatic_radii(trh_problem &P)
+{
+  const int n = (int)P.a_rad.size();
+  const double rfct = P.rad_fct, g0 = P.gsurf, p0 = P.p0, r0 = P.r0;
+  std::vector<double> &rad = P.a_rad; const std::vector<double> &t = P.a_t, &mu = P.a_mm, &p = P.a_p;
+  int i0 = -1; double best = 1e37;
+  for (int i = 0; i < n; i++)
+    if (std::fabs(p[i] - p0) < best) { i0 = i; best = std::fabs(p[i] - p0); }
+  if (i0 < 0) throw Fail(TRX_E_RANGE, "reference pressure level not found");
+  const int nb = (p[i0] > p0) ? i0 + 1 : i0 - 1;            // neighbour on the p0 side
+  if (nb < 0 || nb >= n) throw Fail(TRX_E_RANGE, "reference pressure outside the layer range");
+  const double lr = std::log(p[nb] / p[i0]);
+  const double temp0 = t[i0]  + ((t[nb]  - t[i0])  / lr) * std::log(p0 / p[i0]);
+  const double mu0   = mu[i0] + ((mu[nb] - mu[i0]) / lr) * std::log(p0 / p[i0]);
+  const double kam = trx::kKb / trx::kAmu;
+  if (p[i0] > p0) rad[i0] = r0 + 0.5 * (t[i0] / mu[i0] + temp0 / mu0) * (kam * std::log(p0 / p[i0]) / g0) / rfct;
+  else            rad[i0] = r0 - 0.5 * (t[i0] / mu[i0] + temp0 / mu0) * (kam * std::log(p[i0] / p0) / g0) / rfct;
+  double g = g0 * std::pow(r0 / rad[i0], 2);
+  for (int i = i0 - 1; i >= 0; i--) {
+    rad[i] = rad[i+1] - 0.5 * (t[i] / mu[i] + t[i+1] / mu[i+1]) * (kam * std::log(p[i] / p[i+1]) / g) / rfct;
+    g = g * std::pow(rad[i+1] / rad[i], 2);
+  }
+  g = g0 * std::pow(r0 / rad[i0], 2);
+  for (int i = i0 + 1; i < n; i++) {
+    rad[i] = rad[i-1] + 0.5 * (t[i] / mu[i] + t[i-1] / mu[i-1]) * (kam * std::log(p[i-1] / p[i]) / g) / rfct;
+    g = g * std::pow(rad[i-1] / rad[i], 2);
+  }
+}
+
+void fill_pods(trh_problem &P)
+{
+  trx_static &s = P.st;
+  s = trx_static{};
+  s.abi_version = TRX_ABI_VERSION; s.device = 0;
+  s.wn_i = P.wn_i; s.wn_d = P.wn_d; s.nwn = P.nwn; s.osamp = P.osamp; s.nown = P.nown;
+  s.wn_lo = 0; s.wn_hi = P.nwn;
+  s.ndop = (int)num(P, "ndop"); s.nlor = (int)num(P, "nlor");
+  s.dmin = (float)num(P, "dmin"); s.dmax = (float)num(P, "dmax");
+  s.lmin = (float)num(P, "lmin"); s.lmax = (float)num(P, "lmax");
+  s.timesalpha = (float)num(P, "nwidth");
+  s.nlines = (int64_t)P.wl.size();
+  s.wl_um = P.wl.data(); s.isoid = P.isoid.data(); s.elow = P.elow.data(); s.gf = P.gf.data();
+  s.niso = (int)P.iso_mass.size();
+  s.iso_mass = P.iso_mass.data(); s.iso_ratio = P.iso_ratio.data(); s.iso_imol = P.iso_imol.data();
+  s.nmol = (int)P.species.size();
+  s.mol_mass = P.mol_mass.data(); s.mol_radius = P.mol_radius.data(); s.mol_pol = P.mol_pol.data();
+  s.mol_is_h2 = P.mol_is_h2.data();
+  P.cia_pod.clear();
+  for (auto &c : P.cia) {
+    trx_cia t{}; t.nspec = c.nspec; t.mol[0] = c.mol[0]; t.mol[1] = c.mol[1];
+    t.nwave = (int)c.wn.size(); t.ntemp = (int)c.temp.size();
+    t.wn = c.wn.data(); t.temp = c.temp.data(); t.cs = c.cs.data();
+    P.cia_pod.push_back(t);
+  }
+  s.ncia = (int)P.cia_pod.size(); s.cia = P.cia_pod.data();
+
+  trx_atm &a = P.atm;
+  a = trx_atm{};
+  a.nlayer = (int)P.rad.size(); a.rad_fct = P.rad_fct;
+  a.radius = P.rad.data(); a.temp = P.t_k.data(); a.press = P.p.data();
+  a.density = P.dens.data(); a.abund = P.q.data(); a.zpart = P.zpart.data();
+
+  trx_opts &o = P.opts;
+  const int keep_chunk = o.layer_chunk, keep_eager = o.eager;
+  const int cf = o.cloud_flag; const double ce = o.cloud_ext, ct = o.cloud_top, cb = o.cloud_bot;
+  const int sf = o.scat_flag; const double sl = o.scat_logext;
+  const bool had = (o.toomuch != 0);
+  o = trx_opts{};
+  const std::string sol = str(P, "solution");
+  if (sol == "eclipse") o.solution = TRX_SOL_ECLIPSE;
+  else if (sol == "transit") o.solution = TRX_SOL_TRANSIT;
+  else throw Fail(TRX_E_ARG, "solution kind '" + sol + "' is invalid (eclipse, transit)");
+  o.toomuch = num(P, "toomuch"); o.ethresh = num(P, "ethreshold");
+  if (o.ethresh <= 0) throw Fail(TRX_E_ARG, "ethreshold has to be positive");
+  if ((float)num(P, "nwidth") < 1) throw Fail(TRX_E_ARG, "nwidth has to be greater than one");
+  o.wn_fct = 1.0;                                          // makesample.c:369 (reference grid is cm-1)
+  P.angles.clear();
+  if (o.solution == TRX_SOL_ECLIPSE)
+    for (auto &w : split_ws(str(P, "raygrid"))) P.angles.push_back(std::atof(w.c_str()));
+  o.nangles = (int)P.angles.size(); o.angles_deg = P.angles.data();
+  o.starrad_cm = num(P, "starrad") * trx::kSunRadius;      // geometry.c:33-47
+  o.transparent = has(P, "transparent"); o.modlevel = (int)num(P, "modlevel", 1);
+  if ((int)num(P, "taulevel", 1) != 1) throw Fail(TRX_E_UNSUPPORTED, "taulevel 2 is not implemented (neither in the reference, slantpath.c:135)");
+  // clouds, argum.c:653-716
+  if (has(P, "cloud")) {
+    const std::string c = str(P, "cloud");
+    if (c.find("ext") != std::string::npos) o.cloud_flag = 1;
+    else if (c.find("opa") != std::string::npos) o.cloud_flag = 2;
+    else if (c.find("B17") != std::string::npos) o.cloud_flag = 3;
+    else if (c.find("F18") != std::string::npos) o.cloud_flag = 4;
+    else if (c.find("P19") != std::string::npos) o.cloud_flag = 5;
+    std::vector<double> v; std::string rest = c.size() > 4 ? c.substr(4) : ""; std::string tok; std::istringstream is(rest);
+    while (std::getline(is, tok, ',')) v.push_back(std::atof(tok.c_str()));
+    if (v.size() < 3) throw Fail(TRX_E_ARG, "cloud needs cloudtype,cloudext,cloudtop,cloudbot");
+    o.cloud_ext = v[0]; o.cloud_top = v[1]; o.cloud_bot = v[2];
+    o.cloud_gamma = o.cloud_Q = o.cloud_r = o.cloud_sig = o.cloud_refwn = 1;
+    if (o.cloud_flag >= 3 && v.size() > 3) o.cloud_gamma = v[3];
+    if (o.cloud_flag == 4 && v.size() > 5) { o.cloud_Q = v[4]; o.cloud_r = v[5]; }
+    if (o.cloud_flag == 5 && v.size() > 5) { o.cloud_sig = v[4]; o.cloud_refwn = v[5]; }
+    if (o.cloud_top > o.cloud_bot) throw Fail(TRX_E_ARG, "cloud top must be less than cloud bottom");
+  }
+  if (has(P, "cloudtop")) {                                 // argum.c:718-724
+    o.cloud_top = num(P, "cloudtop"); o.cloud_bot = o.cloud_top + 10; o.cloud_ext = 100.0; o.cloud_flag = 1;
+  }
+  if (has(P, "scattering")) {                               // argum.c:726-740
+    if (str(P, "scattering") == "polar") { o.scat_flag = 2; o.scat_logext = 0; }
+    else { o.scat_flag = 1; o.scat_logext = num(P, "scattering"); }
+  }
+  if (had) {   // keep run-time overrides set through trh_set_* across reloads
+    if (cf) { o.cloud_flag = cf; o.cloud_ext = ce; o.cloud_top = ct; o.cloud_bot = cb; }
+    if (sf) { o.scat_flag = sf; o.scat_logext = sl; }
+  }
+  o.layer_chunk = keep_chunk; o.eager = keep_eager;
+}
+
+void load(trh_problem &P, int argc, const char *const *argv)
+{
+  parse_args(P, argc, argv);
+  make_wn_sampling(P);
+  if (!has(P, "atm") || str(P, "atm") == "NULL" || str(P, "atm") == "-")
+    throw Fail(TRX_E_ARG, "no atmospheric file specified");
+  P.allowq = (float)num(P, "allowq");
+  read_atmosphere(P, join_path(P.base_dir, str(P, "atm")), join_path(P.base_dir, str(P, "molfile")));
+  if (has(P, "linedb")) read_tli(P, join_path(P.base_dir, str(P, "linedb")));
+  make_layer_sampling(P);
+  if (has(P, "csfile")) {
+    std::string tok; std::istringstream is(str(P, "csfile"));
+    while (std::getline(is, tok, ',')) if (!tok.empty()) read_cia(P, join_path(P.base_dir, tok));
+  }
+  P.p0 = num(P, "refpress"); P.r0 = num(P, "refradius"); P.gsurf = num(P, "gsurf");
+  if (has(P, "opacityfile")) throw Fail(TRX_E_UNSUPPORTED, "opacity-grid mode is not implemented yet");
+  fill_pods(P);
+}
+
+}  // namespace
+
+extern "C" {
+
+int trh_load(int argc, const char *const *argv, trh_problem **out, char *err, int errlen)
+{
+  if (!out) return TRX_E_ARG;
+  trh_problem *P = new trh_problem();
+  try { load(*P, argc, argv); }
+  catch (const Fail &f) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", f.what());
+    delete P; return f.code;
+  }
+  catch (const std::exception &e) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what());
+    delete P; return TRX_E_NOMEM;
+  }
+  *out = P;
+  return TRX_OK;
+}
+
+void trh_free(trh_problem *p) { delete p; }
+const trx_static *trh_static(const trh_problem *p) { return p ? &p->st : nullptr; }
+const trx_atm *trh_atm(const trh_problem *p) { return p ? &p->atm : nullptr; }
+const trx_opts *trh_opts(const trh_problem *p) { return p ? &p->opts : nullptr; }
+int64_t trh_nwn(const trh_problem *p) { return p ? p->nwn : 0; }
+void trh_wavenumbers(const trh_problem *p, double *out)
+{ if (p && out) for (int64_t k = 0; k < p->nwn; k++) out[k] = p->wn_i + (double)k * p->wn_d; }
+void trh_set_shard(trh_problem *p, int64_t lo, int64_t hi)
+{ if (p) { p->st.wn_lo = lo; p->st.wn_hi = hi; } }
+
+int trh_reload_atm(trh_problem *p, const double *input, int n)
+{
+  if (!p || !input) return TRX_E_ARG;
+  const size_t nl = p->a_rad.size(), nm = p->species.size();
+  if ((size_t)n != (1 + nm) * nl) return TRX_E_ARG;
+  try {
+    for (size_t i = 0; i < nl; i++) p->a_t[i] = input[i];
+    for (size_t j = 0; j < nm; j++) for (size_t i = 0; i < nl; i++) p->a_q[j][i] = input[nl * (j + 1) + i];
+    for (size_t i = 0; i < nl; i++) layer_state(*p, i);
+    if (p->p0 == 0 || p->r0 == 0 || p->gsurf == 0)
+      throw Fail(TRX_E_ARG, "refpress, refradius and gsurf must be defined to reload an atmosphere");
+    hydrostatic_radii(*p);
+    make_layer_sampling(*p);
+    fill_pods(*p);
+  } catch (const Fail &f) { p->err = f.what(); return f.code; }
+  return TRX_OK;
+}
+void trh_set_radius(trh_problem *p, double r) { if (p) p->r0 = r; }
+void trh_set_cloudtop(trh_problem *p, double c)
+{ if (p) { p->opts.cloud_top = c; p->opts.cloud_bot = c + 10; p->opts.cloud_ext = 100; p->opts.cloud_flag = 1; } }
+void trh_set_scattering(trh_problem *p, int flag, double logext)
+{ if (p) { p->opts.scat_flag = flag; p->opts.scat_logext = logext; } }
+
+const char *trh_option(const trh_problem *p, const char *name)
+{
+  if (!p || !name) return nullptr;
+  auto it = p->opt.find(name);
+  return it == p->opt.end() ? nullptr : it->second.c_str();
+}
+
+int trh_write_spectrum(const trh_problem *p, const double *sp, const char *path)
+{
+  if (!p || !sp) return TRX_E_ARG;
+  std::string f = path ? std::string(path) : join_path(p->base_dir, str(*p, "outspec"));
+  FILE *out = (f.empty() || f[0] == '-') ? stdout : std::fopen(f.c_str(), "w");
+  if (!out) return TRX_E_ARG;
+  if (p->opts.solution == TRX_SOL_ECLIPSE) {                 // eclipse.c:370-375
+    std::fprintf(out, "#wvl [um]%*sFlux [erg/s/cm]\n", 6, " ");
+    for (int64_t k = 0; k < p->nwn; k++)
+      std::fprintf(out, "%-15.10g%-18.9g\n", 1e4 / ((p->wn_i + (double)k * p->wn_d) / 1.0), sp[k]);
+  } else {                                                  // slantpath.c:545-551
+    std::fprintf(out, "#wvl [um]        modulation\n");
+    for (int64_t k = 0; k < p->nwn; k++)
+      std::fprintf(out, "%-17.9g%-18.9g\n", 1 / ((p->wn_i + (double)k * p->wn_d) / 1.0 * 1e-4), sp[k]);
+  }
+  if (out != stdout) std::fclose(out);
+  return TRX_OK;
+}
+
+int trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *last, const char *path)
+{
+  if (!p || !tau || !last) return TRX_E_ARG;
+  std::string f = path ? std::string(path) : join_path(p->base_dir, str(*p, "outtoomuch"));
+  if (f.empty()) return TRX_OK;
+  FILE *out = f[0] == '-' ? stdout : std::fopen(f.c_str(), "w");
+  if (!out) return TRX_E_ARG;
+  const int64_t nr = (int64_t)p->rad.size();
+  std::fprintf(out, "# Wavelength   Max Optical   Radius at the    Radius\n"
+                    "   (microns)         depth   max depth (km)    index\n");
+  for (int64_t w = 0; w < p->nwn; w++) {                     // tau.c:634-638 (ips = reversed radii)
+    const double wn = p->wn_i + (double)w * p->wn_d;
+    std::fprintf(out, "%12.7f   %.5e     %12.4f     %04ld\n", 1.0 / wn * 1.0 * 1e4,
+                 tau[w * nr + last[w]], p->rad[(size_t)(nr - 1 - last[w])] * p->rad_fct / 1e5, (long)last[w]);
+  }
+  if (out != stdout) std::fclose(out);
+  return TRX_OK;
+}
+
+}  // extern "C"

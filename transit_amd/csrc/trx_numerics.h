@@ -1,0 +1,146 @@
+// trx_numerics.h -- small numerical building blocks shared by the host side
+// (g++) and the HIP kernels (hipcc).  Each routine reproduces the arithmetic of
+// the reference routine it names, operation for operation, so that discrete
+// decisions (nearest index, bracketing) and quadrature weights agree with it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TRX_HD __host__ __device__ __forceinline__
+#else
+#define TRX_HD inline
+#endif
+
+namespace trx {
+
+// physical constants, values of transit/include/constants_tr.h:35-63 (cgs)
+constexpr double kPi      = 3.141592653589793;
+constexpr double kAmu     = 1.66053886e-24;
+constexpr double kEc      = 4.8032068e-10;
+constexpr double kLs      = 2.99792458e10;
+constexpr double kMe      = 9.1093897e-28;
+constexpr double kKb      = 1.380658e-16;
+constexpr double kH       = 6.6260755e-27;
+constexpr double kAmagat  = 2.68678e19;
+constexpr double kSigCte  = kPi*kEc*kEc/kLs/kLs/kMe/kAmu;
+constexpr double kExpCte  = kH*kLs/kKb;
+constexpr double kSqrtLn2 = 0.83255461115769775635;
+constexpr double kDeg     = kPi/180.0;
+constexpr double kNavo    = 6.02214076e23;
+constexpr double kE0H2    = 4.911e-23;
+constexpr double kMicron  = 1e-4;
+constexpr double kSunRadius = 6.957e10;
+constexpr double kTliWfct = 1e-4;   // readlineinfo.c:6
+constexpr double kTliEfct = 1.0;    // readlineinfo.c:7
+
+// pu/src/iomisc.c:1088-1108 (binsearchapprox): nearest element by the
+// reference's bisection; lo/hi are inclusive search bounds as passed there.
+TRX_HD int nearest_index(const double *a, double v, int lo, int hi)
+{
+  while (hi - lo > 1) {
+    const int mid = (hi + lo) / 2;
+    if (a[mid] > v) hi = mid; else lo = mid;
+  }
+  if (hi - lo == 1)
+    return (fabs(a[hi] - v) < fabs(a[lo] - v)) ? hi : lo;
+  return lo;
+}
+
+// pu/src/numerical.c:16-45 (binsearchie)
+TRX_HD int bracket_ie(const double *a, long i, long f, double v)
+{
+  if (a[i] > v) return -1;
+  if (a[f] < v) return -2;
+  if (a[f] == v) return -5;
+  if (i == f && a[i] != v) return -3;
+  while (f - i > 1) {
+    const long m = (f + i) >> 1;
+    if (a[m] > v) f = m; else i = m;
+  }
+  return (int)i;
+}
+
+// pu/src/numerical.c:182-195 (interp_parab), scalar-argument form
+TRX_HD double parab3(double x0r, double x1r, double y0, double y1, double y2, double xr)
+{
+  const double dx = x1r - x0r;
+  const double x0 = x0r / dx;
+  const double my = y0 + y2 - 2*y1;
+  const double a  = my / (2.0 * dx * dx);
+  const double b  = (y2 - y1 - (x0 + 1.5) * my) / dx;
+  const double c  = y0 + x0 * (y2 - 4*y1 + 3*y0 + x0 * my) / 2.0;
+  return xr * xr * a + xr * b + c;
+}
+
+// pu/src/spline.c:12-48 + 186-206 (tri / spline_init).  Scratch arrays u, v of
+// length n are supplied by the caller (no allocation: usable in a kernel).
+// Strided access so that a kernel can keep column-major scratch.
+TRX_HD void spline_second_derivs(double *z, const double *x, const double *y, long n,
+                                 double *u, double *v, long zs = 1, long xs = 1, long ys = 1,
+                                 long us = 1)
+{
+  if (n > 2) {
+    const double h0 = x[1*xs] - x[0], h1 = x[2*xs] - x[1*xs];
+    const double b0 = (y[1*ys] - y[0]) / h0, b1 = (y[2*ys] - y[1*ys]) / h1;
+    u[1*us] = 2 * (h1 + h0);
+    v[1*us] = 6 * (b1 - b0);
+  }
+  for (long i = 2; i < n - 1; i++) {
+    const double hi  = x[(i+1)*xs] - x[i*xs], him = x[i*xs] - x[(i-1)*xs];
+    const double bi  = (y[(i+1)*ys] - y[i*ys]) / hi, bim = (y[i*ys] - y[(i-1)*ys]) / him;
+    u[i*us] = 2*(hi + him) - him*him/u[(i-1)*us];
+    v[i*us] = 6*(bi - bim) - v[(i-1)*us]*him/u[(i-1)*us];
+  }
+  z[0] = 0; z[(n-1)*zs] = 0;
+  for (long i = n - 2; i > 0; i--) {
+    const double hi = x[(i+1)*xs] - x[i*xs];
+    z[i*zs] = (v[i*us] - hi*z[(i+1)*zs]) / u[i*us];
+  }
+}
+
+// bracketing rule shared by splinterp_pt and spline3 (spline.c:76-80, 151-155)
+TRX_HD int spline_interval(const double *x, long n, double xo, long xs = 1)
+{
+  // nearest_index on a strided array
+  int lo = 0, hi = (int)n - 1;
+  while (hi - lo > 1) {
+    const int mid = (hi + lo) / 2;
+    if (x[mid*xs] > xo) hi = mid; else lo = mid;
+  }
+  int k = lo;
+  if (hi - lo == 1) k = (fabs(x[hi*xs] - xo) < fabs(x[lo*xs] - xo)) ? hi : lo;
+  if (k == n - 1 || xo < x[k*xs]) k--;
+  return k;
+}
+
+// pu/src/spline.c:131-183 (splinterp_pt): Horner form
+TRX_HD double spline_eval_pt(const double *z, long n, const double *x, const double *y, double xo,
+                             long zs = 1, long xs = 1, long ys = 1)
+{
+  const int k = spline_interval(x, n, xo, xs);
+  const double xl = x[k*xs], xh = x[(k+1)*xs], yl = y[k*ys], yh = y[(k+1)*ys];
+  const double h = xh - xl, dy = yh - yl;
+  if (xl == xo) return yl;
+  if (h > 0) {
+    const double dx = xo - xl;
+    const double zk = z[k*zs], zk1 = z[(k+1)*zs];
+    const double a = (zk1 - zk) / (6*h);
+    const double b = 0.5 * zk;
+    const double c = dy/h - h/6 * (zk1 + 2*zk);
+    return yl + dx*(c + dx*(b + dx*a));
+  }
+  return 0;
+}
+
+// pu/src/spline.c:55-91 (spline3): power form used by splinterp()
+TRX_HD double spline_eval_pow(const double *z, long n, const double *x, const double *y, double xo)
+{
+  const int k = spline_interval(x, n, xo);
+  const double h = x[k+1] - x[k];
+  const double B = (y[k+1] - y[k]) / h - h/6 * (z[k+1] + 2 * z[k]);
+  const double d = xo - x[k];
+  return y[k] + d * B + pow(d, 2) * 0.5*z[k] + pow(d, 3) * (z[k+1] - z[k]) / (6*h);
+}
+
+}  // namespace trx

@@ -1,0 +1,153 @@
+"""The spectrum engine: thin ctypes binding of the C ABI in include/transit_hip.h.
+
+`Engine` is the MI355X product path (libtransit_hip.so, hand-written HIP).  It
+never falls back to anything else: if the HIP library is missing or no gfx950
+device is usable it raises.  `CEngine` is the ABI-shaped binding itself and
+serves any library exporting the same create/run/destroy family.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _abi
+from .build import lib_path
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        super().__init__("%s failed: %s (%d) %s" % (where, _abi.STATUS.get(code, "?"), code, detail))
+        self.code = code
+
+
+class CEngine:
+    """create/run/destroy over one handle of an ABI-shaped library."""
+
+    def __init__(self, lib, prefix: str, static: _abi.TrxStatic):
+        self._lib, self._p = lib, prefix
+        self._h = C.c_void_p()
+        self.nwn_total = int(static.nwn)
+        self.lo, self.hi = int(static.wn_lo), int(static.wn_hi)
+        self.ndop, self.nlor = int(static.ndop), int(static.nlor)
+        rc = self._f("create")(C.byref(static), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise EngineError(rc, prefix + "create", self._last_error())
+
+    def _f(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _last_error(self) -> str:
+        fn = getattr(self._lib, self._p + "last_error", None)
+        if fn is None or not self._h:
+            return ""
+        fn.argtypes, fn.restype = [C.c_void_p], C.c_char_p
+        v = fn(self._h)
+        return v.decode(errors="replace") if v else ""
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._f("destroy")(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def nwn(self) -> int:
+        return self.hi - self.lo if self._p == "trx_" else self.nwn_total
+
+    def run(self, atm: _abi.TrxAtm, opts: _abi.TrxOpts, debug: bool = False,
+            n_out: Optional[int] = None) -> Dict[str, np.ndarray]:
+        n = n_out if n_out is not None else self.nwn
+        nl, na = int(atm.nlayer), max(int(opts.nangles), 1)
+        out = {"spectrum": np.zeros(n)}
+        dbg = None
+        if debug:
+            out.update(e=np.zeros((nl, n)), e_cs=np.zeros((nl, n)), tau=np.zeros((n, nl)),
+                       last=np.zeros(n, dtype=np.int64), intens=np.zeros((na, n)),
+                       computed=np.zeros(nl, dtype=np.uint8))
+            dbg = _abi.TrxDebug(out["e"].ctypes.data_as(_abi.c_double_p),
+                                out["e_cs"].ctypes.data_as(_abi.c_double_p),
+                                out["tau"].ctypes.data_as(_abi.c_double_p),
+                                out["last"].ctypes.data_as(_abi.c_int64_p),
+                                out["intens"].ctypes.data_as(_abi.c_double_p),
+                                out["computed"].ctypes.data_as(_abi.c_uint8_p))
+        rc = self._f("run")(self._h, C.byref(atm), C.byref(opts),
+                            out["spectrum"].ctypes.data_as(_abi.c_double_p),
+                            C.byref(dbg) if dbg is not None else None)
+        if rc != 0:
+            raise EngineError(rc, self._p + "run", self._last_error())
+        return out
+
+    def stats(self) -> Dict[str, float]:
+        s = _abi.TrxStats()
+        rc = self._f("get_stats")(self._h, C.byref(s))
+        if rc != 0:
+            raise EngineError(rc, self._p + "get_stats")
+        return s.as_dict()
+
+    def table(self):
+        """(profsize[ndop,nlor], offset[ndop,nlor], floats[total])"""
+        n = self.ndop * self.nlor
+        ps, off = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        tot = C.c_int64()
+        rc = self._f("table_info")(self._h, ps.ctypes.data_as(_abi.c_int64_p),
+                                   off.ctypes.data_as(_abi.c_int64_p), C.byref(tot))
+        if rc != 0:
+            raise EngineError(rc, self._p + "table_info")
+        tab = np.zeros(tot.value, dtype=np.float32)
+        rc = self._f("table_copy")(self._h, tab.ctypes.data_as(_abi.c_float_p))
+        if rc != 0:
+            raise EngineError(rc, self._p + "table_copy")
+        return ps.reshape(self.ndop, self.nlor), off.reshape(self.ndop, self.nlor), tab
+
+    def width_grids(self):
+        d, l = np.zeros(self.ndop), np.zeros(self.nlor)
+        rc = self._f("width_grids")(self._h, d.ctypes.data_as(_abi.c_double_p),
+                                    l.ctypes.data_as(_abi.c_double_p))
+        if rc != 0:
+            raise EngineError(rc, self._p + "width_grids")
+        return d, l
+
+
+_hip = None
+
+
+def hip_library():
+    """Load libtransit_hip.so or raise -- there is no CPU fallback."""
+    global _hip
+    if _hip is None:
+        path = lib_path("libtransit_hip.so")
+        if not os.path.exists(path):
+            raise RuntimeError("HIP extension %s is missing; build it with "
+                               "`python -m transit_amd.build` (hipcc --offload-arch=gfx950)" % path)
+        lib = C.CDLL(path)
+        _abi.bind_engine_api(lib, "trx_")
+        lib.trx_run_device.argtypes = [C.c_void_p, C.POINTER(_abi.TrxAtm), C.POINTER(_abi.TrxOpts),
+                                       C.c_void_p, C.POINTER(_abi.TrxDebug)]
+        lib.trx_run_device.restype = C.c_int
+        lib.trx_device_count.restype = C.c_int
+        lib.trx_abi_version.restype = C.c_int
+        if lib.trx_abi_version() != _abi.ABI_VERSION:
+            raise RuntimeError("libtransit_hip.so ABI %d != binding %d" % (lib.trx_abi_version(), _abi.ABI_VERSION))
+        _hip = lib
+    return _hip
+
+
+class Engine(CEngine):
+    """MI355X engine: one handle = one GPU = one wavenumber shard."""
+
+    def __init__(self, static: _abi.TrxStatic):
+        super().__init__(hip_library(), "trx_", static)
+
+    def run_device(self, atm, opts, d_spectrum_ptr: int):
+        rc = self._lib.trx_run_device(self._h, C.byref(atm), C.byref(opts), C.c_void_p(d_spectrum_ptr), None)
+        if rc != 0:
+            raise EngineError(rc, "trx_run_device", self._last_error())
+
+
+def device_count() -> int:
+    return int(hip_library().trx_device_count())
