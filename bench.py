@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the CH4-demo-shaped emission spectrum (BASELINE.json
+configs[1]): 2500-5000 cm-1 at 1 cm-1 (2501 points, wnosamp 2160), 100 layers,
+10^6 synthetic CH4 lines, 60x60 Voigt grid, H2-H2 CIA, eclipse geometry with
+five angles -- one "step" = one full spectrum (trx_run: CIA + line sweep +
+optical depth + intensities + flux) with the line list, grids and Voigt table
+already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  metric = wavenumber-points x layers / s where
+"layers" is the number of layers the reference's lazy sweep needs for this
+input (deepest toomuch crossing), as in BASELINE.md.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lines", type=int, default=1_000_000)
+    ap.add_argument("--layers", type=int, default=100)
+    ap.add_argument("--wnlow", type=float, default=2500.0)
+    ap.add_argument("--wnhigh", type=float, default=5000.0)
+    ap.add_argument("--wnosamp", type=int, default=2160)
+    ap.add_argument("--layer-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = full workload)")
+    return ap.parse_args()
+
+
+def make_workload(args, tag, nlines):
+    from transit_amd import synth
+    d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%d" % (tag, nlines, args.layers, os.getpid()))
+    synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=args.wnhigh, wndelt=1.0, wnosamp=args.wnosamp,
+                    nlayers=args.layers, solution="eclipse", toomuch=10.0, ethresh=1e-50, nwidth=20.0,
+                    raygrid="0 20 40 60 80", ncia=1, seed=1234)
+    return d
+
+
+def cpu_baseline(args, gpu_spectrum_full):
+    """Time the CPU path on this box's host cores (one thread: the reference is
+    single-threaded).  Prefers the real reference binary (oracle/_ref/transit,
+    built from the reference sources by oracle/Makefile); falls back to our C
+    restatement.  Test infrastructure, used here only as the baseline/checker."""
+    nlines = args.cpu_lines or args.lines
+    d = make_workload(args, "cpu", nlines)
+    ref = os.path.join(ROOT, "oracle", "_ref", "transit")
+    out = {"cores": 1, "unit": "wavenumber-points*layers/s"}
+    if os.path.exists(ref) and os.access(ref, os.X_OK):
+        t0 = time.time()
+        p = subprocess.run([ref, "-c", "case.cfg"], cwd=d, capture_output=True, text=True)
+        wall = time.time() - t0
+        if p.returncode == 0:
+            stage = {}
+            for m in re.finditer(r"Check point: \d+ - (\d+) ([^:]+):\s+dt = ([0-9.]+) sec", p.stdout):
+                stage.setdefault(m.group(2).strip(), 0.0)
+                stage[m.group(2).strip()] += float(m.group(3))
+            t_path = sum(v for k, v in stage.items() if k in ("makeipsample", "interpcs", "idxrefrac", "extwn",
+                                                              "tau eclipse", "emergent intensity", "flux"))
+            t_table = stage.get("opacity", 0.0)
+            tm = np.loadtxt(os.path.join(d, "toomuch.dat"), comments="#", skiprows=2)
+            layers = int(tm[:, 3].max()) + 1
+            spec = np.loadtxt(os.path.join(d, "spectrum.dat"), comments="#")[:, 1]
+            out.update(kind="reference", value=len(spec) * layers / t_path, seconds=t_path,
+                       seconds_voigt_table=t_table, seconds_wall=wall, layers=layers,
+                       sample="full workload: %d lines x %d layers, spectrum path = reference stages "
+                              "interpcs..flux (its own timers), Voigt table %.2f s excluded" % (nlines, args.layers, t_table))
+            if gpu_spectrum_full is not None and nlines == args.lines and len(spec) == len(gpu_spectrum_full):
+                out["gpu_vs_reference_max_rel"] = float(np.max(np.abs(gpu_spectrum_full / spec - 1)))
+            return out
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from transit_amd.host import Problem
+    nl = min(nlines, 200_000)
+    d = make_workload(args, "cpuport", nl)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    eng = ol.OracleEngine(P.static)
+    t0 = time.time()
+    r = eng.run(P.atm, P.opts, debug=True)
+    t = time.time() - t0
+    layers = int(r["last"].max()) + 1
+    out.update(kind="port", value=P.nwn * layers / t, seconds=t, layers=layers,
+               sample="%d of %d lines x %d layers (CPU cost is linear in lines)" % (nl, args.lines, args.layers))
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+
+    from transit_amd.host import Problem
+    from transit_amd.engine import Engine
+    from transit_amd.shard import shard_bounds
+
+    d = make_workload(args, "r%d" % rank, args.lines)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    nwn, nlayer = P.nwn, P.nlayer
+    lo, hi = shard_bounds(nwn, world, rank)
+    P.set_shard(lo, hi)
+    st = P.static
+    st.device = local
+    t0 = time.time()
+    eng = Engine(st)
+    t_create = time.time() - t0
+    opts = P.opts
+    opts.layer_chunk = args.layer_chunk
+    opts.profile = 0
+
+    spec_local = torch.zeros(hi - lo, dtype=torch.float64, device=dev)
+    counts = [shard_bounds(nwn, world, r)[1] - shard_bounds(nwn, world, r)[0] for r in range(world)]
+    gathered = [torch.zeros(c, dtype=torch.float64, device=dev) for c in counts] if world > 1 else None
+
+    def step():
+        eng.run_device(P.atm, opts, spec_local.data_ptr())
+        if world > 1:
+            dist.all_gather(gathered, spec_local)            # the single RCCL gather of the path
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_step = 1e3 * elapsed / args.steps
+
+    # one profiled run for the per-kernel event timings and the counters
+    opts.profile = 1
+    r = eng.run(P.atm, opts, debug=True)
+    opts.profile = 0
+    stats = eng.stats()
+    layers_needed = int(r["last"].max()) + 1
+    if world > 1:
+        t = torch.tensor([layers_needed], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        layers_needed = int(t.item())
+        full = torch.cat(gathered).cpu().numpy()
+    else:
+        full = spec_local.cpu().numpy()
+
+    if rank == 0:
+        L, R, nang = stats["nlines_inrange"], stats["layers_swept"], int(opts.nangles)
+        launches = max(int(stats["sweep_launches"]), 1)
+        kern = {"k_line_strength": stats["ms_k_line"], "k_group_strength": stats["ms_k_group"],
+                "k_accumulate": stats["ms_k_accum"]}
+        dom = max(kern, key=kern.get)
+        # algorithmic bytes of the reference's data flow: 26 B per
+        # line per layer per pass; 4 B per accumulated bin + 8 B per stored e
+        alg = {"k_line_strength": 26.0 * L * R, "k_group_strength": 26.0 * L * R,
+               "k_accumulate": 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
+        ach = alg[dom] / launches / (kern[dom] / launches * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        b_alg_run = 52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * nwn + 8.0 * nwn * (1 + nang)
+        out = {
+            "metric": "wavenumber-points*layers/sec (CH4 2-4um emission spectrum)",
+            "value": nwn * layers_needed / (ms_step * 1e-3),
+            "unit": "wavenumber-points*layers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]): %g-%g cm-1 @1 cm-1, wnosamp %d, "
+                                   "eclipse, 5 angles, H2-H2 CIA" % (args.wnlow, args.wnhigh, args.wnosamp),
+                       "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
+                       "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
+                       "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
+                       "parallelism": "wn-shard x%d" % world,
+                       "ms_create_total": 1e3 * t_create, "ms_create_voigt_table_kernels": stats["ms_create_table"],
+                       "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
+                       "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],
+                       "b_alg_run_bytes": b_alg_run,
+                       "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
+                         "launches": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, full)
+            except Exception as e:          # the baseline must never sink the measurement
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,7 @@ typedef struct {
   /* execution knobs (no effect on results)                                    */
   int32_t layer_chunk;    /* layers swept per top-down step; 0 = default       */
   int32_t eager;          /* 1 = sweep every layer (debug dumps of all layers) */
+  int32_t profile;        /* 1 = bracket every kernel with HIP events (trx_stats timings) */
 } trx_opts;
 
 /* Optional intermediate outputs (host buffers, any may be NULL).  They mirror
@@ -173,8 +174,10 @@ typedef struct {
   double  ms_create_table;/* device time of the Voigt-table build              */
   double  ms_run_total;   /* device time of the last run, first to last kernel */
   double  ms_sweep;       /* line-sweep kernels (pass 1 + pass 2 + accumulate) */
-  double  ms_sweep_kernel_avg; /* mean duration of the dominant sweep kernel   */
-  int64_t sweep_launches;
+  double  ms_k_line;      /* sum over launches of k_line_strength              */
+  double  ms_k_group;     /* sum over launches of k_group_strength             */
+  double  ms_k_accum;     /* sum over launches of k_accumulate                 */
+  int64_t sweep_launches; /* launches of each sweep kernel that did work       */
   double  ms_tau;         /* optical-depth kernels                             */
   double  ms_cia;
   double  ms_spectrum;    /* intensity/flux or modulation                      */

@@ -323,10 +323,14 @@ static int build_table(trxo_handle *h)
 {
   const trx_static *s = &h->st;
   const int nd = s->ndop, nl = s->nlor;
-  h->adop = malloc(sizeof(double)*nd);
-  h->alor = malloc(sizeof(double)*nl);
+  /* one sentinel past the end: the reference searches with hi = nDop / nLor
+   * (extinction.c:393-394, 482), i.e. may compare against the element after
+   * the array; +inf makes that comparison pick the last real sample. */
+  h->adop = malloc(sizeof(double)*(nd+1));
+  h->alor = malloc(sizeof(double)*(nl+1));
   logspace((double)s->dmin, (double)s->dmax, nd, h->adop);
   logspace((double)s->lmin, (double)s->lmax, nl, h->alor);
+  h->adop[nd] = HUGE_VAL; h->alor[nl] = HUGE_VAL;
   h->psize = calloc((size_t)nd*nl, sizeof(int64_t));
   h->poff  = calloc((size_t)nd*nl, sizeof(int64_t));
   const double dwn = s->wn_d / s->osamp;

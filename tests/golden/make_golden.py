@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Regenerate the golden fixtures: synthetic inputs -> compiled reference -> outputs.
+
+Run in the build container only (needs oracle/_ref/transit, built by
+`make -C oracle ref` from the reference sources where they lie).  Each case
+directory holds the inputs (cfg, atmosphere, TLI, CIA, molecules) and what the
+reference wrote for them: spectrum.dat, toomuch.dat and the --savefiles dumps
+tau.dat / mol_extion.dat / CIA.dat (tau.c:180-190, 293-329).  Only data is
+kept; no reference source or binary enters the repository.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from transit_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "transit")
+
+KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "cia_h2he.dat",
+        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "total_extion.dat"]
+
+CASES = {
+    # demo-shaped emission run, narrow band
+    "eclipse_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="eclipse"),
+    # transmission geometry, two CIA tables
+    "transit_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="transit", ncia=2,
+                          seed=4321),
+    # coarse fine-grid + high threshold: co-adding, skipped lines, sticky Doppler index
+    "coadd_thresh": dict(nlines=20000, wnlow=2500, wnhigh=2540, nlayers=24, wnosamp=24, ethresh=1e-6,
+                         solution="eclipse", seed=99, toomuch=8.0),
+    # grey cloud deck + Rayleigh-like scattering, lines reaching beyond the band edges
+    "cloud_scatter": dict(nlines=2000, wnlow=3000, wnhigh=3040, nlayers=40, solution="transit",
+                          seed=7, line_margin=3.0,
+                          extra={"cloudtop": "-2.0", "scattering": "1.5"}),
+    # opaque-disc modulation level and a transparent planet, odd layer count
+    "transit_modm1": dict(nlines=4000, wnlow=4000, wnhigh=4030, nlayers=31, solution="transit", seed=11,
+                          toomuch=5.0, extra={"modlevel": "-1"}),
+}
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/transit is missing: run `make -C oracle ref` first")
+    for name, kw in CASES.items():
+        d = os.path.join(HERE, name)
+        tmp = d + ".tmp"
+        shutil.rmtree(tmp, ignore_errors=True)
+        kw = dict(kw)
+        extra = dict(kw.pop("extra", {}))
+        extra.update({"savefiles": "yes"})
+        synth.make_case(tmp, extra=extra, **kw)
+        log = subprocess.run([REF, "-c", "case.cfg"], cwd=tmp, capture_output=True, text=True)
+        if log.returncode != 0:
+            sys.exit("reference failed on %s:\n%s\n%s" % (name, log.stdout[-2000:], log.stderr[-2000:]))
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        for f in KEEP:
+            if os.path.exists(os.path.join(tmp, f)):
+                shutil.copy(os.path.join(tmp, f), os.path.join(d, f))
+        shutil.rmtree(tmp)
+        print("%-16s -> %s" % (name, ", ".join(sorted(os.listdir(d)))))
+
+
+if __name__ == "__main__":
+    main()

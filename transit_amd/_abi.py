@@ -58,7 +58,7 @@ class TrxOpts(C.Structure):
         ("cloud_bot", C.c_double), ("cloud_gamma", C.c_double), ("cloud_Q", C.c_double),
         ("cloud_r", C.c_double), ("cloud_sig", C.c_double), ("cloud_refwn", C.c_double),
         ("scat_flag", C.c_int32), ("scat_logext", C.c_double),
-        ("layer_chunk", C.c_int32), ("eager", C.c_int32),
+        ("layer_chunk", C.c_int32), ("eager", C.c_int32), ("profile", C.c_int32),
     ]
 
 
@@ -73,7 +73,8 @@ class TrxStats(C.Structure):
         ("layers_swept", C.c_int64), ("neval", C.c_int64), ("nskip", C.c_int64),
         ("sum_bins", C.c_int64), ("table_floats", C.c_int64),
         ("ms_create_table", C.c_double), ("ms_run_total", C.c_double), ("ms_sweep", C.c_double),
-        ("ms_sweep_kernel_avg", C.c_double), ("sweep_launches", C.c_int64),
+        ("ms_k_line", C.c_double), ("ms_k_group", C.c_double), ("ms_k_accum", C.c_double),
+        ("sweep_launches", C.c_int64),
         ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_spectrum", C.c_double),
     ]
 

@@ -1,0 +1,759 @@
+// trx_api.hip -- C ABI of include/transit_hip.h on top of the gfx950 kernels.
+//
+// Host responsibilities (all layer- or geometry-only, O(N) or O(N^2) scalars):
+//   * line-list preparation once per handle: wavenumbers, range flags, the
+//     greedy co-adding groups (extinction.c:449-462) and their fine-grid
+//     indices (:445-447) -- exact reference arithmetic, sequential by nature;
+//   * per-run layer prologue: broadening widths, nearest table indices,
+//     strength prefactors (extinction.c:364-395, 464, 473);
+//   * Simpson weights of the ray geometry (numerical.c:390-425);
+//   * CIA interpolation (crosssec.c:272-428) -- small; device version is the
+//     next step.
+// Everything per (line x layer), per (group x layer x bin) and per
+// (wavenumber x layer) runs in the kernels of trx_kernels.hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "transit_hip.h"
+#include "trx_kernels.hip.h"
+
+using namespace trx;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr; size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct trx_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // grids
+  double wn_i = 0, wn_d = 0, odwn = 0; int64_t nwn = 0, nown = 0, lo = 0, hi = 0, nsh = 0; int osamp = 1;
+  // isotopes / molecules (host copies)
+  int niso = 0, nmol = 0;
+  std::vector<double> iso_mass, iso_ratio, mol_mass, mol_radius, mol_pol;
+  std::vector<int32_t> iso_imol, mol_is_h2;
+  std::vector<double> iso_wmin, iso_wmax;          // anchor wavenumber range per isotope
+  // Voigt table
+  int ndop = 0, nlor = 0;
+  std::vector<double> adop, alor;                   // +1 sentinel
+  std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
+  DevBuf d_adop, d_psize, d_poff, d_tab;
+  // lines
+  int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
+  DevBuf d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
+  LinesDev L{};
+  // CIA (host copies)
+  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs; };
+  std::vector<Cia> cia;
+  // per-run workspaces (grown on demand)
+  int ws_nr = 0, ws_chunk = 0;
+  DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags;
+  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status;
+  trx_stats stats{};
+};
+
+namespace {
+
+int fail(trx_handle *h, int code, const std::string &msg)
+{ if (h) h->err = msg; return code; }
+
+#define HIPCHK(h, call)                                                              \
+  do { hipError_t e_ = (call);                                                       \
+       if (e_ != hipSuccess)                                                         \
+         return fail(h, e_ == hipErrorOutOfMemory ? TRX_E_NOMEM : TRX_E_HIP,         \
+                     std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+int ensure(trx_handle *h, DevBuf &b, size_t bytes)
+{
+  if (bytes == 0) bytes = 8;
+  if (b.bytes >= bytes) return TRX_OK;
+  b.release();
+  HIPCHK(h, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return TRX_OK;
+}
+
+template <class T>
+int upload(trx_handle *h, DevBuf &b, const std::vector<T> &v)
+{
+  int rc = ensure(h, b, v.size() * sizeof(T));
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(h, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return TRX_OK;
+}
+
+// pu/src/iomisc.c:1064-1083 (logspace)
+void logspace(double lo, double hi, int n, std::vector<double> &out)
+{
+  out.resize(n + 1);
+  const double l0 = std::log10(lo), l1 = std::log10(hi);
+  const double step = (l1 - l0) / (n - 1.0);
+  for (int i = 0; i < n; i++) out[i] = std::pow(10, l0 + i * step);
+  out[n] = HUGE_VAL;   // the reference searches with hi = n (extinction.c:393-394)
+}
+
+// ---- Voigt table plan: opacity.c:219-277 + extinction.c:8-57 ---------------
+int plan_table(trx_handle *h, const trx_static *s, std::vector<ProfileJob> &jobs)
+{
+  const int nd = s->ndop, nl = s->nlor;
+  logspace((double)s->dmin, (double)s->dmax, nd, h->adop);
+  logspace((double)s->lmin, (double)s->lmax, nl, h->alor);
+  h->psize.assign((size_t)nd * nl, 0); h->poff.assign((size_t)nd * nl, 0);
+  const double dwn = s->wn_d / s->osamp;
+  int64_t total = 0, bins = 0;
+  for (int i = 0; i < nd; i++)
+    for (int j = 0; j < nl; j++) {
+      const size_t k = (size_t)i * nl + j;
+      if (h->adop[i] * 10.0 < h->alor[j] && i != 0) {         // opacity.c:262-265
+        h->psize[k] = h->psize[k - nl]; h->poff[k] = h->poff[k - nl];
+        continue;
+      }
+      const float dop = (float)h->adop[i], lor = (float)h->alor[j];   // extinction.c:11-12
+      double big = dop; if (big < lor) big = lor;
+      const double wv = big * s->timesalpha;
+      int nv = 2 * (long)(wv / dwn + 0.5) + 1;
+      if (nv < 2) nv = 3;
+      if (nv > 2 * (int)s->nown) nv = 2 * (int)s->nown + 1;
+      if (nv < 0) return fail(h, TRX_E_ARG, "negative Voigt profile size");
+      ProfileJob J{};
+      J.off = total; J.nv = nv; J.alphaL = lor; J.alphaD = dop;
+      J.half = dwn * (long)(nv / 2);
+      const bool quick = nv > 99999;                            // voigt.c:109, extinction.c:51
+      // voigt.c:399-433
+      double step = 2.0 * J.half / (nv - 1);
+      int npts = 50; double sub = J.alphaD / (npts - 1);
+      if (step < sub || quick) { sub = step; J.regime = quick ? 0 : 1; J.m = 1; }
+      else {
+        npts = (int)(step / sub) + 1;
+        if (npts & 1) npts++;
+        J.m = npts; J.regime = 2;
+        const long long tot = (long long)nv * npts + 1;
+        if (tot > 2000000000LL) return fail(h, TRX_E_UNSUPPORTED, "Voigt sub-sampling exceeds int range");
+        sub = 2.0 * J.half / (double)(tot - 1);
+      }
+      J.sub = sub; J.first_bin = bins;
+      jobs.push_back(J);
+      h->psize[k] = nv / 2; h->poff[k] = total;
+      total += nv; bins += nv;
+    }
+  h->tab_n = total;
+  return TRX_OK;
+}
+
+int build_table(trx_handle *h, const trx_static *s)
+{
+  std::vector<ProfileJob> jobs;
+  int rc = plan_table(h, s, jobs);
+  if (rc) return rc;
+  // series coefficients 1/(n!(2n+1)), voigt.c:45-108
+  double coef[64]; long double fact = 1.0L;
+  for (int n = 0; n < 64; n++) { if (n > 0) fact *= (long double)n; coef[n] = (double)(1.0L / (fact * (long double)(2 * n + 1))); }
+  HIPCHK(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_voigt_coef), coef, sizeof(coef), 0, hipMemcpyHostToDevice, h->stream));
+  DevBuf d_jobs;
+  if ((rc = upload(h, d_jobs, jobs))) return rc;
+  if ((rc = ensure(h, h->d_tab, sizeof(float) * (size_t)h->tab_n))) return rc;
+  std::vector<int32_t> ps32(h->psize.begin(), h->psize.end());
+  if ((rc = upload(h, h->d_psize, ps32))) return rc;
+  if ((rc = upload(h, h->d_poff, h->poff))) return rc;
+  if ((rc = upload(h, h->d_adop, h->adop))) return rc;
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  const int m_limit = 64;
+  for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
+    const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
+    int maxnv = 0; bool any_wave = false;
+    for (int j = 0; j < nj; j++) { maxnv = std::max(maxnv, jobs[j0 + j].nv); any_wave |= (jobs[j0 + j].regime == 2 && jobs[j0 + j].m > m_limit); }
+    const int gx = std::max(1, std::min(64, (maxnv + 255) / 256));
+    hipLaunchKernelGGL(k_voigt_bins, dim3(gx, nj), dim3(256), 0, h->stream,
+                       d_jobs.as<ProfileJob>() + j0, h->d_tab.as<float>(), m_limit);
+    if (any_wave)
+      hipLaunchKernelGGL(k_voigt_bins_wave, dim3(std::max(1, std::min(256, maxnv)), nj), dim3(64), 0, h->stream,
+                         d_jobs.as<ProfileJob>() + j0, h->d_tab.as<float>(), m_limit);
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  h->stats.ms_create_table = ms;
+  h->stats.table_floats = h->tab_n;
+  return TRX_OK;
+}
+
+// ---- line list preparation --------------------------------------------------
+int prepare_lines(trx_handle *h, const trx_static *s)
+{
+  const int64_t n = s->nlines;
+  const double wn0 = s->wn_i, odwn = s->wn_d / s->osamp;
+  const double own_last = wn0 + (double)(s->nown - 1) * odwn;
+  auto own = [&](long long k) { return wn0 + (double)k * odwn; };
+  if (n > 2000000000LL) return fail(h, TRX_E_UNSUPPORTED, "more than 2^31 lines per handle");
+  std::vector<double> wavn((size_t)n);
+  std::vector<uint8_t> inr((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    if (s->isoid[i] < 0 || s->isoid[i] >= s->niso) return fail(h, TRX_E_ARG, "isotope id out of range");
+    wavn[i] = 1.0 / (s->wl_um[i] * kTliWfct);
+    inr[i] = !(wavn[i] < wn0 || wavn[i] > own_last);             // extinction.c:410
+    h->ninrange += inr[i];
+  }
+  // TLI order: isotope blocks in ascending id, wavelength ascending inside a
+  // block (pylineread.py:369-383); the gather kernel relies on it.
+  for (int64_t i = 1; i < n; i++) {
+    if (s->isoid[i] < s->isoid[i-1]) return fail(h, TRX_E_ORDER, "isotope blocks are not in ascending order");
+    if (s->isoid[i] == s->isoid[i-1] && wavn[i] > wavn[i-1])
+      return fail(h, TRX_E_ORDER, "wavelengths are not ascending inside an isotope block");
+  }
+  std::vector<int32_t> gfirst, gcount, giown; std::vector<int16_t> giso; std::vector<double> gwavn;
+  h->iso_wmin.assign(s->niso, HUGE_VAL); h->iso_wmax.assign(s->niso, 0.0);
+  for (int64_t ln = 0; ln < n; ln++) {
+    if (!inr[ln]) continue;
+    const double w = wavn[ln]; const int iso = s->isoid[ln];
+    int iown = (int)((w - wn0) / odwn);                          // extinction.c:445-447
+    if (std::fabs(w - own(iown + 1)) < std::fabs(w - own(iown))) iown++;
+    const int64_t first = ln;
+    while (ln != n - 1 && s->isoid[ln + 1] == iso) {             // extinction.c:449-462
+      if (std::fabs(wavn[ln + 1] - own(iown)) < odwn) { h->nadd++; ln++; }
+      else break;
+    }
+    gfirst.push_back((int32_t)first); gcount.push_back((int32_t)(ln - first + 1));
+    giown.push_back(iown); giso.push_back((int16_t)iso); gwavn.push_back(w);
+    h->iso_wmin[iso] = std::min(h->iso_wmin[iso], w); h->iso_wmax[iso] = std::max(h->iso_wmax[iso], w);
+  }
+  h->nlines = n; h->ngroups = (int64_t)gfirst.size();
+  // isotope blocks and the coarse-bin index over them
+  std::vector<int32_t> gblock(s->niso + 1, 0);
+  for (size_t g = 0; g < giso.size(); g++) gblock[giso[g] + 1]++;
+  for (int b = 0; b < s->niso; b++) gblock[b + 1] += gblock[b];
+  std::vector<int32_t> cntge((size_t)s->niso * (s->nwn + 1), 0);
+  for (size_t g = 0; g < giso.size(); g++) {
+    long long k = giown[g] / s->osamp;
+    if (k > s->nwn - 1) k = s->nwn - 1;
+    cntge[(size_t)giso[g] * (s->nwn + 1) + k]++;
+  }
+  for (int b = 0; b < s->niso; b++) {                             // suffix sums: groups with key >= k
+    int32_t *c = &cntge[(size_t)b * (s->nwn + 1)];
+    for (long long k = s->nwn - 1; k >= 0; k--) c[k] += c[k + 1];
+  }
+  for (size_t g = 1; g < giown.size(); g++)
+    if (giso[g] == giso[g-1] && giown[g] > giown[g-1])
+      return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
+
+  std::vector<double> elow(s->elow, s->elow + n), gf(s->gf, s->gf + n);
+  std::vector<int16_t> iso(s->isoid, s->isoid + n);
+  int rc;
+  if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_elow, elow)) || (rc = upload(h, h->d_gf, gf)) ||
+      (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
+      (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
+      (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
+    return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
+  LinesDev &L = h->L;
+  L.nlines = n; L.wavn = h->d_wavn.as<double>(); L.elow = h->d_elow.as<double>(); L.gf = h->d_gf.as<double>();
+  L.iso = h->d_iso.as<int16_t>(); L.inrange = h->d_inr.as<uint8_t>();
+  L.ngroups = h->ngroups; L.gfirst = h->d_gfirst.as<int32_t>(); L.gcount = h->d_gcount.as<int32_t>();
+  L.giown = h->d_giown.as<int32_t>(); L.giso = h->d_giso.as<int16_t>(); L.gwavn = h->d_gwavn.as<double>();
+  L.gblock = h->d_gblock.as<int32_t>(); L.cnt_ge = h->d_cntge.as<int32_t>();
+  h->stats.nlines_inrange = h->ninrange; h->stats.ngroups = h->ngroups; h->stats.nadd = h->nadd;
+  return TRX_OK;
+}
+
+// ---- CIA on the host: crosssec.c:272-344 + 354-428 --------------------------
+int cia_host(trx_handle *h, const trx_atm *a, const trx_opts *o, std::vector<double> &ecs /* [nr][nsh] */)
+{
+  const long nr = a->nlayer, nsh = (long)h->nsh;
+  ecs.assign((size_t)nr * nsh, 0.0);
+  if (h->cia.empty()) return TRX_OK;
+  double tmin = 0.0, tmax = 70000.0;
+  for (auto &c : h->cia) { tmin = std::fmax(tmin, c.temp.front()); tmax = std::fmin(tmax, c.temp.back()); }
+  for (long i = 0; i < nr; i++)
+    if (a->temp[i] < tmin || a->temp[i] > tmax) return fail(h, TRX_E_RANGE, "layer temperature outside the CIA tables");
+  std::vector<double> w(nsh);
+  for (long i = 0; i < nsh; i++) w[i] = o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d);
+  for (auto &c : h->cia) {
+    const long nx1 = (long)c.wn.size(), nx2 = (long)c.temp.size();
+    const double *x1 = c.wn.data(), *x2 = c.temp.data(), *t1 = w.data(), *t2 = a->temp;
+    const long nt1 = nsh, nt2 = nr;
+    const double fx1 = x1[0], fx2 = x2[0], lx1 = x1[nx1-1], lx2 = x2[nx2-1];
+    if (t1[0] > lx1 || t1[nt1-1] < fx1 || t2[0] > lx2 || t2[nt2-1] < fx2) continue;   // crosssec.c:376-377
+    long fi = 0, li = nt1, fj = 0, lj = nt2;
+    while (t1[fi] < fx1) fi++;
+    for (long i = 0; i < li; i++) if (t1[i] > lx1) li = i;
+    while (t2[fj] < fx2) fj++;
+    for (long j = 0; j < lj; j++) if (t2[j] > lx2) lj = j;
+    std::vector<double> z1(nx2), z2(nx1), u(std::max(nx1, nx2)), v(std::max(nx1, nx2)), mid((size_t)nt2 * nx1);
+    for (long i = 0; i < nx1; i++) {
+      spline_second_derivs(z1.data(), x2, &c.cs[(size_t)i * nx2], nx2, u.data(), v.data());
+      for (long j = fj; j < lj; j++)
+        mid[(size_t)j * nx1 + i] = spline_eval_pt(z1.data(), nx2, x2, &c.cs[(size_t)i * nx2], t2[j]);
+    }
+    for (long j = fj; j < lj; j++) {
+      double dens = 1.0;
+      for (int k = 0; k < c.nspec; k++) {
+        const int m = c.mol[k];
+        dens *= a->density[(size_t)m * nr + j] / (kAmu * h->mol_mass[m] * kAmagat);
+      }
+      spline_second_derivs(z2.data(), x1, &mid[(size_t)j * nx1], nx1, u.data(), v.data());
+      for (long i = fi; i < li; i++) {
+        const double val = spline_eval_pt(z2.data(), nx1, x1, &mid[(size_t)j * nx1], t1[i]);
+        if (val > 0) ecs[(size_t)j * nsh + i] += val * dens;
+      }
+    }
+  }
+  return TRX_OK;
+}
+
+// Simpson weights of one abscissa (numerical.c:390-425 geth, 486-495 makeh):
+// per interval pair {2-hratio, hfactor, 2-1/hratio, hsum}; h0 = first interval.
+void simpson_weights(const double *x, int n, double *row, double *h0)
+{
+  *h0 = (n >= 2) ? x[1] - x[0] : 0.0;
+  if (n < 3) return;
+  const int even = (n % 2 == 0);
+  for (int i = 0; i < (n - 1) / 2; i++) {
+    const int j = 2 * i + even;
+    const double ha = x[j+1] - x[j], hb = x[j+2] - x[j+1];
+    const double hsum = ha + hb, hratio = hb / ha, hfactor = hsum * hsum / (ha * hb);
+    row[4*i] = 2.0 - hratio; row[4*i+1] = hfactor; row[4*i+2] = 2.0 - 1.0 / hratio; row[4*i+3] = hsum;
+  }
+}
+
+// smallest wavenumber w for which alphad*w/alphal >= 0.1 holds in double
+// arithmetic (extinction.c:480); the predicate is monotone in w.
+double doppler_refresh_cut(double alphad, double alphal)
+{
+  auto cond = [&](double w) { return alphad * w / alphal >= 1e-1; };
+  double lo = 0.0, hi = 1e30;
+  if (!cond(hi)) return HUGE_VAL;
+  if (cond(std::nextafter(0.0, 1.0))) return 0.0;
+  while (std::nextafter(lo, hi) < hi) {
+    double mid = lo + (hi - lo) / 2;
+    if (mid <= lo || mid >= hi) mid = std::nextafter(lo, hi);
+    if (cond(mid)) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
+}  // namespace
+
+// ============================================================================
+extern "C" {
+
+int trx_abi_version(void) { return TRX_ABI_VERSION; }
+
+int trx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *trx_strerror(int st)
+{
+  switch (st) {
+    case TRX_OK: return "success";
+    case TRX_E_ARG: return "bad argument or inconsistent sizes";
+    case TRX_E_NOMEM: return "host or device allocation failed";
+    case TRX_E_HIP: return "HIP runtime call failed";
+    case TRX_E_NODEVICE: return "no usable gfx950 device";
+    case TRX_E_RANGE: return "value outside a table range";
+    case TRX_E_UNSUPPORTED: return "option combination not implemented";
+    case TRX_E_ORDER: return "line list is not sorted as the TLI format requires";
+    case TRX_E_NOTREACHED: return "optical depth never reached toomuch (modlevel -1)";
+  }
+  return "unknown status";
+}
+
+const char *trx_last_error(const trx_handle *h) { return h ? h->err.c_str() : ""; }
+
+int trx_create(const trx_static *s, trx_handle **out)
+{
+  if (!s || !out) return TRX_E_ARG;
+  *out = nullptr;
+  if (s->abi_version != TRX_ABI_VERSION) return TRX_E_ARG;
+  if (s->nwn < 2 || s->osamp < 1 || s->nown != (s->nwn - 1) * s->osamp + 1) return TRX_E_ARG;
+  if (s->ndop < 2 || s->nlor < 2 || s->ndop > kMaxDop) return TRX_E_UNSUPPORTED;
+  if (s->niso < 0 || s->niso > kMaxIso || s->nmol < 1) return TRX_E_UNSUPPORTED;
+  if (s->wn_lo < 0 || s->wn_hi > s->nwn || s->wn_lo >= s->wn_hi) return TRX_E_ARG;
+  if (s->nlines < 0 || (s->nlines > 0 && (!s->wl_um || !s->isoid || !s->elow || !s->gf))) return TRX_E_ARG;
+  if (s->nown > 2000000000LL) return TRX_E_UNSUPPORTED;     // iown/beg_j are int in the reference too
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || s->device < 0 || s->device >= ndev) return TRX_E_NODEVICE;
+  trx_handle *h = new (std::nothrow) trx_handle();
+  if (!h) return TRX_E_NOMEM;
+  h->device = s->device;
+  int rc = TRX_OK;
+  auto bail = [&](int code) { trx_destroy(h); return code; };
+  if (hipSetDevice(h->device) != hipSuccess) return bail(TRX_E_NODEVICE);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+  h->wn_i = s->wn_i; h->wn_d = s->wn_d; h->osamp = s->osamp; h->odwn = s->wn_d / s->osamp;
+  h->nwn = s->nwn; h->nown = s->nown; h->lo = s->wn_lo; h->hi = s->wn_hi; h->nsh = s->wn_hi - s->wn_lo;
+  h->niso = s->niso; h->nmol = s->nmol; h->ndop = s->ndop; h->nlor = s->nlor;
+  h->iso_mass.assign(s->iso_mass, s->iso_mass + s->niso);
+  h->iso_ratio.assign(s->iso_ratio, s->iso_ratio + s->niso);
+  h->iso_imol.assign(s->iso_imol, s->iso_imol + s->niso);
+  h->mol_mass.assign(s->mol_mass, s->mol_mass + s->nmol);
+  h->mol_radius.assign(s->mol_radius, s->mol_radius + s->nmol);
+  if (s->mol_pol) h->mol_pol.assign(s->mol_pol, s->mol_pol + s->nmol); else h->mol_pol.assign(s->nmol, 0.0);
+  if (s->mol_is_h2) h->mol_is_h2.assign(s->mol_is_h2, s->mol_is_h2 + s->nmol); else h->mol_is_h2.assign(s->nmol, 0);
+  for (int i = 0; i < s->niso; i++) if (s->iso_imol[i] < 0 || s->iso_imol[i] >= s->nmol) return bail(TRX_E_ARG);
+  for (int k = 0; k < s->ncia; k++) {
+    const trx_cia &c = s->cia[k];
+    if (c.nspec < 1 || c.nspec > 2 || c.nwave < 3 || c.ntemp < 3) return bail(TRX_E_ARG);
+    trx_handle::Cia t; t.nspec = c.nspec; t.mol[0] = c.mol[0]; t.mol[1] = c.mol[1];
+    t.wn.assign(c.wn, c.wn + c.nwave); t.temp.assign(c.temp, c.temp + c.ntemp);
+    t.cs.assign(c.cs, c.cs + (size_t)c.nwave * c.ntemp);
+    h->cia.push_back(std::move(t));
+  }
+  if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
+  if ((rc = prepare_lines(h, s)) != TRX_OK) { std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
+  *out = h;
+  return TRX_OK;
+}
+
+void trx_destroy(trx_handle *h)
+{
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  delete h;
+}
+
+int trx_get_stats(const trx_handle *h, trx_stats *out)
+{ if (!h || !out) return TRX_E_ARG; *out = h->stats; return TRX_OK; }
+
+int trx_table_info(const trx_handle *h, int64_t *ps, int64_t *off, int64_t *total)
+{
+  if (!h) return TRX_E_ARG;
+  const size_t n = (size_t)h->ndop * h->nlor;
+  if (ps)  for (size_t k = 0; k < n; k++) ps[k] = h->psize[k];
+  if (off) for (size_t k = 0; k < n; k++) off[k] = h->poff[k];
+  if (total) *total = h->tab_n;
+  return TRX_OK;
+}
+
+int trx_table_copy(const trx_handle *hc, float *out)
+{
+  trx_handle *h = const_cast<trx_handle *>(hc);
+  if (!h || !out) return TRX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(out, h->d_tab.p, sizeof(float) * (size_t)h->tab_n, hipMemcpyDeviceToHost));
+  return TRX_OK;
+}
+
+int trx_width_grids(const trx_handle *h, double *adop, double *alor)
+{
+  if (!h) return TRX_E_ARG;
+  if (adop) std::memcpy(adop, h->adop.data(), sizeof(double) * h->ndop);
+  if (alor) std::memcpy(alor, h->alor.data(), sizeof(double) * h->nlor);
+  return TRX_OK;
+}
+
+static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum,
+                    trx_debug *dbg)
+{
+  if (!h || !a || !o) return TRX_E_ARG;
+  const int nr = a->nlayer, niso = h->niso, nmol = h->nmol;
+  const int64_t nsh = h->nsh;
+  if (nr < 3) return fail(h, TRX_E_ARG, "at least three layers are needed");
+  if (o->solution != TRX_SOL_ECLIPSE && o->solution != TRX_SOL_TRANSIT) return fail(h, TRX_E_ARG, "unknown solution");
+  if (o->solution == TRX_SOL_ECLIPSE && (o->nangles < 1 || o->nangles > kMaxAngles || !o->angles_deg))
+    return fail(h, TRX_E_ARG, "eclipse needs 1..16 angles");
+  if (o->solution == TRX_SOL_TRANSIT && o->modlevel != 1 && o->modlevel != -1) return fail(h, TRX_E_UNSUPPORTED, "modlevel must be 1 or -1");
+  if (!(o->ethresh > 0)) return fail(h, TRX_E_ARG, "ethresh must be positive");
+  if ((o->cloud_flag >= 2 || o->scat_flag == 2) && !a->abund && o->cloud_flag >= 2) return fail(h, TRX_E_ARG, "cloud model needs abundances");
+  for (int i = 1; i < nr; i++) if (!(a->radius[i] > a->radius[i-1])) return fail(h, TRX_E_ARG, "radii must ascend");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 8;
+  nc_max = std::max(3, std::min(nc_max, kMaxChunk));
+  const bool eager = o->eager != 0, prof = o->profile != 0;
+  int rc;
+
+  // ---- layer prologue (extinction.c:364-395) --------------------------------
+  const size_t nli = (size_t)nr * std::max(niso, 1);
+  std::vector<double> f64(7 * nli + 8 * (size_t)nr, 0.0);
+  double *negct = &f64[0], *strength = negct + nr, *dens = strength + nli, *alphad = dens + nli,
+         *alphal = alphad + nli, *wcut = alphal + nli, *pad0 = wcut + nli;
+  (void)pad0;
+  std::vector<int32_t> i32(3 * nli, 0);
+  int32_t *idop0 = &i32[0], *ilor = idop0 + nli, *psmax = ilor + nli;
+  for (int r = 0; r < nr; r++) {
+    const double temp = a->temp[r];
+    if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
+    negct[r] = -kExpCte * kTliEfct / temp;
+    const double fdoppler = std::sqrt(2 * kKb * temp / kAmu) * kSqrtLn2 / kLs;
+    const double florentz = std::sqrt(2 * kKb * temp / kPi / kAmu) / (kAmu * kLs);
+    for (int i = 0; i < niso; i++) {
+      double al = 0.0;
+      for (int j = 0; j < nmol; j++) {
+        const double csd = h->mol_radius[j] + h->mol_radius[h->iso_imol[i]];
+        al += a->density[(size_t)j * nr + r] / h->mol_mass[j] * csd * csd *
+              std::sqrt(1 / h->iso_mass[i] + 1 / h->mol_mass[j]);
+      }
+      al *= florentz;
+      const double ad = fdoppler / std::sqrt(h->iso_mass[i]);
+      const size_t k = (size_t)r * niso + i;
+      alphal[k] = al; alphad[k] = ad;
+      idop0[k] = nearest_index(h->adop.data(), ad * h->wn_i, 0, h->ndop);
+      ilor[k]  = nearest_index(h->alor.data(), al, 0, h->nlor);
+      strength[k] = kSigCte * h->iso_ratio[i] / (h->iso_mass[i] * a->zpart[(size_t)i * nr + r]);
+      dens[k] = a->density[(size_t)h->iso_imol[i] * nr + r];
+      wcut[k] = doppler_refresh_cut(ad, al);
+      int dlo = idop0[k], dhi = idop0[k];
+      if (h->iso_wmax[i] > 0) {
+        const int a0 = nearest_index(h->adop.data(), ad * h->iso_wmin[i], 0, h->ndop);
+        const int a1 = nearest_index(h->adop.data(), ad * h->iso_wmax[i], 0, h->ndop);
+        dlo = std::min(dlo, std::min(a0, a1)); dhi = std::max(dhi, std::max(a0, a1));
+      }
+      int32_t pm = 0;
+      for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
+      psmax[k] = pm;
+    }
+  }
+  // layer-only scalars of the scattering / cloud models (tau.c:193-214, extinction.c:617-621)
+  double *press = &f64[7 * nli], *tempk = press + nr, *mdens = tempk + nr, *nH = mdens + nr,
+         *scat_pol = nH + nr, *radv = scat_pol + nr;
+  for (int r = 0; r < nr; r++) {
+    press[r] = a->press ? a->press[r] : 0.0; tempk[r] = a->temp[r]; radv[r] = a->radius[r];
+    double mm = 0, md = 0, sp = 0;
+    for (int j = 0; j < nmol; j++) {
+      const double d = a->density[(size_t)j * nr + r];
+      if (a->abund) {
+        const double q = a->abund[(size_t)j * nr + r];
+        md += d / h->mol_mass[j] * q;
+        if (h->mol_is_h2[j]) nH[r] = d / h->mol_mass[j] * q * kNavo;
+        mm += h->mol_mass[j] * q;
+      }
+      sp += kPi * 8e-32 / 3. * std::pow(h->mol_pol[j], 2) * d / h->mol_mass[j] * kNavo;
+    }
+    mdens[r] = md * mm; scat_pol[r] = sp;
+  }
+
+  // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
+  const int gstride = 4 * (nr / 2 + 1);
+  std::vector<double> geom((size_t)(nr + 1) * gstride * 2 + 2 * (size_t)(nr + 1), 0.0);
+  double *gw = &geom[0], *gh0 = gw + (size_t)(nr + 1) * gstride;
+  double *mw = gh0 + (nr + 1), *mh0 = mw + (size_t)(nr + 1) * gstride;
+  {
+    std::vector<double> sx(nr + 1);
+    for (int rs = 0; rs < nr - 1; rs++) {
+      int n = nr - rs;
+      const double *rad = a->radius + rs;
+      double r3[3];
+      if (n == 2) { r3[0] = rad[0]; r3[2] = rad[1]; r3[1] = (rad[0] + rad[1]) / 2.0; rad = r3; n = 3; }
+      sx[0] = 0.0;
+      if (o->solution == TRX_SOL_ECLIPSE) for (int i = 1; i < n; i++) sx[i] = sx[i-1] + (rad[i] - rad[i-1]);
+      else { const double r0 = rad[0]; for (int i = 1; i < n; i++) sx[i] = std::sqrt(rad[i] * rad[i] - r0 * r0); }
+      simpson_weights(sx.data(), n, gw + (size_t)rs * gstride, gh0 + rs);
+    }
+    if (o->solution == TRX_SOL_TRANSIT)                       // slantpath.c:399-408, per point count
+      for (int cnt = 3; cnt <= nr; cnt++) {
+        for (int q = 0; q < cnt; q++) sx[q] = a->radius[nr - 1 - (cnt - 1 - q)] * a->rad_fct;
+        simpson_weights(sx.data(), cnt, mw + (size_t)cnt * gstride, mh0 + cnt);
+      }
+  }
+  std::vector<double> ipv(nr);
+  for (int i = 0; i < nr; i++) ipv[i] = a->radius[nr - 1 - i];
+
+  // ---- CIA -----------------------------------------------------------------
+  std::vector<double> ecs;
+  if ((rc = cia_host(h, a, o, ecs))) return rc;
+
+  // ---- workspaces -------------------------------------------------------------
+  const size_t ln_b = (size_t)std::max<int64_t>(h->nlines, 1), gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
+  if ((rc = ensure(h, h->d_S, sizeof(double) * ln_b * nc_max)) || (rc = ensure(h, h->d_SG, sizeof(double) * gr_b * nc_max)) ||
+      (rc = ensure(h, h->d_idop8, gr_b * nc_max)) || (rc = ensure(h, h->d_kmax, sizeof(double) * nr)) ||
+      (rc = ensure(h, h->d_sticky, sizeof(int) * nli)) || (rc = ensure(h, h->d_counters, 16 * (size_t)nr)) ||
+      (rc = ensure(h, h->d_bins, 8 * (size_t)nr)) || (rc = ensure(h, h->d_flags, 64)) ||
+      (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
+      (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
+      (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
+      (rc = ensure(h, h->d_status, 16)))
+    return rc;
+  if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, i32)) || (rc = upload(h, h->d_geom, geom)) ||
+      (rc = upload(h, h->d_ecs, ecs)))
+    return rc;
+  DevBuf d_ip; if ((rc = upload(h, d_ip, ipv))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * nr, st));
+  HIPCHK(h, hipMemsetAsync(h->d_sticky.p, 0xFF, sizeof(int) * nli, st));
+  HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 16 * (size_t)nr, st));
+  HIPCHK(h, hipMemsetAsync(h->d_bins.p, 0, 8 * (size_t)nr, st));
+  HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
+  HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
+  HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
+  HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
+  { const int f0[4] = {(int)std::min<int64_t>(nsh, 0x7fffffff), 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(h->d_flags.p, f0, sizeof(f0), hipMemcpyHostToDevice, st)); }
+
+  const double *df = h->d_layer_f64.as<double>(); const int32_t *di = h->d_layer_i32.as<int32_t>();
+  LayerDev Y{};
+  Y.negc_over_t = df; Y.strength_f = df + nr; Y.density = Y.strength_f + nli; Y.alphad = Y.density + nli;
+  Y.alphal = Y.alphad + nli; const double *d_wcut = Y.alphal + nli;
+  Y.idop0 = di; Y.ilor = di + nli; Y.psmax = Y.ilor + nli;
+  const double *d_press = df + 7 * nli, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
+               *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
+  const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
+               *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride;
+
+  // ---- events -----------------------------------------------------------------
+  std::vector<hipEvent_t> ev;
+  auto mark = [&]() -> int { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev.push_back(e); return hipEventRecord(e, st) == hipSuccess ? 0 : -1; };
+  hipEvent_t ev_begin, ev_end;
+  HIPCHK(h, hipEventCreate(&ev_begin)); HIPCHK(h, hipEventCreate(&ev_end));
+  HIPCHK(h, hipEventRecord(ev_begin, st));
+
+  // ---- top-down sweep in chunks of layers (tau.c:235-290) ----
+  const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
+  int nchunks = 0;
+  for (int r_top = nr - 1; r_top >= 0; ) {
+    const int nc = std::min(nc_max, r_top + 1);
+    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    if (h->nlines > 0) {
+      hipLaunchKernelGGL(k_line_strength, dim3((unsigned)((h->nlines + 255) / 256)), dim3(256), 0, st,
+                         h->L, Y, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<unsigned long long>(),
+                         h->d_flags.as<int>(), (int)eager);
+    }
+    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    if (h->ngroups > 0) {
+      hipLaunchKernelGGL(k_group_strength, dim3((unsigned)((h->ngroups + 255) / 256)), dim3(256), 0, st,
+                         h->L, Y, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<double>(), o->ethresh,
+                         h->d_adop.as<double>(), h->ndop, d_wcut, h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(),
+                         h->d_sticky.as<int>(), h->d_counters.as<unsigned long long>(), h->d_flags.as<int>(), (int)eager);
+    }
+    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    if (h->ngroups > 0) {
+      AccumArgs A{};
+      A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
+      A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
+      A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky = h->d_sticky.as<int>();
+      A.adop = h->d_adop.as<double>(); A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
+      A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>(); A.bins = h->d_bins.as<unsigned long long>();
+      A.flags = h->d_flags.as<int>(); A.eager = eager;
+      const long long items = (long long)ntiles * nc;
+      hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, A);
+    }
+    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    {
+      TauArgs T{};
+      T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
+      T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
+      T.r_top = r_top; T.nc = nc; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
+      T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
+      T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
+      T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
+      T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
+      T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
+      T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
+      T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
+      T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
+      hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, T);
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, h->d_flags.as<int>(), nc, (int)eager);
+    }
+    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    r_top -= nc; nchunks++;
+  }
+
+  // ---- spectrum ---------------------------------------------------------------
+  double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
+  if (o->solution == TRX_SOL_ECLIPSE) {
+    EmisArgs E{};
+    E.nr = nr; E.nang = o->nangles; E.nsh = nsh; E.lo = h->lo; E.wn_i = h->wn_i; E.wn_d = h->wn_d; E.wn_fct = o->wn_fct;
+    E.tau = h->d_tau.as<double>(); E.last = h->d_last.as<int>(); E.temp = d_tempk;
+    std::vector<double> grid(o->nangles + 1);                    // eclipse.c:262-269
+    grid[0] = 0.0 * kDeg; grid[o->nangles] = 90.0 * kDeg;
+    for (int i = 1; i < o->nangles; i++) grid[i] = (o->angles_deg[i-1] + o->angles_deg[i]) * kDeg / 2.0;
+    for (int i = 0; i < o->nangles; i++) {
+      E.cosang[i] = std::cos(o->angles_deg[i] * kDeg);
+      E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
+    }
+    E.intens = h->d_intens.as<double>(); E.flux = d_out;
+    hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, E);
+  } else {
+    ModArgs M{};
+    M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
+    M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
+    M.ip = d_ip.as<double>(); M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
+    hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(ev_end, st));
+
+  // ---- results back -----------------------------------------------------------
+  int flags_host[4] = {0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
+  if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
+  std::vector<unsigned long long> counters(2 * (size_t)nr), bins(nr);
+  HIPCHK(h, hipMemcpyAsync(counters.data(), h->d_counters.p, 16 * (size_t)nr, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(bins.data(), h->d_bins.p, 8 * (size_t)nr, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+
+  trx_stats &S = h->stats;
+  S.layers_swept = flags_host[2];
+  S.neval = S.nskip = S.sum_bins = 0;
+  for (int r = 0; r < nr; r++) { S.neval += (int64_t)counters[2*r]; S.nskip += (int64_t)counters[2*r+1]; S.sum_bins += (int64_t)bins[r]; }
+  float ms = 0; (void)hipEventElapsedTime(&ms, ev_begin, ev_end); S.ms_run_total = ms;
+  S.ms_k_line = S.ms_k_group = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
+  if (prof) {
+    const int swept_chunks = std::min(nchunks, (int)((S.layers_swept + nc_max - 1) / nc_max));
+    for (int c = 0; c < nchunks; c++) {
+      float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+      (void)hipEventElapsedTime(&t1, ev[5*c], ev[5*c+1]); (void)hipEventElapsedTime(&t2, ev[5*c+1], ev[5*c+2]);
+      (void)hipEventElapsedTime(&t3, ev[5*c+2], ev[5*c+3]); (void)hipEventElapsedTime(&t4, ev[5*c+3], ev[5*c+4]);
+      if (c < swept_chunks) { S.ms_k_line += t1; S.ms_k_group += t2; S.ms_k_accum += t3; S.sweep_launches++; }
+      S.ms_tau += t4;
+    }
+    S.ms_sweep = S.ms_k_line + S.ms_k_group + S.ms_k_accum;
+  }
+  for (auto e : ev) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
+
+  if (dbg) {
+    if (dbg->e)    HIPCHK(h, hipMemcpy(dbg->e, h->d_e.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    if (dbg->e_cs) std::memcpy(dbg->e_cs, ecs.data(), sizeof(double) * nr * nsh);
+    if (dbg->tau || dbg->last) {
+      std::vector<double> t((size_t)nr * nsh); std::vector<int> l(nsh);
+      HIPCHK(h, hipMemcpy(t.data(), h->d_tau.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+      HIPCHK(h, hipMemcpy(l.data(), h->d_last.p, sizeof(int) * nsh, hipMemcpyDeviceToHost));
+      if (dbg->tau) for (int64_t w = 0; w < nsh; w++) for (int i = 0; i < nr; i++) dbg->tau[(size_t)w * nr + i] = t[(size_t)i * nsh + w];
+      if (dbg->last) for (int64_t w = 0; w < nsh; w++) dbg->last[w] = l[w];
+    }
+    if (dbg->intens && o->solution == TRX_SOL_ECLIPSE)
+      HIPCHK(h, hipMemcpy(dbg->intens, h->d_intens.p, sizeof(double) * o->nangles * nsh, hipMemcpyDeviceToHost));
+    if (dbg->computed) for (int r = 0; r < nr; r++) dbg->computed[r] = (r >= nr - S.layers_swept) ? 1 : 0;
+  }
+  if (status_host[0] == 1) return fail(h, TRX_E_NOTREACHED, "optical depth never reached toomuch (modlevel -1)");
+  if (status_host[0] == 2) return fail(h, TRX_E_ARG, "fewer than three points for the radial integration");
+  return TRX_OK;
+}
+
+int trx_run(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, trx_debug *dbg)
+{
+  if (!spectrum) return TRX_E_ARG;
+  return run_impl(h, a, o, spectrum, nullptr, dbg);
+}
+
+int trx_run_device(trx_handle *h, const trx_atm *a, const trx_opts *o, void *d_spectrum, trx_debug *dbg)
+{
+  if (!d_spectrum) return TRX_E_ARG;
+  return run_impl(h, a, o, nullptr, d_spectrum, dbg);
+}
+
+}  // extern "C"

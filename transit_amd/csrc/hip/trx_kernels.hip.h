@@ -1,0 +1,609 @@
+// trx_kernels.hip.h -- hand-written gfx950 kernels of the spectrum path.
+//
+// All of it is HBM/latency-bound fp64 accumulation over a line list -- no
+// dense contraction, hence no MFMA.  Wavefront = 64 lanes.
+//
+//   k_voigt_bins / k_voigt_bins_wave  Voigt-profile table      (opacity.c:219-277, voigt.c)
+//   k_line_strength                   pass 1: per-line strength + layer maximum
+//                                                               (extinction.c:399-427)
+//   k_group_strength                  pass 2a: co-added group strength, threshold,
+//                                     Doppler index             (extinction.c:429-483)
+//   k_accumulate                      pass 2b: profile accumulation into e[layer][wn]
+//                                                               (extinction.c:485-509)
+//   k_optical_depth                   total extinction + ray quadrature + toomuch cut
+//                                                               (tau.c:216-305, eclipse.c:29-105,
+//                                                                slantpath.c:19-108)
+//   k_emission / k_modulation         spectrum from tau         (eclipse.c:118-287, slantpath.c:351-473)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "trx_device.h"
+#include "../trx_numerics.h"
+
+namespace trx {
+
+// ---------------------------------------------------------------------------
+// wavefront helpers (64 lanes, fixed butterfly order => deterministic sums)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Voigt table
+// ---------------------------------------------------------------------------
+__constant__ double c_voigt_coef[64];     // 1/(n!(2n+1)), voigt.c:45-108
+
+constexpr double kTwoOSqrtPi = 1.12837916709551257389;
+constexpr double kSqrtLn2Pi  = 0.46971863934982566689;
+
+// voigt.c:132-200 (voigtxy).  The reference runs the Region-I recurrence in
+// long double; double carries ~1e-12 relative error through its worst
+// cancellation (x -> 3), far below the float the result is rounded to.
+__device__ __forceinline__ float voigt_point(double x, double y, double alphaD)
+{
+  const double x2y2 = x*x - y*y;
+  const double xy2  = 2*x*y;
+  if (x < 3 && y < 1.8) {
+    double sn, cs;
+    sincos(xy2, &sn, &cs);
+    const int nterm = (x < 1 ? 15 : (int)(6.842*x + 8.0)) + 1;
+    double pr = y, pi = -x, sr = y, si = -x;
+    for (int k = 1; k <= nterm; k++) {
+      const double ti = pr*xy2 + pi*x2y2;
+      const double tr = pr*x2y2 - pi*xy2;
+      si += ti * c_voigt_coef[k];
+      sr += tr * c_voigt_coef[k];
+      pi = ti; pr = tr;
+    }
+    return (float)(kSqrtLn2Pi/alphaD * exp(-x2y2) *
+                   (cs*(1 - sr*kTwoOSqrtPi) - sn*si*kTwoOSqrtPi));
+  }
+  const double q = xy2*xy2, p = xy2*x;
+  if (x < 5 && y < 5) {
+    const double t1 = x2y2 - 0.19016350, t2 = x2y2 - 1.78449270, t3 = x2y2 - 5.52534370;
+    return (float)(kSqrtLn2Pi/alphaD * (0.46131350 *((p - t1*y)/(t1*t1 + q)) +
+                                        0.09999216 *((p - t2*y)/(t2*t2 + q)) +
+                                        0.002883894*((p - t3*y)/(t3*t3 + q))));
+  }
+  const double t1 = x2y2 - 0.27525510, t2 = x2y2 - 2.72474500;
+  return (float)(kSqrtLn2Pi/alphaD * (0.51242424*((p - t1*y)/(t1*t1 + q)) +
+                                      0.05176536*((p - t2*y)/(t2*t2 + q))));
+}
+
+__device__ __forceinline__ float voigt_at(const ProfileJob &J, double yv, long long i)
+{
+  return voigt_point(kSqrtLn2 * fabs(J.sub * (double)i - J.half) / J.alphaD, yv, J.alphaD);
+}
+
+// One thread per output bin; blockIdx.y selects the profile (voigt.c:369-483).
+// The float accumulation order of the two averaging rules (:489-554) is kept.
+__global__ __launch_bounds__(256)
+void k_voigt_bins(const ProfileJob *jobs, float *table, int m_limit)
+{
+  const ProfileJob J = jobs[blockIdx.y];
+  if (J.regime == 2 && J.m > m_limit) return;          // done by k_voigt_bins_wave
+  const double yv = kSqrtLn2 * J.alphaL / J.alphaD;
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < J.nv;
+       k += (long long)gridDim.x * blockDim.x) {
+    float r;
+    if (J.regime == 0) {
+      r = voigt_at(J, yv, k);
+    } else if (J.regime == 1) {
+      const float a = voigt_at(J, yv, k), b = voigt_at(J, yv, k + 1);
+      float s = 0;
+      s = (float)((s + (a + b) / 2.0) / (double)1);
+      r = s;
+    } else {
+      const int m = J.m;
+      const long long base = k * m;
+      float s = 0;
+      for (int i = 1; i < m; i += 2) s += voigt_at(J, yv, base + i);
+      s *= 2;
+      for (int i = 2; i < m; i += 2) s += voigt_at(J, yv, base + i);
+      s *= 2;
+      s += voigt_at(J, yv, base) + voigt_at(J, yv, base + m);
+      s = (float)(s / (m * 3.0));
+      r = s;
+    }
+    table[J.off + k] = r;
+  }
+}
+
+// Coarse grids: thousands of sub-intervals per bin.  One wavefront per bin: the
+// 64 lanes evaluate 64 points at a time, lane 0 adds them in the reference order.
+__global__ __launch_bounds__(64)
+void k_voigt_bins_wave(const ProfileJob *jobs, float *table, int m_limit)
+{
+  const ProfileJob J = jobs[blockIdx.y];
+  if (J.regime != 2 || J.m <= m_limit) return;
+  __shared__ float buf[64];
+  const int lane = threadIdx.x;
+  const double yv = kSqrtLn2 * J.alphaL / J.alphaD;
+  const int m = J.m;
+  for (long long k = blockIdx.x; k < J.nv; k += gridDim.x) {
+    const long long base = k * m;
+    float s = 0;
+    for (int pass = 0; pass < 2; pass++) {             // odd points, then even points
+      for (int i0 = 1 + pass; i0 < m; i0 += 128) {
+        const int i = i0 + 2*lane;
+        buf[lane] = (i < m) ? voigt_at(J, yv, base + i) : 0.f;
+        __syncthreads();
+        if (lane == 0) {
+          const int cnt = min(64, (m - i0 + 1) / 2);
+          for (int t = 0; t < cnt; t++) s += buf[t];
+        }
+        __syncthreads();
+      }
+      if (lane == 0) s *= 2;
+    }
+    if (lane == 0) {
+      s += voigt_at(J, yv, base) + voigt_at(J, yv, base + m);
+      s = (float)(s / (m * 3.0));
+      table[J.off + k] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 1: per-line strengths of a chunk of layers + the layer maximum
+// ---------------------------------------------------------------------------
+// extinction.c:399-427.  One lane per line; the line's 26 bytes are read once
+// for the whole chunk, the two exponentials are evaluated once per line-layer
+// and parked in S[chunk][line] for pass 2 (instead of re-evaluating them as
+// the reference's second loop does).
+__global__ __launch_bounds__(256)
+void k_line_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
+                     double *__restrict__ S, unsigned long long *__restrict__ kmax_bits,
+                     const int *__restrict__ flags, int eager)
+{
+  if (!eager && flags[0] == 0) return;
+  __shared__ double red[4][kMaxChunk];
+  const long long ln = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = ln < L.nlines;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double wavn = 0, elow = 0, gf = 0; int iso = 0; bool inr = false;
+  if (ok) {
+    wavn = L.wavn[ln]; elow = L.elow[ln]; gf = L.gf[ln];
+    iso = L.iso[ln]; inr = L.inrange[ln] != 0;
+  }
+  for (int c = 0; c < nc; c++) {
+    const int r = r_top - c;
+    const double ct = Y.negc_over_t[r];
+    double pk = 0;
+    if (ok) {
+      const double s = gf * exp(ct * elow) * (1 - exp(ct * wavn));
+      S[(long long)c * L.nlines + ln] = s;
+      if (inr) pk = s * Y.strength_f[r * niso + iso];
+    }
+    pk = wave_max(pk);
+    if (lane == 0) red[wv][c] = pk;
+  }
+  __syncthreads();
+  if (threadIdx.x < nc) {
+    const int c = threadIdx.x;
+    const double m = fmax(fmax(red[0][c], red[1][c]), fmax(red[2][c], red[3][c]));
+    if (m > 0) atomicMax(&kmax_bits[r_top - c], (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 2a: co-added group strength, threshold test, Doppler-width index
+// ---------------------------------------------------------------------------
+// extinction.c:449-483.  One lane per group (anchor line).  Output per
+// (layer, group): SG = strength*density (0 when below ethresh*kmax) and the
+// Doppler index (0xFF = "use the isotope's sticky index", :480-483).
+__global__ __launch_bounds__(256)
+void k_group_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
+                      const double *__restrict__ S, const double *__restrict__ kmax,
+                      double ethresh, const double *__restrict__ adop, int ndop,
+                      const double *__restrict__ wcut,     // [layer][iso] cond <=> wavn >= wcut
+                      double *__restrict__ SG, uint8_t *__restrict__ idop8,
+                      int *__restrict__ sticky,            // [layer][iso], max group index
+                      unsigned long long *__restrict__ counters,   // [layer][2] neval, nskip
+                      const int *__restrict__ flags, int eager)
+{
+  if (!eager && flags[0] == 0) return;
+  __shared__ double s_adop[kMaxDop + 1];
+  for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
+  __syncthreads();
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = g < L.ngroups;
+  int first = 0, cnt = 0, iso = 0; double wavn = 0;
+  if (ok) { first = L.gfirst[g]; cnt = L.gcount[g]; iso = L.giso[g]; wavn = L.gwavn[g]; }
+  for (int c = 0; c < nc; c++) {
+    const int r = r_top - c;
+    int evald = 0, skipped = 0, stick = -1;
+    if (ok) {
+      const double *Sr = S + (long long)c * L.nlines + first;
+      double pk = Sr[0];
+      for (int m = 1; m < cnt; m++) pk += Sr[m];
+      pk *= Y.strength_f[r * niso + iso];
+      uint8_t id = 0xFF;
+      if (pk < ethresh * kmax[r]) { pk = 0; skipped = 1; }
+      else {
+        pk *= Y.density[r * niso + iso];
+        evald = 1;
+        if (wavn >= wcut[r * niso + iso]) {
+          id = (uint8_t)nearest_index(s_adop, Y.alphad[r * niso + iso] * wavn, 0, ndop);
+          stick = (int)g;
+        }
+      }
+      SG[(long long)c * L.ngroups + g] = pk;
+      idop8[(long long)c * L.ngroups + g] = id;
+    }
+    // sticky index: last evaluated group of the isotope that refreshed idop
+    // (wave-level max per isotope, then one atomic per wave and isotope)
+    unsigned long long todo = __ballot(stick >= 0);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      const int iso0 = __shfl(iso, src, 64);
+      const bool mine = (stick >= 0) && (iso == iso0);
+      const int mx = wave_max_i(mine ? stick : -1);
+      if ((threadIdx.x & 63) == src) atomicMax(&sticky[r * niso + iso0], mx);
+      todo &= ~__ballot(mine);
+    }
+    const long long ne = wave_sum_ll(evald), ns = wave_sum_ll(skipped);
+    if ((threadIdx.x & 63) == 0) {
+      if (ne) atomicAdd(&counters[2*r], (unsigned long long)ne);
+      if (ns) atomicAdd(&counters[2*r + 1], (unsigned long long)ns);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 2b: profile accumulation (gather form, deterministic)
+// ---------------------------------------------------------------------------
+// extinction.c:485-509.  The reference scatters every line into the bins its
+// profile covers; bin j receives a term iff |osamp*j - iown| <= profsize (the
+// minj/maxj/beg_j arithmetic of :486-509 reduces to exactly that set).  Here
+// one wavefront owns a tile of kTileBins coarse bins of one layer, its lanes
+// stride over the groups whose window can reach the tile (contiguous per
+// isotope block because the TLI is wavelength-sorted), each lane keeps private
+// partial sums, and a shuffle reduction closes the line sum.
+struct AccumArgs {
+  LinesDev L;
+  LayerDev Y;
+  int niso, nlor, ndop, osamp;
+  long long nwn, lo, nsh;           // full grid, shard origin, shard bins
+  int r_top, nc, ntiles;
+  const double  *SG;                // [chunk][ngroups]
+  const uint8_t *idop8;             // [chunk][ngroups]
+  const int     *sticky;            // [layer][iso]
+  const double  *adop;              // [ndop+1]
+  const int32_t *psize;             // [ndop][nlor]
+  const long long *poff;            // [ndop][nlor]
+  const float   *table;
+  double        *e;                 // [layer][nsh]
+  unsigned long long *bins;         // [layer] accumulated (group,bin) pairs
+  const int *flags;
+  int eager;
+};
+
+__global__ __launch_bounds__(256)
+void k_accumulate(AccumArgs A)
+{
+  if (!A.eager && A.flags[0] == 0) return;
+  __shared__ int32_t  s_ps[4][kMaxDop];
+  __shared__ long long s_po[4][kMaxDop];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long item = (long long)blockIdx.x * 4 + wv;
+  if (item >= (long long)A.ntiles * A.nc) return;      // whole wave leaves together
+  const int c = (int)(item / A.ntiles);
+  const int tile = (int)(item - (long long)c * A.ntiles);
+  const int r = A.r_top - c;
+  const long long j0 = A.lo + (long long)tile * kTileBins;      // global coarse bin
+  const long long j1 = min(j0 + kTileBins, A.lo + A.nsh) - 1;
+  double acc[kTileBins];
+#pragma unroll
+  for (int t = 0; t < kTileBins; t++) acc[t] = 0.0;
+  long long nb = 0;
+
+  for (int b = 0; b < A.niso; b++) {
+    const int gb0 = A.L.gblock[b], gb1 = A.L.gblock[b + 1];
+    if (gb0 == gb1) continue;
+    const int ri = r * A.niso + b;
+    const int il = A.Y.ilor[ri];
+    // profile column of this (layer, isotope): size and offset per Doppler index
+    for (int i = lane; i < A.ndop; i += 64) {
+      s_ps[wv][i] = A.psize[i * A.nlor + il];
+      s_po[wv][i] = A.poff [i * A.nlor + il];
+    }
+    // sticky Doppler index of the isotope in this layer (extinction.c:393, 480-483)
+    int idst = A.Y.idop0[ri];
+    const int sg = A.sticky[ri];
+    if (sg >= 0) idst = nearest_index(A.adop, A.Y.alphad[ri] * A.L.gwavn[sg], 0, A.ndop);
+    // window of groups that can reach the tile
+    const long long psm = A.Y.psmax[ri];
+    long long klo = ((long long)A.osamp * j0 - psm) / A.osamp - 1;
+    long long khi = ((long long)A.osamp * j1 + psm) / A.osamp + 1;
+    if (klo < 0) klo = 0;
+    if (khi > A.nwn - 1) khi = A.nwn - 1;
+    const int32_t *cg = A.L.cnt_ge + (long long)b * (A.nwn + 1);
+    const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
+    const double  *SGr = A.SG    + (long long)c * A.L.ngroups;
+    const uint8_t *idr = A.idop8 + (long long)c * A.L.ngroups;
+    __builtin_amdgcn_wave_barrier();
+    for (int g = ga + lane; g < gz; g += 64) {
+      const double sg_k = SGr[g];
+      if (sg_k == 0.0) continue;
+      int id = idr[g];
+      if (id == 0xFF) id = idst;
+      const long long ps = s_ps[wv][id];
+      const float *prof = A.table + s_po[wv][id] + ps;           // centre of the profile
+      const long long d0 = (long long)A.osamp * j0 - A.L.giown[g];
+#pragma unroll
+      for (int t = 0; t < kTileBins; t++) {
+        const long long d = d0 + (long long)t * A.osamp;
+        if (d >= -ps && d <= ps && j0 + t <= j1) { acc[t] += sg_k * (double)prof[d]; nb++; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int t = 0; t < kTileBins; t++) {
+    const double s = wave_sum(acc[t]);
+    if (lane == 0 && j0 + t <= j1) A.e[(long long)r * A.nsh + (j0 - A.lo) + t] = s;
+  }
+  nb = wave_sum_ll(nb);
+  if (lane == 0 && nb) atomicAdd(&A.bins[r], (unsigned long long)nb);
+}
+
+// ---------------------------------------------------------------------------
+// optical depth
+// ---------------------------------------------------------------------------
+struct TauArgs {
+  int nr, solution;                  // layers; TRX_SOL_*
+  long long nsh, lo;
+  double wn_i, wn_d, wn_fct, rad_fct, toomuch;
+  int r_top, nc;                     // layers of this chunk: r_top, r_top-1, ...
+  const double *rad;                 // [nr]
+  const double *e, *ecs;             // [nr][nsh]
+  double *er;                        // [nr][nsh] total extinction, edited in place (eclipse.c:65-66)
+  double *tau;                       // [nr(height)][nsh]
+  int *last;                         // [nsh], -1 while the ray is still descending
+  // Simpson weights per start layer rs: row rs holds, per interval pair,
+  // {2-hratio, hfactor, 2-1/hratio, hsum} (numerical.c:390-425, 500-525)
+  const double *gw; int gstride;     // gw[rs*gstride + 4*i + k]
+  const double *gh0;                 // [nr] first interval (trapezoid when the count is even)
+  // scattering / clouds (extinction.c:587-693)
+  int scat_flag, cloud_flag, nmol;
+  double scat_pref;                  // 10^logext * E0H2
+  const double *press, *temp;        // [nr]
+  const double *scat_pol;            // [nr] sum_j pi*8e-32/3*pol_j^2*rho_j/m_j*N_A  (flag 2)
+  double cloud_top, cloud_bot, cloud_ext, cloud_gamma, cloud_Q, cloud_r, cloud_sig, cloud_refwn;
+  const double *mdens, *nH;          // [nr]
+  int *flags;                        // [0] active rays (gate), [1] rays still active after this chunk
+  int eager;
+};
+
+__device__ __forceinline__ double scat_term(const TauArgs &T, int r, double wn)
+{
+  if (T.scat_flag == 1) return T.scat_pref * T.press[r] / T.temp[r] * pow(wn, 4);
+  if (T.scat_flag == 2) return T.scat_pol[r] * pow(2. * kPi * wn * kMicron, 4);
+  return 0.0;
+}
+
+// extinction.c:630-693: zero above the top and below the bottom of the deck
+__device__ __forceinline__ double cloud_term(const TauArgs &T, int r, double wn)
+{
+  if (T.cloud_flag == 0 || T.cloud_ext == 0.0) return 0.0;
+  const double ctop = pow(10, T.cloud_top), cbot = pow(10, T.cloud_bot);
+  const double p = T.press[r];
+  // the reference walks down from the top: layers with p < ctop are clear, then
+  // cloudy until the first layer with p >= cbot, clear below (pressure is monotonic)
+  if (p < ctop || p >= cbot) return 0.0;
+  switch (T.cloud_flag) {
+    case 1: return T.cloud_ext;
+    case 2: return T.cloud_ext * T.mdens[r];
+    case 3: return T.cloud_ext * pow(wn, T.cloud_gamma) * T.mdens[r];
+    case 4: {
+      const double x = 2 * kPi * T.cloud_r * wn;
+      return T.cloud_ext / (T.cloud_Q * pow(x, -1 * T.cloud_gamma) + pow(x, 0.2)) * T.mdens[r];
+    }
+    case 5: return T.nH[r] * (T.cloud_ext * pow(wn, T.cloud_gamma)) * T.cloud_sig /
+                   pow(T.cloud_refwn, T.cloud_gamma) * T.mdens[r];
+  }
+  return 0.0;
+}
+
+// One lane per wavenumber; heights are visited top-down, a chunk of layers per
+// launch (tau.c:235-290).  All lanes of a wave walk the same height, so the
+// Simpson weights are wave-uniform loads and er[layer][w] reads are coalesced.
+__global__ __launch_bounds__(256)
+void k_optical_depth(TauArgs T)
+{
+  if (!T.eager && T.flags[0] == 0) return;
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = w < T.nsh;
+  const int nr = T.nr;
+  const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
+  bool alive = ok && (T.last[ok ? w : 0] < 0);
+
+  if (ok) {                                              // tau.c:231-232, 267-268
+    for (int c = 0; c < T.nc; c++) {
+      const int r = T.r_top - c;
+      const long long k = (long long)r * T.nsh + w;
+      T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
+    }
+  }
+  if (alive) {
+    for (int c = 0; c < T.nc; c++) {
+      const int rs = T.r_top - c;                        // layer reached by this height
+      const int ri = nr - 1 - rs;                        // height index from the top
+      double t;
+      if (rs == nr - 1) {
+        t = 0.0;                                         // eclipse.c:45-46, slantpath.c:37-38
+      } else {
+        const int n = nr - rs;
+        const double *y = T.er + (long long)rs * T.nsh + w;       // y[j*nsh] = er[rs+j][w]
+        const double *g = T.gw + (long long)rs * T.gstride;
+        double res;
+        if (n == 2) {                                    // eclipse.c:65,68-80
+          const double ym = T.er[(long long)(rs - 1) * T.nsh + w];
+          const double y0 = parab3(T.rad[rs-1], T.rad[rs], ym, y[0], y[T.nsh], T.rad[rs]);
+          const double y2 = y[T.nsh];
+          const double y1 = (T.solution == 0) ? (y2 + y0) / 2.0 : (y0 + y2) / 2.0;
+          res = ((y0 * g[0] + y1 * g[1] + y2 * g[2]) * g[3]) / 6.0;
+        } else {
+          const double y0 = parab3(T.rad[rs], T.rad[rs+1], y[0], y[T.nsh], y[2*T.nsh], T.rad[rs]);
+          if (T.solution == 0) T.er[(long long)rs * T.nsh + w] = y0;   // not restored: eclipse.c:66
+          const int even = (n % 2 == 0);
+          double acc = 0.0;
+          const int npair = (n - 1) / 2;
+          for (int i = 0; i < npair; i++) {
+            const int j = 2*i + even;
+            const double ya = (j == 0) ? y0 : y[(long long)j * T.nsh];
+            const double yb = y[(long long)(j+1) * T.nsh], yc = y[(long long)(j+2) * T.nsh];
+            acc += (ya * g[4*i] + yb * g[4*i+1] + yc * g[4*i+2]) * g[4*i+3];
+          }
+          res = acc / 6.0;
+          if (even) res += T.gh0[rs] * (y0 + y[T.nsh]) / 2;
+        }
+        t = (T.solution == 0) ? res : 2 * res;
+      }
+      const double tv = T.rad_fct * t;
+      T.tau[(long long)ri * T.nsh + w] = tv;
+      if (tv > T.toomuch) { T.last[w] = ri; alive = false; break; }     // tau.c:277-287
+      if (ri == nr - 1)   { T.last[w] = ri; alive = false; break; }     // tau.c:299-304
+    }
+  }
+  const unsigned long long still = __ballot(alive);
+  if ((threadIdx.x & 63) == 0 && still) atomicAdd(&T.flags[1], __popcll(still));
+}
+
+// flags[0] <- rays still descending; counts the layers actually swept
+__global__ void k_advance(int *flags, int nc, int eager)
+{
+  if (eager || flags[0] != 0) flags[2] += nc;
+  flags[0] = flags[1];
+  flags[1] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// spectrum
+// ---------------------------------------------------------------------------
+struct EmisArgs {
+  int nr, nang; long long nsh, lo;
+  double wn_i, wn_d, wn_fct;
+  const double *tau; const int *last; const double *temp;
+  double cosang[kMaxAngles], area[kMaxAngles];
+  double *intens;                    // [nang][nsh]
+  double *flux;                      // [nsh]
+};
+
+// eclipse.c:118-160 (eclipse_intens) for every angle + eclipse.c:243-287 (flux)
+__global__ __launch_bounds__(256)
+void k_emission(EmisArgs E)
+{
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= E.nsh) return;
+  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
+  const int last = E.last[w];
+  const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
+  const double pl_exp = kH * wv * kLs;
+  double Bp = 0, dtp[kMaxAngles], sum[kMaxAngles];
+  for (int a = 0; a < E.nang; a++) { sum[a] = 0; dtp[a] = 0; }
+  for (int i = 0; i <= last; i++) {
+    const double tv = E.tau[(long long)i * E.nsh + w];
+    const double B = pl_num / (exp(pl_exp / (kKb * E.temp[E.nr - 1 - i])) - 1.0);
+    for (int a = 0; a < E.nang; a++) {
+      const double dt = exp(-tv / E.cosang[a]);
+      if (i > 0) sum[a] += (dt - dtp[a]) * (B + Bp);     // numerical.c:168-170
+      dtp[a] = dt;
+    }
+    Bp = B;
+  }
+  double fl = 0.0;
+  for (int a = 0; a < E.nang; a++) {
+    const double I = Bp * dtp[a] - 0.5 * sum[a];
+    E.intens[(long long)a * E.nsh + w] = I;
+    fl += kPi * I * E.area[a];
+  }
+  E.flux[w] = fl;
+}
+
+struct ModArgs {
+  int nr, modlevel, transparent; long long nsh;
+  double toomuch, ip_fct, srad;
+  const double *tau; const int *last;
+  const double *ip;                  // [nr] impact parameters, top first (makesample.c:564-574)
+  // Simpson weights per point count (slantpath.c:399-408): row "cnt"
+  const double *gw; int gstride; const double *gh0;
+  double *out;                       // [nsh]
+  int *status;                       // set to 1 when modlevel -1 cannot be evaluated
+};
+
+// slantpath.c:351-436 (modulation1) and :447-473 (modulationm1)
+__global__ __launch_bounds__(256)
+void k_modulation(ModArgs M)
+{
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= M.nsh) return;
+  const int nr = M.nr;
+  int last = M.last[w];
+  const double *tw = M.tau + w;                           // tw[i*nsh] = tau[i][w]
+  if (M.modlevel == -1) {
+    const double tl = tw[(long long)last * M.nsh];
+    if (tl < M.toomuch) { M.out[w] = -1; *M.status = 1; return; }
+    int ini = last + 1 - 2; if (ini < 0) ini = 0;
+    // interp_line(tau+ini, ipv, toomuch), numerical.c:202-211
+    const double x0 = tw[(long long)ini * M.nsh], x1 = tw[(long long)(ini+1) * M.nsh];
+    const double y0 = M.ip[ini] * M.ip_fct, y1 = M.ip[ini+1] * M.ip_fct;
+    const double r = y0 + (M.toomuch - x0) * ((y1 - y0) / (x1 - x0));
+    M.out[w] = r * r / (M.srad * M.srad);
+    return;
+  }
+  const double tlast = tw[(long long)last * M.nsh];
+  const double maxtau = tlast > M.toomuch ? tlast : M.toomuch;
+  // integrand on ascending radius: index q = 0..cnt-1 maps to height i = cnt-1-q
+  int lastp = last + 1; if (lastp > nr - 1) lastp = nr - 1;
+  const int cnt = lastp + 1;                               // points, including the zero pad
+  if (cnt < 3) { M.out[w] = nan(""); *M.status = 2; return; }
+  const double *g = M.gw + (long long)cnt * M.gstride;
+  auto val = [&](int q) -> double {
+    const int i = cnt - 1 - q;
+    if (i > last) return 0.0;                              // slantpath.c:383-386
+    const double b = M.ip[i] * M.ip_fct;
+    return exp(-tw[(long long)i * M.nsh]) * b;
+  };
+  const int even = (cnt % 2 == 0);
+  double acc = 0.0;
+  for (int i = 0; i < (cnt - 1) / 2; i++) {
+    const int j = 2*i + even;
+    acc += (val(j) * g[4*i] + val(j+1) * g[4*i+1] + val(j+2) * g[4*i+2]) * g[4*i+3];
+  }
+  double res = acc / 6.0;
+  if (even) res += M.gh0[cnt] * (val(0) + val(1)) / 2;
+  const double rtop = M.ip[0] * M.ip_fct;
+  res = rtop * rtop - 2.0 * res;
+  if (M.transparent) {
+    const double bmin = M.ip[cnt - 1] * M.ip_fct;
+    res -= exp(-maxtau) * bmin * bmin;
+  }
+  res *= 1.0 / (M.srad * M.srad);
+  M.out[w] = res;
+}
+
+}  // namespace trx
