@@ -48,12 +48,12 @@ def parse():
     return ap.parse_args()
 
 
-def make_workload(args, tag, nlines):
+def make_workload(args, tag, nlines, verb=2):
     from transit_amd import synth
     d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%d" % (tag, nlines, args.layers, os.getpid()))
     synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=args.wnhigh, wndelt=1.0, wnosamp=args.wnosamp,
                     nlayers=args.layers, solution="eclipse", toomuch=10.0, ethresh=1e-50, nwidth=20.0,
-                    raygrid="0 20 40 60 80", ncia=1, seed=1234)
+                    raygrid="0 20 40 60 80", ncia=1, seed=1234, extra={"verb": verb})
     return d
 
 
@@ -63,7 +63,7 @@ def cpu_baseline(args, gpu_spectrum_full):
     built from the reference sources by oracle/Makefile); falls back to our C
     restatement.  Test infrastructure, used here only as the baseline/checker."""
     nlines = args.cpu_lines or args.lines
-    d = make_workload(args, "cpu", nlines)
+    d = make_workload(args, "cpu", nlines, verb=4)     # verb 4 prints the reference's stage timers
     ref = os.path.join(ROOT, "oracle", "_ref", "transit")
     out = {"cores": 1, "unit": "wavenumber-points*layers/s"}
     if os.path.exists(ref) and os.access(ref, os.X_OK):

@@ -179,7 +179,8 @@ typedef struct {
   double  ms_k_accum;     /* sum over launches of k_accumulate                 */
   int64_t sweep_launches; /* launches of each sweep kernel that did work       */
   double  ms_tau;         /* optical-depth kernels                             */
-  double  ms_cia;
+  double  ms_cia;         /* host wall time of the CIA interpolation            */
+  double  ms_host_total;  /* host wall time of the whole trx_run call           */
   double  ms_spectrum;    /* intensity/flux or modulation                      */
 } trx_stats;
 

@@ -84,12 +84,14 @@ def test_counters(both):
     keep = opts.eager
     try:
         opts.eager = 1
+        opts.profile = 1            # counters are collected in profiling runs only
         he = both[6].run(P.atm, opts, debug=False)
         hst2 = both[6].stats()
         oe = both[5].run(P.atm, opts, debug=False)
         ost2 = both[5].stats()
     finally:
         opts.eager = keep
+        opts.profile = 0
     assert hst2["layers_swept"] == P.nlayer == ost2["layers_swept"]
     assert hst2["neval"] == ost2["neval"]
     assert hst2["nskip"] == ost2["nskip"]

@@ -75,7 +75,8 @@ class TrxStats(C.Structure):
         ("ms_create_table", C.c_double), ("ms_run_total", C.c_double), ("ms_sweep", C.c_double),
         ("ms_k_line", C.c_double), ("ms_k_group", C.c_double), ("ms_k_accum", C.c_double),
         ("sweep_launches", C.c_int64),
-        ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_spectrum", C.c_double),
+        ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_host_total", C.c_double),
+        ("ms_spectrum", C.c_double),
     ]
 
     def as_dict(self):

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -58,13 +59,14 @@ struct trx_handle {
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
   DevBuf d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
   LinesDev L{};
+  std::vector<double> h_gwavn; std::vector<int32_t> h_gblock;   // host copies for the per-run prologue
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs; };
   std::vector<Cia> cia;
   // per-run workspaces (grown on demand)
   int ws_nr = 0, ws_chunk = 0;
-  DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags;
-  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status;
+  DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags, d_part2, d_part3;
+  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip;
   trx_stats stats{};
 };
 
@@ -264,6 +266,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
       (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
     return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
+  h->h_gwavn = gwavn; h->h_gblock = gblock;
   LinesDev &L = h->L;
   L.nlines = n; L.wavn = h->d_wavn.as<double>(); L.elow = h->d_elow.as<double>(); L.gf = h->d_gf.as<double>();
   L.iso = h->d_iso.as<int16_t>(); L.inrange = h->d_inr.as<uint8_t>();
@@ -469,6 +472,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                     trx_debug *dbg)
 {
   if (!h || !a || !o) return TRX_E_ARG;
+  const auto t_host0 = std::chrono::steady_clock::now();
   const int nr = a->nlayer, niso = h->niso, nmol = h->nmol;
   const int64_t nsh = h->nsh;
   if (nr < 3) return fail(h, TRX_E_ARG, "at least three layers are needed");
@@ -492,8 +496,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   double *negct = &f64[0], *strength = negct + nr, *dens = strength + nli, *alphad = dens + nli,
          *alphal = alphad + nli, *wcut = alphal + nli, *pad0 = wcut + nli;
   (void)pad0;
-  std::vector<int32_t> i32(3 * nli, 0);
-  int32_t *idop0 = &i32[0], *ilor = idop0 + nli, *psmax = ilor + nli;
+  std::vector<int32_t> i32(4 * nli, 0);
+  int32_t *idop0 = &i32[0], *ilor = idop0 + nli, *psmax = ilor + nli, *npre = psmax + nli;
   for (int r = 0; r < nr; r++) {
     const double temp = a->temp[r];
     if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
@@ -525,6 +529,11 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       int32_t pm = 0;
       for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
       psmax[k] = pm;
+      {   // groups of the block that refresh the Doppler index: wavn >= wcut (descending order)
+        const double *gb = h->h_gwavn.data() + h->h_gblock[i], *ge = h->h_gwavn.data() + h->h_gblock[i + 1];
+        const double wc = wcut[k];
+        npre[k] = (int32_t)(std::partition_point(gb, ge, [wc](double w) { return w >= wc; }) - gb);
+      }
     }
   }
   // layer-only scalars of the scattering / cloud models (tau.c:193-214, extinction.c:617-621)
@@ -574,7 +583,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- CIA -----------------------------------------------------------------
   std::vector<double> ecs;
+  const auto t_cia0 = std::chrono::steady_clock::now();
   if ((rc = cia_host(h, a, o, ecs))) return rc;
+  const double ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cia0).count();
 
   // ---- workspaces -------------------------------------------------------------
   const size_t ln_b = (size_t)std::max<int64_t>(h->nlines, 1), gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
@@ -587,12 +598,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
       (rc = ensure(h, h->d_status, 16)))
     return rc;
+  if (prof && ((rc = ensure(h, h->d_part2, 16 * (size_t)nc_max * ((gr_b + 255) / 256))) ||
+               (rc = ensure(h, h->d_part3, 8 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4)))))
+    return rc;
   if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, i32)) || (rc = upload(h, h->d_geom, geom)) ||
       (rc = upload(h, h->d_ecs, ecs)))
     return rc;
-  DevBuf d_ip; if ((rc = upload(h, d_ip, ipv))) return rc;
+  if ((rc = upload(h, h->d_ip, ipv))) return rc;
   HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * nr, st));
-  HIPCHK(h, hipMemsetAsync(h->d_sticky.p, 0xFF, sizeof(int) * nli, st));
   HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 16 * (size_t)nr, st));
   HIPCHK(h, hipMemsetAsync(h->d_bins.p, 0, 8 * (size_t)nr, st));
   HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
@@ -606,7 +619,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   LayerDev Y{};
   Y.negc_over_t = df; Y.strength_f = df + nr; Y.density = Y.strength_f + nli; Y.alphad = Y.density + nli;
   Y.alphal = Y.alphad + nli; const double *d_wcut = Y.alphal + nli;
-  Y.idop0 = di; Y.ilor = di + nli; Y.psmax = Y.ilor + nli;
+  Y.idop0 = di; Y.ilor = di + nli; Y.psmax = Y.ilor + nli; const int32_t *d_npre = Y.psmax + nli;
   const double *d_press = df + 7 * nli, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
   const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
@@ -631,25 +644,38 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                          h->d_flags.as<int>(), (int)eager);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    const unsigned gblocks = (unsigned)((h->ngroups + 255) / 256);
+    const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
     if (h->ngroups > 0) {
-      hipLaunchKernelGGL(k_group_strength, dim3((unsigned)((h->ngroups + 255) / 256)), dim3(256), 0, st,
+      hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
+                         h->L, Y, niso, r_top, nc, h->d_kmax.as<double>(), o->ethresh, h->d_adop.as<double>(), h->ndop,
+                         d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), (int)eager);
+      hipLaunchKernelGGL(k_group_strength, dim3(gblocks), dim3(256), 0, st,
                          h->L, Y, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<double>(), o->ethresh,
                          h->d_adop.as<double>(), h->ndop, d_wcut, h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(),
-                         h->d_sticky.as<int>(), h->d_counters.as<unsigned long long>(), h->d_flags.as<int>(), (int)eager);
+                         prof ? h->d_part2.as<unsigned long long>() : nullptr, h->d_flags.as<int>(), (int)eager);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     if (h->ngroups > 0) {
       AccumArgs A{};
       A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
       A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
-      A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky = h->d_sticky.as<int>();
-      A.adop = h->d_adop.as<double>(); A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
-      A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>(); A.bins = h->d_bins.as<unsigned long long>();
+      A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
+      A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
+      A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>();
+      A.part = prof ? h->d_part3.as<unsigned long long>() : nullptr;
       A.flags = h->d_flags.as<int>(); A.eager = eager;
-      const long long items = (long long)ntiles * nc;
-      hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, A);
+      hipLaunchKernelGGL(k_accumulate, dim3(tblocks, (unsigned)nc), dim3(256), 0, st, A);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    if (prof && h->ngroups > 0) {      // counters (profiling runs only; gated like the sweep itself)
+      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part2.as<unsigned long long>(),
+                         (int)gblocks, 2, 0, h->d_counters.as<unsigned long long>(), 2, r_top, h->d_flags.as<int>(), (int)eager);
+      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part2.as<unsigned long long>(),
+                         (int)gblocks, 2, 1, h->d_counters.as<unsigned long long>(), 2, r_top, h->d_flags.as<int>(), (int)eager);
+      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
+                         (int)tblocks, 1, 0, h->d_bins.as<unsigned long long>(), 1, r_top, h->d_flags.as<int>(), (int)eager);
+    }
     {
       TauArgs T{};
       T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
@@ -689,7 +715,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     ModArgs M{};
     M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
     M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
-    M.ip = d_ip.as<double>(); M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
+    M.ip = h->d_ip.as<double>(); M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
     hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
   }
   HIPCHK(h, hipGetLastError());
@@ -710,6 +736,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   S.neval = S.nskip = S.sum_bins = 0;
   for (int r = 0; r < nr; r++) { S.neval += (int64_t)counters[2*r]; S.nskip += (int64_t)counters[2*r+1]; S.sum_bins += (int64_t)bins[r]; }
   float ms = 0; (void)hipEventElapsedTime(&ms, ev_begin, ev_end); S.ms_run_total = ms;
+  S.ms_cia = ms_cia;
+  S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   S.ms_k_line = S.ms_k_group = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
   if (prof) {
     const int swept_chunks = std::min(nchunks, (int)((S.layers_swept + nc_max - 1) / nc_max));

@@ -214,27 +214,29 @@ void k_line_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
 // extinction.c:449-483.  One lane per group (anchor line).  Output per
 // (layer, group): SG = strength*density (0 when below ethresh*kmax) and the
 // Doppler index (0xFF = "use the isotope's sticky index", :480-483).
+// part (optional, profiling only): per-block {evaluated, skipped} counts.
 __global__ __launch_bounds__(256)
 void k_group_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
                       const double *__restrict__ S, const double *__restrict__ kmax,
                       double ethresh, const double *__restrict__ adop, int ndop,
-                      const double *__restrict__ wcut,     // [layer][iso] cond <=> wavn >= wcut
+                      const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                       double *__restrict__ SG, uint8_t *__restrict__ idop8,
-                      int *__restrict__ sticky,            // [layer][iso], max group index
-                      unsigned long long *__restrict__ counters,   // [layer][2] neval, nskip
+                      unsigned long long *__restrict__ part,       // [nc][gridDim.x][2] or null
                       const int *__restrict__ flags, int eager)
 {
   if (!eager && flags[0] == 0) return;
   __shared__ double s_adop[kMaxDop + 1];
+  __shared__ int s_cnt[4][2];
   for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
   __syncthreads();
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool ok = g < L.ngroups;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int first = 0, cnt = 0, iso = 0; double wavn = 0;
   if (ok) { first = L.gfirst[g]; cnt = L.gcount[g]; iso = L.giso[g]; wavn = L.gwavn[g]; }
   for (int c = 0; c < nc; c++) {
     const int r = r_top - c;
-    int evald = 0, skipped = 0, stick = -1;
+    int evald = 0, skipped = 0;
     if (ok) {
       const double *Sr = S + (long long)c * L.nlines + first;
       double pk = Sr[0];
@@ -245,31 +247,87 @@ void k_group_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
       else {
         pk *= Y.density[r * niso + iso];
         evald = 1;
-        if (wavn >= wcut[r * niso + iso]) {
+        if (wavn >= wcut[r * niso + iso])
           id = (uint8_t)nearest_index(s_adop, Y.alphad[r * niso + iso] * wavn, 0, ndop);
-          stick = (int)g;
-        }
       }
       SG[(long long)c * L.ngroups + g] = pk;
       idop8[(long long)c * L.ngroups + g] = id;
     }
-    // sticky index: last evaluated group of the isotope that refreshed idop
-    // (wave-level max per isotope, then one atomic per wave and isotope)
-    unsigned long long todo = __ballot(stick >= 0);
-    while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      const int iso0 = __shfl(iso, src, 64);
-      const bool mine = (stick >= 0) && (iso == iso0);
-      const int mx = wave_max_i(mine ? stick : -1);
-      if ((threadIdx.x & 63) == src) atomicMax(&sticky[r * niso + iso0], mx);
-      todo &= ~__ballot(mine);
-    }
-    const long long ne = wave_sum_ll(evald), ns = wave_sum_ll(skipped);
-    if ((threadIdx.x & 63) == 0) {
-      if (ne) atomicAdd(&counters[2*r], (unsigned long long)ne);
-      if (ns) atomicAdd(&counters[2*r + 1], (unsigned long long)ns);
+    if (part) {
+      const int ne = __popcll(__ballot(evald)), ns = __popcll(__ballot(skipped));
+      if (lane == 0) { s_cnt[wv][0] = ne; s_cnt[wv][1] = ns; }
+      __syncthreads();
+      if (threadIdx.x < 2)
+        part[((long long)c * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+            (unsigned long long)(s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] +
+                                 s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x]);
+      __syncthreads();
     }
   }
+}
+
+// Sticky Doppler index of every (layer, isotope): extinction.c:393 and :480-483.
+// idop[i] is refreshed by every evaluated line with alphad*wn/alphal >= 0.1 and
+// keeps its last value for the others.  Inside an isotope block wavenumbers
+// descend, so the refreshing lines are a prefix of the block (npre groups,
+// found on the host) and the index every other line sees is the one of the
+// LAST evaluated group of that prefix.  One wavefront per (layer, isotope)
+// walks back from the end of the prefix, 64 candidates at a time, evaluating
+// their strengths exactly as pass 1/2a do.
+__global__ __launch_bounds__(64)
+void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
+                    const double *__restrict__ kmax, double ethresh,
+                    const double *__restrict__ adop, int ndop,
+                    const int *__restrict__ npre,        // [layer][iso] refreshing groups
+                    int *__restrict__ sticky_idop,       // [layer][iso]
+                    const int *__restrict__ flags, int eager)
+{
+  if (!eager && flags[0] == 0) return;
+  const int c = blockIdx.x / niso, b = blockIdx.x - c * niso;
+  if (c >= nc) return;
+  const int r = r_top - c, ri = r * niso + b, lane = threadIdx.x;
+  const int gb0 = L.gblock[b];
+  const double ct = Y.negc_over_t[r], lim = ethresh * kmax[r], f = Y.strength_f[ri];
+  int found = -1;
+  for (int base = npre[ri] - 1; base >= 0 && found < 0; base -= 64) {
+    const int k = base - lane;
+    bool ev = false;
+    if (k >= 0) {
+      const int g = gb0 + k, first = L.gfirst[g], cnt = L.gcount[g];
+      double pk = 0;
+      for (int m = 0; m < cnt; m++) {
+        const int ln = first + m;
+        const double s = L.gf[ln] * exp(ct * L.elow[ln]) * (1 - exp(ct * L.wavn[ln]));
+        pk = (m == 0) ? s : pk + s;
+      }
+      pk *= f;
+      ev = !(pk < lim);
+    }
+    const unsigned long long mask = __ballot(ev);
+    if (mask) found = base - (__ffsll((long long)mask) - 1);
+  }
+  if (lane == 0) {
+    int id = Y.idop0[ri];
+    if (found >= 0) id = nearest_index(adop, Y.alphad[ri] * L.gwavn[gb0 + found], 0, ndop);
+    sticky_idop[ri] = id;
+  }
+}
+
+// sum per-block partial counters: out[slot] += sum_k parts[slot*nparts + k]
+__global__ __launch_bounds__(256)
+void k_sum_parts_gated(const unsigned long long *__restrict__ parts, int nparts, int stride, int offset,
+                       unsigned long long *__restrict__ out, int out_stride, int r_top,
+                       const int *__restrict__ flags, int eager)
+{
+  if (!eager && flags[0] == 0) return;
+  __shared__ unsigned long long red[256];
+  const int slot = blockIdx.x;                       // layer of the chunk
+  unsigned long long s = 0;
+  for (int k = threadIdx.x; k < nparts; k += 256) s += parts[((long long)slot * nparts + k) * stride + offset];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[(long long)(r_top - slot) * out_stride + offset] += red[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -290,29 +348,29 @@ struct AccumArgs {
   int r_top, nc, ntiles;
   const double  *SG;                // [chunk][ngroups]
   const uint8_t *idop8;             // [chunk][ngroups]
-  const int     *sticky;            // [layer][iso]
-  const double  *adop;              // [ndop+1]
+  const int     *sticky_idop;       // [layer][iso]
   const int32_t *psize;             // [ndop][nlor]
   const long long *poff;            // [ndop][nlor]
   const float   *table;
   double        *e;                 // [layer][nsh]
-  unsigned long long *bins;         // [layer] accumulated (group,bin) pairs
+  unsigned long long *part;         // [nc][gridDim.x] accumulated (group,bin) pairs, or null
   const int *flags;
   int eager;
 };
 
+// grid: x = groups of 4 tiles, y = layer of the chunk
 __global__ __launch_bounds__(256)
 void k_accumulate(AccumArgs A)
 {
   if (!A.eager && A.flags[0] == 0) return;
   __shared__ int32_t  s_ps[4][kMaxDop];
   __shared__ long long s_po[4][kMaxDop];
+  __shared__ long long s_nb[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long item = (long long)blockIdx.x * 4 + wv;
-  if (item >= (long long)A.ntiles * A.nc) return;      // whole wave leaves together
-  const int c = (int)(item / A.ntiles);
-  const int tile = (int)(item - (long long)c * A.ntiles);
+  const int c = blockIdx.y;
+  const int tile = blockIdx.x * 4 + wv;
   const int r = A.r_top - c;
+  const bool live = tile < A.ntiles;                 // wave-uniform
   const long long j0 = A.lo + (long long)tile * kTileBins;      // global coarse bin
   const long long j1 = min(j0 + kTileBins, A.lo + A.nsh) - 1;
   double acc[kTileBins];
@@ -320,6 +378,7 @@ void k_accumulate(AccumArgs A)
   for (int t = 0; t < kTileBins; t++) acc[t] = 0.0;
   long long nb = 0;
 
+  if (live)
   for (int b = 0; b < A.niso; b++) {
     const int gb0 = A.L.gblock[b], gb1 = A.L.gblock[b + 1];
     if (gb0 == gb1) continue;
@@ -330,10 +389,7 @@ void k_accumulate(AccumArgs A)
       s_ps[wv][i] = A.psize[i * A.nlor + il];
       s_po[wv][i] = A.poff [i * A.nlor + il];
     }
-    // sticky Doppler index of the isotope in this layer (extinction.c:393, 480-483)
-    int idst = A.Y.idop0[ri];
-    const int sg = A.sticky[ri];
-    if (sg >= 0) idst = nearest_index(A.adop, A.Y.alphad[ri] * A.L.gwavn[sg], 0, A.ndop);
+    const int idst = A.sticky_idop[ri];
     // window of groups that can reach the tile
     const long long psm = A.Y.psmax[ri];
     long long klo = ((long long)A.osamp * j0 - psm) / A.osamp - 1;
@@ -361,13 +417,20 @@ void k_accumulate(AccumArgs A)
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (live) {
 #pragma unroll
-  for (int t = 0; t < kTileBins; t++) {
-    const double s = wave_sum(acc[t]);
-    if (lane == 0 && j0 + t <= j1) A.e[(long long)r * A.nsh + (j0 - A.lo) + t] = s;
+    for (int t = 0; t < kTileBins; t++) {
+      const double s = wave_sum(acc[t]);
+      if (lane == 0 && j0 + t <= j1) A.e[(long long)r * A.nsh + (j0 - A.lo) + t] = s;
+    }
   }
-  nb = wave_sum_ll(nb);
-  if (lane == 0 && nb) atomicAdd(&A.bins[r], (unsigned long long)nb);
+  if (A.part) {
+    nb = wave_sum_ll(nb);
+    if (lane == 0) s_nb[wv] = nb;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      A.part[(long long)c * gridDim.x + blockIdx.x] = (unsigned long long)(s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
+  }
 }
 
 // ---------------------------------------------------------------------------
