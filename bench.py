@@ -208,6 +208,7 @@ def main():
                        "ms_create_total": 1e3 * t_create, "ms_create_voigt_table_kernels": stats["ms_create_table"],
                        "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
                        "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],
+                       "ms_host_cia": stats["ms_cia"], "ms_host_total_profiled_run": stats["ms_host_total"],
                        "b_alg_run_bytes": b_alg_run,
                        "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -61,8 +61,9 @@ struct trx_handle {
   LinesDev L{};
   std::vector<double> h_gwavn; std::vector<int32_t> h_gblock;   // host copies for the per-run prologue
   // CIA (host copies)
-  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs; };
+  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs; DevBuf d_wn, d_temp, d_cs; };
   std::vector<Cia> cia;
+  DevBuf d_cia_ws, d_cia_dens; std::vector<double> h_cia_dens;
   // per-run workspaces (grown on demand)
   int ws_nr = 0, ws_chunk = 0;
   DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags, d_part2, d_part3;
@@ -277,48 +278,59 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   return TRX_OK;
 }
 
-// ---- CIA on the host: crosssec.c:272-344 + 354-428 --------------------------
-int cia_host(trx_handle *h, const trx_atm *a, const trx_opts *o, std::vector<double> &ecs /* [nr][nsh] */)
+// ---- CIA: crosssec.c:272-344 + 354-428, device kernels ----------------------
+// Host part: range checks and the no-extrapolation index windows only.
+int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double *d_tlay /* [nr] on device */)
 {
-  const long nr = a->nlayer, nsh = (long)h->nsh;
-  ecs.assign((size_t)nr * nsh, 0.0);
+  const int nr = a->nlayer; const long long nsh = h->nsh;
+  HIPCHK(h, hipMemsetAsync(h->d_ecs.p, 0, sizeof(double) * (size_t)nr * nsh, h->stream));
   if (h->cia.empty()) return TRX_OK;
-  double tmin = 0.0, tmax = 70000.0;
-  for (auto &c : h->cia) { tmin = std::fmax(tmin, c.temp.front()); tmax = std::fmin(tmax, c.temp.back()); }
-  for (long i = 0; i < nr; i++)
+  double tmin = 0.0, tmax = 70000.0;                        // crosssec.c:44-45, 175-176
+  size_t nwmax = 0;
+  for (auto &c : h->cia) { tmin = std::fmax(tmin, c.temp.front()); tmax = std::fmin(tmax, c.temp.back()); nwmax = std::max(nwmax, c.wn.size()); }
+  for (int i = 0; i < nr; i++)
     if (a->temp[i] < tmin || a->temp[i] > tmax) return fail(h, TRX_E_RANGE, "layer temperature outside the CIA tables");
-  std::vector<double> w(nsh);
-  for (long i = 0; i < nsh; i++) w[i] = o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d);
-  for (auto &c : h->cia) {
-    const long nx1 = (long)c.wn.size(), nx2 = (long)c.temp.size();
-    const double *x1 = c.wn.data(), *x2 = c.temp.data(), *t1 = w.data(), *t2 = a->temp;
-    const long nt1 = nsh, nt2 = nr;
-    const double fx1 = x1[0], fx2 = x2[0], lx1 = x1[nx1-1], lx2 = x2[nx2-1];
-    if (t1[0] > lx1 || t1[nt1-1] < fx1 || t2[0] > lx2 || t2[nt2-1] < fx2) continue;   // crosssec.c:376-377
-    long fi = 0, li = nt1, fj = 0, lj = nt2;
-    while (t1[fi] < fx1) fi++;
-    for (long i = 0; i < li; i++) if (t1[i] > lx1) li = i;
-    while (t2[fj] < fx2) fj++;
-    for (long j = 0; j < lj; j++) if (t2[j] > lx2) lj = j;
-    std::vector<double> z1(nx2), z2(nx1), u(std::max(nx1, nx2)), v(std::max(nx1, nx2)), mid((size_t)nt2 * nx1);
-    for (long i = 0; i < nx1; i++) {
-      spline_second_derivs(z1.data(), x2, &c.cs[(size_t)i * nx2], nx2, u.data(), v.data());
-      for (long j = fj; j < lj; j++)
-        mid[(size_t)j * nx1 + i] = spline_eval_pt(z1.data(), nx2, x2, &c.cs[(size_t)i * nx2], t2[j]);
-    }
-    for (long j = fj; j < lj; j++) {
-      double dens = 1.0;
-      for (int k = 0; k < c.nspec; k++) {
-        const int m = c.mol[k];
-        dens *= a->density[(size_t)m * nr + j] / (kAmu * h->mol_mass[m] * kAmagat);
+  int rc;
+  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 4 * nwmax * (size_t)nr))) return rc;
+  if ((rc = ensure(h, h->d_cia_dens, sizeof(double) * (size_t)nr * h->cia.size()))) return rc;
+  std::vector<double> &dens = h->h_cia_dens;     // member: must outlive the async copy
+  dens.resize((size_t)nr * h->cia.size());
+  for (size_t n = 0; n < h->cia.size(); n++)
+    for (int j = 0; j < nr; j++) {
+      double d = 1.0;
+      for (int k = 0; k < h->cia[n].nspec; k++) {
+        const int m = h->cia[n].mol[k];
+        d *= a->density[(size_t)m * nr + j] / (kAmu * h->mol_mass[m] * kAmagat);
       }
-      spline_second_derivs(z2.data(), x1, &mid[(size_t)j * nx1], nx1, u.data(), v.data());
-      for (long i = fi; i < li; i++) {
-        const double val = spline_eval_pt(z2.data(), nx1, x1, &mid[(size_t)j * nx1], t1[i]);
-        if (val > 0) ecs[(size_t)j * nsh + i] += val * dens;
-      }
+      dens[n * nr + j] = d;
     }
+  HIPCHK(h, hipMemcpyAsync(h->d_cia_dens.p, dens.data(), dens.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  auto wn_at = [&](long long i) { return o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d); };
+  for (size_t n = 0; n < h->cia.size(); n++) {
+    auto &c = h->cia[n];
+    const long long nt1 = nsh; const int nt2 = nr;
+    const double fx1 = c.wn.front(), lx1 = c.wn.back(), fx2 = c.temp.front(), lx2 = c.temp.back();
+    if (wn_at(0) > lx1 || wn_at(nt1 - 1) < fx1 || a->temp[0] > lx2 || a->temp[nt2 - 1] < fx2) continue;   // crosssec.c:376-377
+    // first index not below the table, first index above it (crosssec.c:381-393)
+    long long fi = (long long)std::floor((fx1 / o->wn_fct - h->wn_i) / h->wn_d) - h->lo - 2;
+    if (fi < 0) fi = 0;
+    while (fi < nt1 && wn_at(fi) < fx1) fi++;
+    long long li = (long long)std::ceil((lx1 / o->wn_fct - h->wn_i) / h->wn_d) - h->lo + 2;
+    if (li > nt1) li = nt1;
+    while (li > 0 && wn_at(li - 1) > lx1) li--;
+    int fj = 0, lj = nt2;
+    while (a->temp[fj] < fx2) fj++;
+    for (int j = 0; j < lj; j++) if (a->temp[j] > lx2) lj = j;
+    if (fi >= li || fj >= lj) continue;
+    CiaDev C{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>()};
+    double *mid = h->d_cia_ws.as<double>(), *z2 = mid + nwmax * nr, *u = z2 + nwmax * nr, *v = u + nwmax * nr;
+    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)((C.nwave + 63) / 64)), dim3(64), 0, h->stream, C, nr, d_tlay, fj, lj, mid);
+    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, h->stream, C, nr, fj, lj, mid, z2, u, v);
+    hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li - fi + 255) / 256), (unsigned)(lj - fj)), dim3(256), 0, h->stream,
+                       C, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi, li, fj, mid, z2,
+                       h->d_cia_dens.as<double>() + n * nr, h->d_ecs.as<double>());
   }
+  HIPCHK(h, hipGetLastError());
   return TRX_OK;
 }
 
@@ -338,19 +350,30 @@ void simpson_weights(const double *x, int n, double *row, double *h0)
 }
 
 // smallest wavenumber w for which alphad*w/alphal >= 0.1 holds in double
-// arithmetic (extinction.c:480); the predicate is monotone in w.
+// arithmetic (extinction.c:480); the predicate is monotone in w, so start from
+// the algebraic root and walk the few ulps to the exact floating-point edge.
 double doppler_refresh_cut(double alphad, double alphal)
 {
   auto cond = [&](double w) { return alphad * w / alphal >= 1e-1; };
-  double lo = 0.0, hi = 1e30;
-  if (!cond(hi)) return HUGE_VAL;
-  if (cond(std::nextafter(0.0, 1.0))) return 0.0;
-  while (std::nextafter(lo, hi) < hi) {
-    double mid = lo + (hi - lo) / 2;
-    if (mid <= lo || mid >= hi) mid = std::nextafter(lo, hi);
-    if (cond(mid)) hi = mid; else lo = mid;
+  if (!(alphad > 0) || !(alphal > 0)) {                 // degenerate widths: bisection over all doubles
+    double lo = 0.0, hi = 1e300;
+    if (!cond(hi)) return HUGE_VAL;
+    if (cond(std::nextafter(0.0, 1.0))) return 0.0;
+    while (std::nextafter(lo, hi) < hi) {
+      double mid = lo + (hi - lo) / 2;
+      if (mid <= lo || mid >= hi) mid = std::nextafter(lo, hi);
+      if (cond(mid)) hi = mid; else lo = mid;
+    }
+    return hi;
   }
-  return hi;
+  double w = 1e-1 * alphal / alphad;
+  if (!std::isfinite(w)) return HUGE_VAL;
+  while (!cond(w)) w = std::nextafter(w, HUGE_VAL);
+  for (;;) {
+    const double p = std::nextafter(w, 0.0);
+    if (p > 0 && cond(p)) w = p; else break;
+  }
+  return w;
 }
 
 }  // namespace
@@ -422,8 +445,11 @@ int trx_create(const trx_static *s, trx_handle **out)
     trx_handle::Cia t; t.nspec = c.nspec; t.mol[0] = c.mol[0]; t.mol[1] = c.mol[1];
     t.wn.assign(c.wn, c.wn + c.nwave); t.temp.assign(c.temp, c.temp + c.ntemp);
     t.cs.assign(c.cs, c.cs + (size_t)c.nwave * c.ntemp);
+    if (c.ntemp > kMaxCiaTemps) return bail(TRX_E_UNSUPPORTED);
     h->cia.push_back(std::move(t));
   }
+  for (auto &c : h->cia)
+    if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs))) return bail(rc);
   if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
   if ((rc = prepare_lines(h, s)) != TRX_OK) { std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
   *out = h;
@@ -582,10 +608,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   for (int i = 0; i < nr; i++) ipv[i] = a->radius[nr - 1 - i];
 
   // ---- CIA -----------------------------------------------------------------
-  std::vector<double> ecs;
-  const auto t_cia0 = std::chrono::steady_clock::now();
-  if ((rc = cia_host(h, a, o, ecs))) return rc;
-  const double ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cia0).count();
+  double ms_cia = 0;
 
   // ---- workspaces -------------------------------------------------------------
   const size_t ln_b = (size_t)std::max<int64_t>(h->nlines, 1), gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
@@ -602,7 +625,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                (rc = ensure(h, h->d_part3, 8 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4)))))
     return rc;
   if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, i32)) || (rc = upload(h, h->d_geom, geom)) ||
-      (rc = upload(h, h->d_ecs, ecs)))
+      (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))
     return rc;
   if ((rc = upload(h, h->d_ip, ipv))) return rc;
   HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * nr, st));
@@ -624,6 +647,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
   const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride;
+
+  // ---- CIA extinction (device) ----------------------------------------------------
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = cia_device(h, a, o, d_tempk))) return rc;
+    ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
 
   // ---- events -----------------------------------------------------------------
   std::vector<hipEvent_t> ev;
@@ -689,7 +719,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
-      hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, T);
+      hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + kTauW - 1) / kTauW)), dim3(256), 0, st, T);
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, h->d_flags.as<int>(), nc, (int)eager);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
@@ -710,7 +740,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
     }
     E.intens = h->d_intens.as<double>(); E.flux = d_out;
-    hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + 15) / 16)), dim3(256), 0, st, E);
   } else {
     ModArgs M{};
     M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
@@ -755,7 +785,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   if (dbg) {
     if (dbg->e)    HIPCHK(h, hipMemcpy(dbg->e, h->d_e.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-    if (dbg->e_cs) std::memcpy(dbg->e_cs, ecs.data(), sizeof(double) * nr * nsh);
+    if (dbg->e_cs) HIPCHK(h, hipMemcpy(dbg->e_cs, h->d_ecs.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
     if (dbg->tau || dbg->last) {
       std::vector<double> t((size_t)nr * nsh); std::vector<int> l(nsh);
       HIPCHK(h, hipMemcpy(t.data(), h->d_tau.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));

@@ -434,6 +434,55 @@ void k_accumulate(AccumArgs A)
 }
 
 // ---------------------------------------------------------------------------
+// CIA / cross-section extinction
+// ---------------------------------------------------------------------------
+// crosssec.c:272-344 (interpcs) + :354-428 (bicubicinterpolate): natural cubic
+// splines (pu/src/spline.c), first along temperature for every table row, then
+// along wavenumber for every layer; no extrapolation; negative values dropped.
+constexpr int kMaxCiaTemps = 64;
+struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs; };
+
+// one lane per table row: spline in T, evaluated at the layer temperatures.
+// mid is [nwave][nr] so that the next kernel walks it with unit stride per lane.
+__global__ __launch_bounds__(64)
+void k_cia_rows(CiaDev C, int nr, const double *__restrict__ tlay, int fj, int lj,
+                double *__restrict__ mid)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= C.nwave) return;
+  double z[kMaxCiaTemps], u[kMaxCiaTemps], v[kMaxCiaTemps];
+  const double *row = C.cs + (long long)i * C.ntemp;
+  spline_second_derivs(z, C.temp, row, C.ntemp, u, v);
+  for (int j = fj; j < lj; j++)
+    mid[(long long)i * nr + j] = spline_eval_pt(z, C.ntemp, C.temp, row, tlay[j]);
+}
+
+// one lane per layer: second derivatives of the wavenumber spline (sequential
+// tridiagonal sweep over the table rows); z2/u/v are [nwave][nr].
+__global__ __launch_bounds__(64)
+void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ mid,
+                  double *__restrict__ z2, double *__restrict__ u, double *__restrict__ v)
+{
+  const int j = fj + blockIdx.x * 64 + threadIdx.x;
+  if (j >= lj) return;
+  spline_second_derivs(z2 + j, C.wn, mid + j, C.nwave, u + j, v + j, nr, 1, nr, nr);
+}
+
+// one lane per (wavenumber, layer): evaluate, scale by the density product, add
+__global__ __launch_bounds__(256)
+void k_cia_eval(CiaDev C, int nr, long long nsh, long long lo, double wn_i, double wn_d, double wn_fct,
+                long long fi, long long li, int fj, const double *__restrict__ mid,
+                const double *__restrict__ z2, const double *__restrict__ dens, double *__restrict__ ecs)
+{
+  const long long w = fi + (long long)blockIdx.x * 256 + threadIdx.x;
+  const int j = fj + blockIdx.y;
+  if (w >= li) return;
+  const double xo = wn_fct * (wn_i + (double)(lo + w) * wn_d);
+  const double val = spline_eval_pt(z2 + j, C.nwave, C.wn, mid + j, xo, nr, 1, nr);
+  if (val > 0) ecs[(long long)j * nsh + w] += val * dens[j];
+}
+
+// ---------------------------------------------------------------------------
 // optical depth
 // ---------------------------------------------------------------------------
 struct TauArgs {
@@ -491,69 +540,106 @@ __device__ __forceinline__ double cloud_term(const TauArgs &T, int r, double wn)
   return 0.0;
 }
 
-// One lane per wavenumber; heights are visited top-down, a chunk of layers per
-// launch (tau.c:235-290).  All lanes of a wave walk the same height, so the
-// Simpson weights are wave-uniform loads and er[layer][w] reads are coalesced.
+// Heights are visited top-down, a chunk of layers per launch (tau.c:235-290).
+// A 256-thread block owns 256/kTauH wavenumbers x kTauH heights:
+//   phase 1 (one lane per wavenumber): total extinction of the chunk's layers
+//           (tau.c:231-232) and the bottom-point parabola of every height, which
+//           the eclipse geometry leaves in er (eclipse.c:65-66) -- a short
+//           sequential chain down the chunk;
+//   phase 2 (one lane per wavenumber x height): the Simpson sums, independent
+//           once the chain is known; weights are wave-uniform loads, er reads are
+//           coalesced along the wavenumber axis;
+//   phase 3 (one lane per wavenumber): toomuch cut in height order (tau.c:277-287).
+constexpr int kTauH = 16;                 // heights per block (>= layers per chunk)
+constexpr int kTauW = 256 / kTauH;        // wavenumbers per block
+
 __global__ __launch_bounds__(256)
 void k_optical_depth(TauArgs T)
 {
   if (!T.eager && T.flags[0] == 0) return;
-  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ double s_y0[kTauH][kTauW];
+  __shared__ double s_tv[kTauH][kTauW];
+  __shared__ int s_alive[kTauW];
+  const int wi = threadIdx.x % kTauW, hc = threadIdx.x / kTauW;
+  const long long w = (long long)blockIdx.x * kTauW + wi;
   const bool ok = w < T.nsh;
   const int nr = T.nr;
-  const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
-  bool alive = ok && (T.last[ok ? w : 0] < 0);
 
-  if (ok) {                                              // tau.c:231-232, 267-268
-    for (int c = 0; c < T.nc; c++) {
-      const int r = T.r_top - c;
-      const long long k = (long long)r * T.nsh + w;
-      T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
-    }
-  }
-  if (alive) {
-    for (int c = 0; c < T.nc; c++) {
-      const int rs = T.r_top - c;                        // layer reached by this height
-      const int ri = nr - 1 - rs;                        // height index from the top
-      double t;
-      if (rs == nr - 1) {
-        t = 0.0;                                         // eclipse.c:45-46, slantpath.c:37-38
-      } else {
-        const int n = nr - rs;
-        const double *y = T.er + (long long)rs * T.nsh + w;       // y[j*nsh] = er[rs+j][w]
-        const double *g = T.gw + (long long)rs * T.gstride;
-        double res;
-        if (n == 2) {                                    // eclipse.c:65,68-80
-          const double ym = T.er[(long long)(rs - 1) * T.nsh + w];
-          const double y0 = parab3(T.rad[rs-1], T.rad[rs], ym, y[0], y[T.nsh], T.rad[rs]);
-          const double y2 = y[T.nsh];
-          const double y1 = (T.solution == 0) ? (y2 + y0) / 2.0 : (y0 + y2) / 2.0;
-          res = ((y0 * g[0] + y1 * g[1] + y2 * g[2]) * g[3]) / 6.0;
-        } else {
-          const double y0 = parab3(T.rad[rs], T.rad[rs+1], y[0], y[T.nsh], y[2*T.nsh], T.rad[rs]);
-          if (T.solution == 0) T.er[(long long)rs * T.nsh + w] = y0;   // not restored: eclipse.c:66
-          const int even = (n % 2 == 0);
-          double acc = 0.0;
-          const int npair = (n - 1) / 2;
-          for (int i = 0; i < npair; i++) {
-            const int j = 2*i + even;
-            const double ya = (j == 0) ? y0 : y[(long long)j * T.nsh];
-            const double yb = y[(long long)(j+1) * T.nsh], yc = y[(long long)(j+2) * T.nsh];
-            acc += (ya * g[4*i] + yb * g[4*i+1] + yc * g[4*i+2]) * g[4*i+3];
-          }
-          res = acc / 6.0;
-          if (even) res += T.gh0[rs] * (y0 + y[T.nsh]) / 2;
-        }
-        t = (T.solution == 0) ? res : 2 * res;
+  if (hc == 0) {
+    const bool alive = ok && T.last[w] < 0;
+    s_alive[wi] = alive;
+    if (alive) {
+      const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
+      for (int c = 0; c < T.nc; c++) {
+        const int r = T.r_top - c;
+        const long long k = (long long)r * T.nsh + w;
+        T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
       }
-      const double tv = T.rad_fct * t;
-      T.tau[(long long)ri * T.nsh + w] = tv;
-      if (tv > T.toomuch) { T.last[w] = ri; alive = false; break; }     // tau.c:277-287
-      if (ri == nr - 1)   { T.last[w] = ri; alive = false; break; }     // tau.c:299-304
+      for (int c = 0; c < T.nc; c++) {
+        const int rs = T.r_top - c;
+        const int n = nr - rs;
+        if (n < 2) { s_y0[c][wi] = 0.0; continue; }
+        const double *y = T.er + (long long)rs * T.nsh + w;
+        double y0;
+        if (n == 2) {                                     // eclipse.c:65, restored at :75-76
+          y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], y[0], y[T.nsh], T.rad[rs]);
+        } else {
+          y0 = parab3(T.rad[rs], T.rad[rs+1], y[0], y[T.nsh], y[2*T.nsh], T.rad[rs]);
+          if (T.solution == 0) T.er[(long long)rs * T.nsh + w] = y0;    // not restored: eclipse.c:66
+        }
+        s_y0[c][wi] = y0;
+      }
     }
   }
-  const unsigned long long still = __ballot(alive);
-  if ((threadIdx.x & 63) == 0 && still) atomicAdd(&T.flags[1], __popcll(still));
+  __syncthreads();
+
+  if (hc < T.nc && s_alive[wi]) {
+    const int c = hc;
+    const int rs = T.r_top - c;
+    double t;
+    if (rs == nr - 1) {
+      t = 0.0;                                            // eclipse.c:45-46, slantpath.c:37-38
+    } else {
+      const int n = nr - rs;
+      const double *y = T.er + (long long)rs * T.nsh + w;           // y[j*nsh] = er[rs+j][w]
+      const double *g = T.gw + (long long)rs * T.gstride;
+      const double y0 = s_y0[c][wi];
+      double res;
+      if (n == 2) {                                       // eclipse.c:68-80, slantpath.c:62-74
+        const double y2 = y[T.nsh];
+        const double y1 = (y2 + y0) / 2.0;
+        res = ((y0 * g[0] + y1 * g[1] + y2 * g[2]) * g[3]) / 6.0;
+      } else {
+        const int even = (n % 2 == 0);
+        double acc = 0.0;
+        const int npair = (n - 1) / 2;
+        for (int i = 0; i < npair; i++) {
+          const int j = 2*i + even;
+          const double ya = (j == 0) ? y0 : y[(long long)j * T.nsh];
+          const double yb = y[(long long)(j+1) * T.nsh], yc = y[(long long)(j+2) * T.nsh];
+          acc += (ya * g[4*i] + yb * g[4*i+1] + yc * g[4*i+2]) * g[4*i+3];
+        }
+        res = acc / 6.0;
+        if (even) res += T.gh0[rs] * (y0 + y[T.nsh]) / 2;
+      }
+      t = (T.solution == 0) ? res : 2 * res;
+    }
+    s_tv[c][wi] = T.rad_fct * t;
+  }
+  __syncthreads();
+
+  bool still = false;
+  if (hc == 0 && s_alive[wi]) {
+    still = true;
+    for (int c = 0; c < T.nc; c++) {
+      const int ri = nr - 1 - (T.r_top - c);
+      const double tv = s_tv[c][wi];
+      T.tau[(long long)ri * T.nsh + w] = tv;
+      if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
+    }
+  }
+  const unsigned long long m = __ballot(still);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&T.flags[1], __popcll(m));
 }
 
 // flags[0] <- rays still descending; counts the layers actually swept
@@ -576,35 +662,40 @@ struct EmisArgs {
   double *flux;                      // [nsh]
 };
 
-// eclipse.c:118-160 (eclipse_intens) for every angle + eclipse.c:243-287 (flux)
+// eclipse.c:118-160 (eclipse_intens) + eclipse.c:243-287 (flux).
+// Block = 16 wavenumbers x 16 angle slots: one lane per (wavenumber, angle)
+// integrates the intensity, then the angle-0 lanes add the flux in angle order.
 __global__ __launch_bounds__(256)
 void k_emission(EmisArgs E)
 {
-  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (w >= E.nsh) return;
-  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
-  const int last = E.last[w];
-  const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
-  const double pl_exp = kH * wv * kLs;
-  double Bp = 0, dtp[kMaxAngles], sum[kMaxAngles];
-  for (int a = 0; a < E.nang; a++) { sum[a] = 0; dtp[a] = 0; }
-  for (int i = 0; i <= last; i++) {
-    const double tv = E.tau[(long long)i * E.nsh + w];
-    const double B = pl_num / (exp(pl_exp / (kKb * E.temp[E.nr - 1 - i])) - 1.0);
-    for (int a = 0; a < E.nang; a++) {
-      const double dt = exp(-tv / E.cosang[a]);
-      if (i > 0) sum[a] += (dt - dtp[a]) * (B + Bp);     // numerical.c:168-170
-      dtp[a] = dt;
+  __shared__ double s_I[kMaxAngles][16];
+  const int wi = threadIdx.x % 16, a = threadIdx.x / 16;
+  const long long w = (long long)blockIdx.x * 16 + wi;
+  const bool ok = w < E.nsh;
+  if (ok && a < E.nang) {
+    const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
+    const int last = E.last[w];
+    const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
+    const double pl_exp = kH * wv * kLs;
+    const double ca = E.cosang[a];
+    double Bp = 0, dtp = 0, sum = 0;
+    for (int i = 0; i <= last; i++) {
+      const double tv = E.tau[(long long)i * E.nsh + w];
+      const double B = pl_num / (exp(pl_exp / (kKb * E.temp[E.nr - 1 - i])) - 1.0);
+      const double dt = exp(-tv / ca);
+      if (i > 0) sum += (dt - dtp) * (B + Bp);            // numerical.c:168-170
+      dtp = dt; Bp = B;
     }
-    Bp = B;
-  }
-  double fl = 0.0;
-  for (int a = 0; a < E.nang; a++) {
-    const double I = Bp * dtp[a] - 0.5 * sum[a];
+    const double I = Bp * dtp - 0.5 * sum;
     E.intens[(long long)a * E.nsh + w] = I;
-    fl += kPi * I * E.area[a];
+    s_I[a][wi] = I;
   }
-  E.flux[w] = fl;
+  __syncthreads();
+  if (ok && a == 0) {
+    double fl = 0.0;
+    for (int k = 0; k < E.nang; k++) fl += kPi * s_I[k][wi] * E.area[k];
+    E.flux[w] = fl;
+  }
 }
 
 struct ModArgs {
