@@ -123,6 +123,7 @@ def main():
     from transit_amd.host import Problem
     from transit_amd.engine import Engine
     from transit_amd.shard import shard_bounds
+    from transit_amd import dist as tdist
 
     d = make_workload(args, "r%d" % rank, args.lines)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
@@ -131,6 +132,10 @@ def main():
     P.set_shard(lo, hi)
     st = P.static
     st.device = local
+    comm = None
+    if world > 1:       # in-stream all-reduce of the per-layer line-strength maxima (engine side)
+        comm = tdist.create_comm(world, rank, local)
+        st.comm, st.nranks, st.rank = comm, world, rank
     t0 = time.time()
     eng = Engine(st)
     t_create = time.time() - t0
@@ -138,14 +143,14 @@ def main():
     opts.layer_chunk = args.layer_chunk
     opts.profile = 0
 
-    spec_local = torch.zeros(hi - lo, dtype=torch.float64, device=dev)
-    counts = [shard_bounds(nwn, world, r)[1] - shard_bounds(nwn, world, r)[0] for r in range(world)]
-    gathered = [torch.zeros(c, dtype=torch.float64, device=dev) for c in counts] if world > 1 else None
+    mpad = tdist.padded_len(nwn, world)
+    spec_local = torch.zeros(mpad, dtype=torch.float64, device=dev)      # slice + padding to equal counts
+    gathered = torch.zeros(mpad * world, dtype=torch.float64, device=dev) if world > 1 else None
 
     def step():
         eng.run_device(P.atm, opts, spec_local.data_ptr())
         if world > 1:
-            dist.all_gather(gathered, spec_local)            # the single RCCL gather of the path
+            dist.all_gather_into_tensor(gathered, spec_local)   # the single RCCL gather of the path
 
     def fence():
         if world > 1:
@@ -176,9 +181,9 @@ def main():
         t = torch.tensor([layers_needed], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         layers_needed = int(t.item())
-        full = torch.cat(gathered).cpu().numpy()
+        full = tdist.gather_spectrum(spec_local, nwn, world, rank, out=gathered).cpu().numpy()
     else:
-        full = spec_local.cpu().numpy()
+        full = spec_local[: hi - lo].cpu().numpy()
 
     if rank == 0:
         L, R, nang = stats["nlines_inrange"], stats["layers_swept"], int(opts.nangles)
@@ -224,6 +229,7 @@ def main():
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
+        tdist.destroy_comm(comm)
         dist.barrier()
         dist.destroy_process_group()
 

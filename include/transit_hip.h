@@ -103,6 +103,13 @@ typedef struct {
   /* CIA tables                                                                */
   int32_t ncia;
   const trx_cia *cia;
+
+  /* multi-GPU job: communicator from trx_comm_create (NULL for one GPU).  With
+   * a communicator each handle sweeps only the lines whose profiles can reach
+   * its shard and the per-layer maximum line strength (extinction.c:399-427,
+   * a global quantity) is agreed by one small in-stream all-reduce per step. */
+  void   *comm;
+  int32_t nranks, rank;
 } trx_static;
 
 /* Per-spectrum atmosphere, already on transit's layer grid, bottom layer first
@@ -208,6 +215,15 @@ int  trx_table_info(const trx_handle *h, int64_t *profsize /* [ndop*nlor] */,
                     int64_t *total_floats);
 int  trx_table_copy(const trx_handle *h, float *out /* [total_floats] */);
 int  trx_width_grids(const trx_handle *h, double *adop /* [ndop] */, double *alor /* [nlor] */);
+
+/* RCCL communicator for the wavenumber-sharded job (one process per GPU).
+ * Rank 0 calls trx_comm_unique_id and ships the 128 bytes to the other ranks
+ * by any channel (torch.distributed, MPI, a file); every rank then calls
+ * trx_comm_create on its own device. */
+#define TRX_COMM_ID_BYTES 128
+int  trx_comm_unique_id(void *id_out /* TRX_COMM_ID_BYTES */);
+int  trx_comm_create(const void *id, int nranks, int rank, int device, void **comm_out);
+void trx_comm_destroy(void *comm);
 
 const char *trx_strerror(int status);
 const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */

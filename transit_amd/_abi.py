@@ -40,6 +40,7 @@ class TrxStatic(C.Structure):
         ("nmol", C.c_int32), ("mol_mass", c_double_p), ("mol_radius", c_double_p),
         ("mol_pol", c_double_p), ("mol_is_h2", c_int32_p),
         ("ncia", C.c_int32), ("cia", C.POINTER(TrxCia)),
+        ("comm", C.c_void_p), ("nranks", C.c_int32), ("rank", C.c_int32),
     ]
 
 

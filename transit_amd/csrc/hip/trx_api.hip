@@ -12,6 +12,8 @@
 // Everything per (line x layer), per (group x layer x bin) and per
 // (wavenumber x layer) runs in the kernels of trx_kernels.hip.h.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -59,7 +61,8 @@ struct trx_handle {
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
   DevBuf d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
   LinesDev L{};
-  std::vector<double> h_gwavn; std::vector<int32_t> h_gblock;   // host copies for the per-run prologue
+  std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
+  void *comm = nullptr; int nranks = 1, rank = 0;
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs; DevBuf d_wn, d_temp, d_cs; };
   std::vector<Cia> cia;
@@ -267,7 +270,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
       (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
     return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
-  h->h_gwavn = gwavn; h->h_gblock = gblock;
+  h->h_gwavn = gwavn; h->h_gblock = gblock; h->h_cntge = cntge; h->h_gfirst = gfirst; h->h_gcount = gcount;
   LinesDev &L = h->L;
   L.nlines = n; L.wavn = h->d_wavn.as<double>(); L.elow = h->d_elow.as<double>(); L.gf = h->d_gf.as<double>();
   L.iso = h->d_iso.as<int16_t>(); L.inrange = h->d_inr.as<uint8_t>();
@@ -376,10 +379,67 @@ double doppler_refresh_cut(double alphad, double alphal)
   return w;
 }
 
+// ---- RCCL, resolved at run time (the library must load on a CPU-only box) ---
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllReduce; }
+};
+Rccl &rccl()
+{
+  static Rccl R;
+  if (R.lib) return R;
+  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char *n : names) if ((R.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;    // the copy torch already mapped
+  if (!R.lib) for (const char *n : names) if ((R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!R.lib) return R;
+  R.GetUniqueId  = (decltype(R.GetUniqueId))dlsym(R.lib, "ncclGetUniqueId");
+  R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.lib, "ncclCommInitRank");
+  R.CommDestroy  = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
+  R.AllReduce    = (decltype(R.AllReduce))dlsym(R.lib, "ncclAllReduce");
+  R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
+  return R;
+}
+
 }  // namespace
 
 // ============================================================================
 extern "C" {
+
+int trx_comm_unique_id(void *id_out)
+{
+  if (!id_out) return TRX_E_ARG;
+  static_assert(sizeof(ncclUniqueId) == TRX_COMM_ID_BYTES, "unique id size");
+  Rccl &R = rccl();
+  if (!R.ok()) return TRX_E_UNSUPPORTED;
+  ncclUniqueId id;
+  if (R.GetUniqueId(&id) != ncclSuccess) return TRX_E_HIP;
+  std::memcpy(id_out, &id, sizeof(id));
+  return TRX_OK;
+}
+
+int trx_comm_create(const void *idp, int nranks, int rank, int device, void **comm_out)
+{
+  if (!idp || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return TRX_E_ARG;
+  Rccl &R = rccl();
+  if (!R.ok()) return TRX_E_UNSUPPORTED;
+  if (hipSetDevice(device) != hipSuccess) return TRX_E_NODEVICE;
+  ncclUniqueId id; std::memcpy(&id, idp, sizeof(id));
+  ncclComm_t c = nullptr;
+  if (R.CommInitRank(&c, nranks, id, rank) != ncclSuccess) return TRX_E_HIP;
+  *comm_out = (void *)c;
+  return TRX_OK;
+}
+
+void trx_comm_destroy(void *comm)
+{
+  if (comm && rccl().ok()) (void)rccl().CommDestroy((ncclComm_t)comm);
+}
+
 
 int trx_abi_version(void) { return TRX_ABI_VERSION; }
 
@@ -431,6 +491,8 @@ int trx_create(const trx_static *s, trx_handle **out)
   h->wn_i = s->wn_i; h->wn_d = s->wn_d; h->osamp = s->osamp; h->odwn = s->wn_d / s->osamp;
   h->nwn = s->nwn; h->nown = s->nown; h->lo = s->wn_lo; h->hi = s->wn_hi; h->nsh = s->wn_hi - s->wn_lo;
   h->niso = s->niso; h->nmol = s->nmol; h->ndop = s->ndop; h->nlor = s->nlor;
+  h->comm = s->comm; h->nranks = s->comm ? std::max(1, s->nranks) : 1; h->rank = s->rank;
+  if (h->comm && !rccl().ok()) return bail(TRX_E_UNSUPPORTED);
   h->iso_mass.assign(s->iso_mass, s->iso_mass + s->niso);
   h->iso_ratio.assign(s->iso_ratio, s->iso_ratio + s->niso);
   h->iso_imol.assign(s->iso_imol, s->iso_imol + s->niso);
@@ -668,20 +730,53 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   for (int r_top = nr - 1; r_top >= 0; ) {
     const int nc = std::min(nc_max, r_top + 1);
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    if (h->nlines > 0) {
-      hipLaunchKernelGGL(k_line_strength, dim3((unsigned)((h->nlines + 255) / 256)), dim3(256), 0, st,
-                         h->L, Y, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<unsigned long long>(),
+    // lines / groups whose profiles can reach this shard in any layer of the chunk
+    Segments GL{}, GG{};
+    {
+      long long nl_tot = 0, ng_tot = 0;
+      for (int b = 0; b < niso; b++) {
+        const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
+        if (gb0 == gb1) continue;
+        long long psm = 0;
+        for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
+        long long klo = ((long long)h->osamp * h->lo - psm) / h->osamp - 1;
+        long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp + 1;
+        if (klo < 0) klo = 0;
+        if (khi > h->nwn - 1) khi = h->nwn - 1;
+        const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
+        const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
+        if (ga >= gz && h->comm) continue;
+        if (ga < gz) { GG.start[GG.n] = ga; GG.base[GG.n] = ng_tot; ng_tot += gz - ga; GG.n++; }
+        // pass 1 feeds a global maximum: with a communicator every rank reduces
+        // its own window and the maxima are all-reduced; without one (a shard
+        // run on its own) the rank sweeps every line itself.
+        const int la_g = h->comm ? ga : gb0, lz_g = h->comm ? gz : gb1;
+        const long long la = h->h_gfirst[la_g], lz = (long long)h->h_gfirst[lz_g - 1] + h->h_gcount[lz_g - 1];
+        GL.start[GL.n] = la; GL.base[GL.n] = nl_tot; nl_tot += lz - la; GL.n++;
+      }
+      GG.base[GG.n] = ng_tot; GL.base[GL.n] = nl_tot;
+    }
+    const long long seg_lines = GL.base[GL.n], seg_groups = GG.base[GG.n];
+    if (seg_lines > 0) {
+      hipLaunchKernelGGL(k_line_strength, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
+                         h->L, Y, GL, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<unsigned long long>(),
                          h->d_flags.as<int>(), (int)eager);
     }
+    if (h->comm) {      // the layer maximum is global: extinction.c:399-427 runs over every line
+      unsigned long long *km = h->d_kmax.as<unsigned long long>() + (r_top - nc + 1);
+      if (rccl().AllReduce(km, km, (size_t)nc, ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
+        return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
+    }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    const unsigned gblocks = (unsigned)((h->ngroups + 255) / 256);
+    const unsigned gblocks = (unsigned)std::max<long long>(1, (seg_groups + 255) / 256);
     const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
     if (h->ngroups > 0) {
       hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
                          h->L, Y, niso, r_top, nc, h->d_kmax.as<double>(), o->ethresh, h->d_adop.as<double>(), h->ndop,
                          d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), (int)eager);
+      if (seg_groups > 0)
       hipLaunchKernelGGL(k_group_strength, dim3(gblocks), dim3(256), 0, st,
-                         h->L, Y, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<double>(), o->ethresh,
+                         h->L, Y, GG, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<double>(), o->ethresh,
                          h->d_adop.as<double>(), h->ndop, d_wcut, h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(),
                          prof ? h->d_part2.as<unsigned long long>() : nullptr, h->d_flags.as<int>(), (int)eager);
     }

@@ -60,4 +60,13 @@ struct LayerDev {
   const int32_t *psmax;       // largest profile half-size the isotope can use in this layer
 };
 
+// Contiguous index ranges (one per isotope block) that a kernel walks as one
+// flat iteration space: item t belongs to segment s with base[s] <= t < base[s+1]
+// and maps to start[s] + (t - base[s]).
+struct Segments {
+  int n;
+  long long start[kMaxIso];
+  long long base[kMaxIso + 1];
+};
+
 }  // namespace trx

@@ -43,6 +43,12 @@ __device__ __forceinline__ int wave_max_i(int v)
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
+__device__ __forceinline__ long long seg_index(const Segments &G, long long t)
+{
+  int s = 0;
+  while (s + 1 < G.n && t >= G.base[s + 1]) s++;
+  return (t < G.base[G.n]) ? G.start[s] + (t - G.base[s]) : -1;
+}
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll
@@ -174,14 +180,14 @@ void k_voigt_bins_wave(const ProfileJob *jobs, float *table, int m_limit)
 // and parked in S[chunk][line] for pass 2 (instead of re-evaluating them as
 // the reference's second loop does).
 __global__ __launch_bounds__(256)
-void k_line_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
+void k_line_strength(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
                      double *__restrict__ S, unsigned long long *__restrict__ kmax_bits,
                      const int *__restrict__ flags, int eager)
 {
   if (!eager && flags[0] == 0) return;
   __shared__ double red[4][kMaxChunk];
-  const long long ln = (long long)blockIdx.x * 256 + threadIdx.x;
-  const bool ok = ln < L.nlines;
+  const long long ln = seg_index(G, (long long)blockIdx.x * 256 + threadIdx.x);
+  const bool ok = ln >= 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double wavn = 0, elow = 0, gf = 0; int iso = 0; bool inr = false;
   if (ok) {
@@ -216,7 +222,7 @@ void k_line_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
 // Doppler index (0xFF = "use the isotope's sticky index", :480-483).
 // part (optional, profiling only): per-block {evaluated, skipped} counts.
 __global__ __launch_bounds__(256)
-void k_group_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
+void k_group_strength(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
                       const double *__restrict__ S, const double *__restrict__ kmax,
                       double ethresh, const double *__restrict__ adop, int ndop,
                       const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
@@ -229,8 +235,8 @@ void k_group_strength(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
   __shared__ int s_cnt[4][2];
   for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
   __syncthreads();
-  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-  const bool ok = g < L.ngroups;
+  const long long g = seg_index(G, (long long)blockIdx.x * 256 + threadIdx.x);
+  const bool ok = g >= 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int first = 0, cnt = 0, iso = 0; double wavn = 0;
   if (ok) { first = L.gfirst[g]; cnt = L.gcount[g]; iso = L.giso[g]; wavn = L.gwavn[g]; }

@@ -602,6 +602,7 @@ void fill_pods(trh_problem &P)
     P.cia_pod.push_back(t);
   }
   s.ncia = (int)P.cia_pod.size(); s.cia = P.cia_pod.data();
+  s.comm = nullptr; s.nranks = 1; s.rank = 0;
 
   trx_atm &a = P.atm;
   a = trx_atm{};
