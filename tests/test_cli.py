@@ -1,0 +1,57 @@
+"""`transit_hip`, the command-line drop-in for the reference's `transit`."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cases import GOLDEN, rel_err
+from transit_amd import build
+
+
+def _run_cli(tmp_path, case):
+    exe = build.build_cli() or build.lib_path("transit_hip")
+    work = tmp_path / case
+    shutil.copytree(os.path.join(GOLDEN, case), work)
+    for f in ("spectrum.dat", "toomuch.dat"):
+        os.remove(work / f)
+    p = subprocess.run([exe, "-c", "case.cfg"], cwd=work, capture_output=True, text=True, timeout=300)
+    return work, p
+
+
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    work, p = _run_cli(tmp_path, "eclipse_small")
+    assert p.returncode != 0
+    assert "trx_create failed" in p.stderr
+    assert not os.path.exists(work / "spectrum.dat")
+
+
+def test_cli_rejects_unknown_option(tmp_path):
+    exe = build.build_cli() or build.lib_path("transit_hip")
+    p = subprocess.run([exe, "--nosuchoption", "1"], capture_output=True, text=True)
+    assert p.returncode != 0 and "unknown" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["eclipse_small", "transit_small"])
+def test_cli_writes_the_reference_spectrum_file(tmp_path, case):
+    work, p = _run_cli(tmp_path, case)
+    assert p.returncode == 0, p.stderr
+    ref_txt = open(os.path.join(GOLDEN, case, "spectrum.dat")).read().split("\n")
+    got_txt = open(work / "spectrum.dat").read().split("\n")
+    assert got_txt[0] == ref_txt[0]                       # same header line
+    assert len(got_txt) == len(ref_txt)
+    got = ol.read_spectrum(work / "spectrum.dat")
+    ref = ol.read_spectrum(os.path.join(GOLDEN, case, "spectrum.dat"))
+    assert np.array_equal(got[:, 0], ref[:, 0])           # wavelength column: same text
+    assert rel_err(got[:, 1], ref[:, 1]) < 2e-8
+    # toomuch file: same layer index where the optical depth crossed the cut
+    g = np.loadtxt(work / "toomuch.dat", comments="#", skiprows=2)
+    r = np.loadtxt(os.path.join(GOLDEN, case, "toomuch.dat"), comments="#", skiprows=2)
+    assert np.array_equal(g[:, 3], r[:, 3])
+    assert rel_err(g[:, 1], r[:, 1]) < 1e-5

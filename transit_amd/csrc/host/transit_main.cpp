@@ -1,0 +1,68 @@
+// transit_main.cpp -- `transit_hip`: command-line drop-in for the reference's
+// `transit` binary on the spectrum path (transit/src/transit.c:233-242):
+//
+//     transit_hip -c run.cfg [--option value ...]
+//
+// Same options, same cfg grammar, same TLI / atmosphere / CIA / molecule files
+// in, same spectrum (and toomuch) files out.  transit_init() -> trh_load(),
+// do_transit() -> trx_create() + trx_run() on the GPU, free_memory() ->
+// trx_destroy() + trh_free().
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "transit_hip.h"
+#include "transit_host.h"
+
+static double now_s()
+{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv)
+{
+  char err[512] = {0};
+  trh_problem *P = nullptr;
+  double t0 = now_s();
+  int rc = trh_load(argc, argv, &P, err, sizeof(err));
+  if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: %s (%s)\n", err, trx_strerror(rc)); return EXIT_FAILURE; }
+  const char *verb = trh_option(P, "verb");
+  const int verblevel = verb ? std::atoi(verb) : 2;
+  if (verblevel > 3) std::printf("Check point: 00 - 04 inputs read and sampled:  dt = %.4f sec.\n\n", now_s() - t0);
+
+  if (trh_option(P, "justOpacity")) { trh_free(P); return EXIT_SUCCESS; }   // transit.c:133-136
+
+  t0 = now_s();
+  trx_handle *h = nullptr;
+  rc = trx_create(trh_static(P), &h);
+  if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: trx_create failed: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE; }
+  if (verblevel > 3) std::printf("Check point: 00 - 05 opacity (Voigt table on device, line list resident):  dt = %.4f sec.\n\n", now_s() - t0);
+
+  const int64_t nwn = trh_nwn(P);
+  const int nr = trh_atm(P)->nlayer;
+  std::vector<double> spectrum((size_t)nwn), tau;
+  std::vector<int64_t> last;
+  trx_debug dbg{};
+  const bool want_toomuch = trh_option(P, "outtoomuch") != nullptr;
+  if (want_toomuch) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
+
+  t0 = now_s();
+  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), want_toomuch ? &dbg : nullptr);
+  if (rc != TRX_OK) {
+    std::fprintf(stderr, "transit_hip: trx_run failed: %s (%s)\n", trx_strerror(rc), trx_last_error(h));
+    trx_destroy(h); trh_free(P); return EXIT_FAILURE;
+  }
+  if (verblevel > 3) {
+    trx_stats s{}; trx_get_stats(h, &s);
+    std::printf("Check point: 00 - 14 spectrum (CIA + line sweep + optical depth + %s):  dt = %.4f sec.\n"
+                "  lines in range %lld, co-added %lld, layers swept %lld of %d, device time %.3f ms\n\n",
+                trh_opts(P)->solution == TRX_SOL_ECLIPSE ? "intensities + flux" : "modulation",
+                now_s() - t0, (long long)s.nlines_inrange, (long long)s.nadd, (long long)s.layers_swept, nr, s.ms_run_total);
+  }
+  if (want_toomuch) trh_write_toomuch(P, tau.data(), last.data(), nullptr);
+  rc = trh_write_spectrum(P, spectrum.data(), nullptr);
+  if (rc != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the spectrum file\n");
+  trx_destroy(h);
+  trh_free(P);
+  return rc == TRX_OK ? EXIT_SUCCESS : EXIT_FAILURE;
+}
