@@ -188,12 +188,13 @@ def main():
     if rank == 0:
         L, R, nang = stats["nlines_inrange"], stats["layers_swept"], int(opts.nangles)
         launches = max(int(stats["sweep_launches"]), 1)
-        kern = {"k_line_strength": stats["ms_k_line"], "k_group_strength": stats["ms_k_group"],
+        kern = {"k_group_sweep": stats["ms_k_sweep"], "k_sticky_index": stats["ms_k_sticky"],
                 "k_accumulate": stats["ms_k_accum"]}
         dom = max(kern, key=kern.get)
         # algorithmic bytes of the reference's data flow: 26 B per
-        # line per layer per pass; 4 B per accumulated bin + 8 B per stored e
-        alg = {"k_line_strength": 26.0 * L * R, "k_group_strength": 26.0 * L * R,
+        # line per layer per pass (k_group_sweep does both passes' line scans);
+        # 4 B per accumulated bin + 8 B per stored e for the accumulation
+        alg = {"k_group_sweep": 52.0 * L * R, "k_sticky_index": 0.0,
                "k_accumulate": 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
         ach = alg[dom] / launches / (kern[dom] / launches * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
         b_alg_run = 52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * nwn + 8.0 * nwn * (1 + nang)

@@ -181,8 +181,8 @@ typedef struct {
   double  ms_create_table;/* device time of the Voigt-table build              */
   double  ms_run_total;   /* device time of the last run, first to last kernel */
   double  ms_sweep;       /* line-sweep kernels (pass 1 + pass 2 + accumulate) */
-  double  ms_k_line;      /* sum over launches of k_line_strength              */
-  double  ms_k_group;     /* sum over launches of k_group_strength             */
+  double  ms_k_sweep;      /* sum over launches of k_group_sweep (+ all-reduce)   */
+  double  ms_k_sticky;     /* sum over launches of k_sticky_index                */
   double  ms_k_accum;     /* sum over launches of k_accumulate                 */
   int64_t sweep_launches; /* launches of each sweep kernel that did work       */
   double  ms_tau;         /* optical-depth kernels                             */

@@ -47,7 +47,7 @@ def test_hip_code_object_is_gfx950():
         build.build_hip()
     blob = open(path, "rb").read()
     assert b"gfx950" in blob
-    for k in (b"k_line_strength", b"k_group_strength", b"k_accumulate", b"k_optical_depth",
+    for k in (b"k_group_sweep", b"k_sticky_index", b"k_accumulate", b"k_optical_depth",
               b"k_emission", b"k_modulation", b"k_voigt_bins"):
         assert k in blob, k
 

@@ -74,7 +74,7 @@ class TrxStats(C.Structure):
         ("layers_swept", C.c_int64), ("neval", C.c_int64), ("nskip", C.c_int64),
         ("sum_bins", C.c_int64), ("table_floats", C.c_int64),
         ("ms_create_table", C.c_double), ("ms_run_total", C.c_double), ("ms_sweep", C.c_double),
-        ("ms_k_line", C.c_double), ("ms_k_group", C.c_double), ("ms_k_accum", C.c_double),
+        ("ms_k_sweep", C.c_double), ("ms_k_sticky", C.c_double), ("ms_k_accum", C.c_double),
         ("sweep_launches", C.c_int64),
         ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_host_total", C.c_double),
         ("ms_spectrum", C.c_double),

@@ -42,7 +42,8 @@ struct DevBuf {
 
 struct trx_handle {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CIA kernels, overlapped with the first sweep step
+  hipEvent_t ev_inputs = nullptr, ev_cia = nullptr;
   std::string err;
 
   // grids
@@ -283,10 +284,11 @@ int prepare_lines(trx_handle *h, const trx_static *s)
 
 // ---- CIA: crosssec.c:272-344 + 354-428, device kernels ----------------------
 // Host part: range checks and the no-extrapolation index windows only.
-int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double *d_tlay /* [nr] on device */)
+int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double *d_tlay /* [nr] on device */,
+               hipStream_t cst)
 {
   const int nr = a->nlayer; const long long nsh = h->nsh;
-  HIPCHK(h, hipMemsetAsync(h->d_ecs.p, 0, sizeof(double) * (size_t)nr * nsh, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_ecs.p, 0, sizeof(double) * (size_t)nr * nsh, cst));
   if (h->cia.empty()) return TRX_OK;
   double tmin = 0.0, tmax = 70000.0;                        // crosssec.c:44-45, 175-176
   size_t nwmax = 0;
@@ -307,7 +309,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
       }
       dens[n * nr + j] = d;
     }
-  HIPCHK(h, hipMemcpyAsync(h->d_cia_dens.p, dens.data(), dens.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_cia_dens.p, dens.data(), dens.size() * sizeof(double), hipMemcpyHostToDevice, cst));
   auto wn_at = [&](long long i) { return o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d); };
   for (size_t n = 0; n < h->cia.size(); n++) {
     auto &c = h->cia[n];
@@ -327,9 +329,9 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     if (fi >= li || fj >= lj) continue;
     CiaDev C{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>()};
     double *mid = h->d_cia_ws.as<double>(), *z2 = mid + nwmax * nr, *u = z2 + nwmax * nr, *v = u + nwmax * nr;
-    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)((C.nwave + 63) / 64)), dim3(64), 0, h->stream, C, nr, d_tlay, fj, lj, mid);
-    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, h->stream, C, nr, fj, lj, mid, z2, u, v);
-    hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li - fi + 255) / 256), (unsigned)(lj - fj)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)((C.nwave + 63) / 64)), dim3(64), 0, cst, C, nr, d_tlay, fj, lj, mid);
+    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, cst, C, nr, fj, lj, mid, z2, u, v);
+    hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li - fi + 255) / 256), (unsigned)(lj - fj)), dim3(256), 0, cst,
                        C, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi, li, fj, mid, z2,
                        h->d_cia_dens.as<double>() + n * nr, h->d_ecs.as<double>());
   }
@@ -488,6 +490,9 @@ int trx_create(const trx_static *s, trx_handle **out)
   auto bail = [&](int code) { trx_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return bail(TRX_E_NODEVICE);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+  if (hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_cia, hipEventDisableTiming) != hipSuccess) return bail(TRX_E_HIP);
   h->wn_i = s->wn_i; h->wn_d = s->wn_d; h->osamp = s->osamp; h->odwn = s->wn_d / s->osamp;
   h->nwn = s->nwn; h->nown = s->nown; h->lo = s->wn_lo; h->hi = s->wn_hi; h->nsh = s->wn_hi - s->wn_lo;
   h->niso = s->niso; h->nmol = s->nmol; h->ndop = s->ndop; h->nlor = s->nlor;
@@ -522,7 +527,10 @@ void trx_destroy(trx_handle *h)
 {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
+  if (h->ev_cia) (void)hipEventDestroy(h->ev_cia);
   delete h;
 }
 
@@ -673,26 +681,24 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   double ms_cia = 0;
 
   // ---- workspaces -------------------------------------------------------------
-  const size_t ln_b = (size_t)std::max<int64_t>(h->nlines, 1), gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
-  if ((rc = ensure(h, h->d_S, sizeof(double) * ln_b * nc_max)) || (rc = ensure(h, h->d_SG, sizeof(double) * gr_b * nc_max)) ||
+  const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
+  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * nc_max)) ||
       (rc = ensure(h, h->d_idop8, gr_b * nc_max)) || (rc = ensure(h, h->d_kmax, sizeof(double) * nr)) ||
-      (rc = ensure(h, h->d_sticky, sizeof(int) * nli)) || (rc = ensure(h, h->d_counters, 16 * (size_t)nr)) ||
-      (rc = ensure(h, h->d_bins, 8 * (size_t)nr)) || (rc = ensure(h, h->d_flags, 64)) ||
+      (rc = ensure(h, h->d_sticky, sizeof(int) * nli)) || (rc = ensure(h, h->d_counters, 24 * (size_t)nr)) ||
+      (rc = ensure(h, h->d_flags, 64)) ||
       (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
       (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
       (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
       (rc = ensure(h, h->d_status, 16)))
     return rc;
-  if (prof && ((rc = ensure(h, h->d_part2, 16 * (size_t)nc_max * ((gr_b + 255) / 256))) ||
-               (rc = ensure(h, h->d_part3, 8 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4)))))
+  if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4))))
     return rc;
   if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, i32)) || (rc = upload(h, h->d_geom, geom)) ||
       (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))
     return rc;
   if ((rc = upload(h, h->d_ip, ipv))) return rc;
   HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * nr, st));
-  HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 16 * (size_t)nr, st));
-  HIPCHK(h, hipMemsetAsync(h->d_bins.p, 0, 8 * (size_t)nr, st));
+  HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 24 * (size_t)nr, st));
   HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
@@ -712,8 +718,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- CIA extinction (device) ----------------------------------------------------
   {
+    // on a second stream: only the first optical-depth kernel needs e_cs, so the
+    // (latency-bound) spline kernels overlap the first sweep step
     const auto t0 = std::chrono::steady_clock::now();
-    if ((rc = cia_device(h, a, o, d_tempk))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_inputs, st));
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
+    if ((rc = cia_device(h, a, o, d_tempk, h->stream2))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_cia, h->stream2));
     ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
@@ -730,55 +741,51 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   for (int r_top = nr - 1; r_top >= 0; ) {
     const int nc = std::min(nc_max, r_top + 1);
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    // lines / groups whose profiles can reach this shard in any layer of the chunk
-    Segments GL{}, GG{};
+    // groups whose profiles can reach this shard in any layer of the chunk
+    // (contiguous per isotope block).  The layer maximum is global
+    // (extinction.c:399-427 runs over every line): with a communicator each rank
+    // reduces its own window and the maxima are all-reduced in-stream; a shard
+    // running on its own scans every group itself.
+    Segments GG{};
     {
-      long long nl_tot = 0, ng_tot = 0;
+      long long ng_tot = 0;
       for (int b = 0; b < niso; b++) {
         const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
         if (gb0 == gb1) continue;
-        long long psm = 0;
-        for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
-        long long klo = ((long long)h->osamp * h->lo - psm) / h->osamp - 1;
-        long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp + 1;
-        if (klo < 0) klo = 0;
-        if (khi > h->nwn - 1) khi = h->nwn - 1;
-        const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
-        const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
-        if (ga >= gz && h->comm) continue;
-        if (ga < gz) { GG.start[GG.n] = ga; GG.base[GG.n] = ng_tot; ng_tot += gz - ga; GG.n++; }
-        // pass 1 feeds a global maximum: with a communicator every rank reduces
-        // its own window and the maxima are all-reduced; without one (a shard
-        // run on its own) the rank sweeps every line itself.
-        const int la_g = h->comm ? ga : gb0, lz_g = h->comm ? gz : gb1;
-        const long long la = h->h_gfirst[la_g], lz = (long long)h->h_gfirst[lz_g - 1] + h->h_gcount[lz_g - 1];
-        GL.start[GL.n] = la; GL.base[GL.n] = nl_tot; nl_tot += lz - la; GL.n++;
+        int ga = gb0, gz = gb1;
+        if (h->comm) {
+          long long psm = 0;
+          for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
+          const long long lo_f = (long long)h->osamp * h->lo - psm;
+          long long klo = lo_f > 0 ? lo_f / h->osamp : 0;
+          long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp;
+          if (khi > h->nwn - 1) khi = h->nwn - 1;
+          const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
+          ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
+        }
+        if (ga >= gz) continue;
+        GG.start[GG.n] = ga; GG.base[GG.n] = ng_tot; ng_tot += gz - ga; GG.n++;
       }
-      GG.base[GG.n] = ng_tot; GL.base[GL.n] = nl_tot;
+      GG.base[GG.n] = ng_tot;
     }
-    const long long seg_lines = GL.base[GL.n], seg_groups = GG.base[GG.n];
-    if (seg_lines > 0) {
-      hipLaunchKernelGGL(k_line_strength, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
-                         h->L, Y, GL, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<unsigned long long>(),
+    const long long seg_groups = GG.base[GG.n];
+    const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
+    if (seg_groups > 0) {
+      hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_groups + 255) / 256)), dim3(256), 0, st,
+                         h->L, Y, GG, niso, r_top, nc, h->d_adop.as<double>(), h->ndop, d_wcut,
+                         h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), h->d_kmax.as<unsigned long long>(),
                          h->d_flags.as<int>(), (int)eager);
     }
-    if (h->comm) {      // the layer maximum is global: extinction.c:399-427 runs over every line
+    if (h->comm) {
       unsigned long long *km = h->d_kmax.as<unsigned long long>() + (r_top - nc + 1);
       if (rccl().AllReduce(km, km, (size_t)nc, ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
         return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    const unsigned gblocks = (unsigned)std::max<long long>(1, (seg_groups + 255) / 256);
-    const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
     if (h->ngroups > 0) {
       hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
                          h->L, Y, niso, r_top, nc, h->d_kmax.as<double>(), o->ethresh, h->d_adop.as<double>(), h->ndop,
                          d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), (int)eager);
-      if (seg_groups > 0)
-      hipLaunchKernelGGL(k_group_strength, dim3(gblocks), dim3(256), 0, st,
-                         h->L, Y, GG, niso, r_top, nc, h->d_S.as<double>(), h->d_kmax.as<double>(), o->ethresh,
-                         h->d_adop.as<double>(), h->ndop, d_wcut, h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(),
-                         prof ? h->d_part2.as<unsigned long long>() : nullptr, h->d_flags.as<int>(), (int)eager);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     if (h->ngroups > 0) {
@@ -786,21 +793,21 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
       A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
       A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
+      A.kmax = h->d_kmax.as<double>(); A.ethresh = o->ethresh;
       A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
       A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>();
       A.part = prof ? h->d_part3.as<unsigned long long>() : nullptr;
       A.flags = h->d_flags.as<int>(); A.eager = eager;
+      A.last = (!eager && !(dbg && dbg->e)) ? h->d_last.as<int>() : nullptr;
       hipLaunchKernelGGL(k_accumulate, dim3(tblocks, (unsigned)nc), dim3(256), 0, st, A);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     if (prof && h->ngroups > 0) {      // counters (profiling runs only; gated like the sweep itself)
-      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part2.as<unsigned long long>(),
-                         (int)gblocks, 2, 0, h->d_counters.as<unsigned long long>(), 2, r_top, h->d_flags.as<int>(), (int)eager);
-      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part2.as<unsigned long long>(),
-                         (int)gblocks, 2, 1, h->d_counters.as<unsigned long long>(), 2, r_top, h->d_flags.as<int>(), (int)eager);
-      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
-                         (int)tblocks, 1, 0, h->d_bins.as<unsigned long long>(), 1, r_top, h->d_flags.as<int>(), (int)eager);
+      for (int k = 0; k < 3; k++)
+        hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
+                           (int)tblocks, 3, k, h->d_counters.as<unsigned long long>(), 3, r_top, h->d_flags.as<int>(), (int)eager);
     }
+    if (nchunks == 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
     {
       TauArgs T{};
       T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
@@ -815,7 +822,6 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
       hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + kTauW - 1) / kTauW)), dim3(256), 0, st, T);
-      hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, h->d_flags.as<int>(), nc, (int)eager);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     r_top -= nc; nchunks++;
@@ -851,29 +857,28 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
   if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
-  std::vector<unsigned long long> counters(2 * (size_t)nr), bins(nr);
-  HIPCHK(h, hipMemcpyAsync(counters.data(), h->d_counters.p, 16 * (size_t)nr, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(bins.data(), h->d_bins.p, 8 * (size_t)nr, hipMemcpyDeviceToHost, st));
+  std::vector<unsigned long long> counters(3 * (size_t)nr);
+  HIPCHK(h, hipMemcpyAsync(counters.data(), h->d_counters.p, 24 * (size_t)nr, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
 
   trx_stats &S = h->stats;
   S.layers_swept = flags_host[2];
   S.neval = S.nskip = S.sum_bins = 0;
-  for (int r = 0; r < nr; r++) { S.neval += (int64_t)counters[2*r]; S.nskip += (int64_t)counters[2*r+1]; S.sum_bins += (int64_t)bins[r]; }
+  for (int r = 0; r < nr; r++) { S.sum_bins += (int64_t)counters[3*r]; S.neval += (int64_t)counters[3*r+1]; S.nskip += (int64_t)counters[3*r+2]; }
   float ms = 0; (void)hipEventElapsedTime(&ms, ev_begin, ev_end); S.ms_run_total = ms;
   S.ms_cia = ms_cia;
   S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-  S.ms_k_line = S.ms_k_group = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
+  S.ms_k_sweep = S.ms_k_sticky = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
   if (prof) {
     const int swept_chunks = std::min(nchunks, (int)((S.layers_swept + nc_max - 1) / nc_max));
     for (int c = 0; c < nchunks; c++) {
       float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
       (void)hipEventElapsedTime(&t1, ev[5*c], ev[5*c+1]); (void)hipEventElapsedTime(&t2, ev[5*c+1], ev[5*c+2]);
       (void)hipEventElapsedTime(&t3, ev[5*c+2], ev[5*c+3]); (void)hipEventElapsedTime(&t4, ev[5*c+3], ev[5*c+4]);
-      if (c < swept_chunks) { S.ms_k_line += t1; S.ms_k_group += t2; S.ms_k_accum += t3; S.sweep_launches++; }
+      if (c < swept_chunks) { S.ms_k_sweep += t1; S.ms_k_sticky += t2; S.ms_k_accum += t3; S.sweep_launches++; }
       S.ms_tau += t4;
     }
-    S.ms_sweep = S.ms_k_line + S.ms_k_group + S.ms_k_accum;
+    S.ms_sweep = S.ms_k_sweep + S.ms_k_sticky + S.ms_k_accum;
   }
   for (auto e : ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);

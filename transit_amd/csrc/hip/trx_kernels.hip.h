@@ -4,12 +4,12 @@
 // dense contraction, hence no MFMA.  Wavefront = 64 lanes.
 //
 //   k_voigt_bins / k_voigt_bins_wave  Voigt-profile table      (opacity.c:219-277, voigt.c)
-//   k_line_strength                   pass 1: per-line strength + layer maximum
-//                                                               (extinction.c:399-427)
-//   k_group_strength                  pass 2a: co-added group strength, threshold,
-//                                     Doppler index             (extinction.c:429-483)
-//   k_accumulate                      pass 2b: profile accumulation into e[layer][wn]
-//                                                               (extinction.c:485-509)
+//   k_group_sweep                     passes 1+2a: co-added group strength, Doppler
+//                                     index, layer maximum      (extinction.c:399-483)
+//   k_sticky_index                    sticky Doppler index      (extinction.c:393, 480-483)
+//   k_accumulate                      pass 2b: threshold + profile accumulation into
+//                                     e[layer][wn]              (extinction.c:467-509)
+//   k_cia_rows/_layers/_eval          CIA extinction            (crosssec.c:272-428)
 //   k_optical_depth                   total extinction + ray quadrature + toomuch cut
 //                                                               (tau.c:216-305, eclipse.c:29-105,
 //                                                                slantpath.c:19-108)
@@ -173,102 +173,70 @@ void k_voigt_bins_wave(const ProfileJob *jobs, float *table, int m_limit)
 }
 
 // ---------------------------------------------------------------------------
-// pass 1: per-line strengths of a chunk of layers + the layer maximum
+// line sweep, strength part: passes 1 and 2a of computemolext in one scan
 // ---------------------------------------------------------------------------
-// extinction.c:399-427.  One lane per line; the line's 26 bytes are read once
-// for the whole chunk, the two exponentials are evaluated once per line-layer
-// and parked in S[chunk][line] for pass 2 (instead of re-evaluating them as
-// the reference's second loop does).
+// extinction.c:399-427 (strongest line of the layer) and :429-483 (co-added
+// group strength, Doppler-width index).  One lane per co-added group (anchor
+// line + the following lines of the same isotope inside one fine bin, built on
+// the host); the lane reads its lines once for the whole chunk of layers and
+// evaluates the two exponentials once per line-layer.  Per (layer, group) it
+// emits
+//     SG    = sum_members gf*exp(-c*Elow/T)*(1-exp(-c*wn/T)) * SIGCTE*ratio/(m*Z)
+//     idop8 = nearest Doppler-width index, or 0xFF = "use the isotope's sticky one"
+// and per layer the maximum single-line strength (wave max -> one 64-bit
+// atomicMax per block).  The threshold test against ethresh*kmax (:467) needs
+// the finished maximum, so it is applied where SG is consumed (k_accumulate).
 __global__ __launch_bounds__(256)
-void k_line_strength(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
-                     double *__restrict__ S, unsigned long long *__restrict__ kmax_bits,
-                     const int *__restrict__ flags, int eager)
+void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
+                   const double *__restrict__ adop, int ndop,
+                   const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
+                   double *__restrict__ SG, uint8_t *__restrict__ idop8,
+                   unsigned long long *__restrict__ kmax_bits,
+                   const int *__restrict__ flags, int eager)
 {
   if (!eager && flags[0] == 0) return;
+  __shared__ double s_adop[kMaxDop + 1];
   __shared__ double red[4][kMaxChunk];
-  const long long ln = seg_index(G, (long long)blockIdx.x * 256 + threadIdx.x);
-  const bool ok = ln >= 0;
+  for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
+  __syncthreads();
+  const long long g = seg_index(G, (long long)blockIdx.x * 256 + threadIdx.x);
+  const bool ok = g >= 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double wavn = 0, elow = 0, gf = 0; int iso = 0; bool inr = false;
+  int first = 0, cnt = 0, iso = 0;
+  double wavn = 0, elow = 0, gf = 0; bool inr = false;
   if (ok) {
-    wavn = L.wavn[ln]; elow = L.elow[ln]; gf = L.gf[ln];
-    iso = L.iso[ln]; inr = L.inrange[ln] != 0;
+    first = L.gfirst[g]; cnt = L.gcount[g]; iso = L.giso[g];
+    wavn = L.wavn[first]; elow = L.elow[first]; gf = L.gf[first]; inr = L.inrange[first] != 0;
   }
   for (int c = 0; c < nc; c++) {
     const int r = r_top - c;
     const double ct = Y.negc_over_t[r];
-    double pk = 0;
+    double kbest = 0;
     if (ok) {
-      const double s = gf * exp(ct * elow) * (1 - exp(ct * wavn));
-      S[(long long)c * L.nlines + ln] = s;
-      if (inr) pk = s * Y.strength_f[r * niso + iso];
+      const double f = Y.strength_f[r * niso + iso];
+      double pk = gf * exp(ct * elow) * (1 - exp(ct * wavn));
+      if (inr) kbest = pk * f;
+      for (int m = 1; m < cnt; m++) {                       // co-added members (extinction.c:449-462)
+        const int ln = first + m;
+        const double sm = L.gf[ln] * exp(ct * L.elow[ln]) * (1 - exp(ct * L.wavn[ln]));
+        if (L.inrange[ln]) kbest = fmax(kbest, sm * f);
+        pk += sm;
+      }
+      pk *= f;
+      uint8_t id = 0xFF;
+      if (wavn >= wcut[r * niso + iso])
+        id = (uint8_t)nearest_index(s_adop, Y.alphad[r * niso + iso] * wavn, 0, ndop);
+      SG[(long long)c * L.ngroups + g] = pk;
+      idop8[(long long)c * L.ngroups + g] = id;
     }
-    pk = wave_max(pk);
-    if (lane == 0) red[wv][c] = pk;
+    kbest = wave_max(kbest);
+    if (lane == 0) red[wv][c] = kbest;
   }
   __syncthreads();
   if (threadIdx.x < nc) {
     const int c = threadIdx.x;
     const double m = fmax(fmax(red[0][c], red[1][c]), fmax(red[2][c], red[3][c]));
     if (m > 0) atomicMax(&kmax_bits[r_top - c], (unsigned long long)__double_as_longlong(m));
-  }
-}
-
-// ---------------------------------------------------------------------------
-// pass 2a: co-added group strength, threshold test, Doppler-width index
-// ---------------------------------------------------------------------------
-// extinction.c:449-483.  One lane per group (anchor line).  Output per
-// (layer, group): SG = strength*density (0 when below ethresh*kmax) and the
-// Doppler index (0xFF = "use the isotope's sticky index", :480-483).
-// part (optional, profiling only): per-block {evaluated, skipped} counts.
-__global__ __launch_bounds__(256)
-void k_group_strength(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
-                      const double *__restrict__ S, const double *__restrict__ kmax,
-                      double ethresh, const double *__restrict__ adop, int ndop,
-                      const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
-                      double *__restrict__ SG, uint8_t *__restrict__ idop8,
-                      unsigned long long *__restrict__ part,       // [nc][gridDim.x][2] or null
-                      const int *__restrict__ flags, int eager)
-{
-  if (!eager && flags[0] == 0) return;
-  __shared__ double s_adop[kMaxDop + 1];
-  __shared__ int s_cnt[4][2];
-  for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
-  __syncthreads();
-  const long long g = seg_index(G, (long long)blockIdx.x * 256 + threadIdx.x);
-  const bool ok = g >= 0;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int first = 0, cnt = 0, iso = 0; double wavn = 0;
-  if (ok) { first = L.gfirst[g]; cnt = L.gcount[g]; iso = L.giso[g]; wavn = L.gwavn[g]; }
-  for (int c = 0; c < nc; c++) {
-    const int r = r_top - c;
-    int evald = 0, skipped = 0;
-    if (ok) {
-      const double *Sr = S + (long long)c * L.nlines + first;
-      double pk = Sr[0];
-      for (int m = 1; m < cnt; m++) pk += Sr[m];
-      pk *= Y.strength_f[r * niso + iso];
-      uint8_t id = 0xFF;
-      if (pk < ethresh * kmax[r]) { pk = 0; skipped = 1; }
-      else {
-        pk *= Y.density[r * niso + iso];
-        evald = 1;
-        if (wavn >= wcut[r * niso + iso])
-          id = (uint8_t)nearest_index(s_adop, Y.alphad[r * niso + iso] * wavn, 0, ndop);
-      }
-      SG[(long long)c * L.ngroups + g] = pk;
-      idop8[(long long)c * L.ngroups + g] = id;
-    }
-    if (part) {
-      const int ne = __popcll(__ballot(evald)), ns = __popcll(__ballot(skipped));
-      if (lane == 0) { s_cnt[wv][0] = ne; s_cnt[wv][1] = ns; }
-      __syncthreads();
-      if (threadIdx.x < 2)
-        part[((long long)c * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
-            (unsigned long long)(s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] +
-                                 s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x]);
-      __syncthreads();
-    }
   }
 }
 
@@ -352,15 +320,18 @@ struct AccumArgs {
   int niso, nlor, ndop, osamp;
   long long nwn, lo, nsh;           // full grid, shard origin, shard bins
   int r_top, nc, ntiles;
-  const double  *SG;                // [chunk][ngroups]
+  const double  *SG;                // [chunk][ngroups] group strength before threshold and density
   const uint8_t *idop8;             // [chunk][ngroups]
+  const double  *kmax;              // [layer] strongest single line (after the all-reduce, if any)
+  double ethresh;
   const int     *sticky_idop;       // [layer][iso]
   const int32_t *psize;             // [ndop][nlor]
   const long long *poff;            // [ndop][nlor]
   const float   *table;
   double        *e;                 // [layer][nsh]
-  unsigned long long *part;         // [nc][gridDim.x] accumulated (group,bin) pairs, or null
+  unsigned long long *part;         // [nc][gridDim.x][3] {bins, evaluated, skipped} or null (profiling)
   const int *flags;
+  const int *last;                  // [nsh] or null: skip tiles whose rays all stopped above this chunk
   int eager;
 };
 
@@ -371,18 +342,27 @@ void k_accumulate(AccumArgs A)
   if (!A.eager && A.flags[0] == 0) return;
   __shared__ int32_t  s_ps[4][kMaxDop];
   __shared__ long long s_po[4][kMaxDop];
-  __shared__ long long s_nb[4];
+  __shared__ long long s_nb[4][3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.y;
   const int tile = blockIdx.x * 4 + wv;
   const int r = A.r_top - c;
-  const bool live = tile < A.ntiles;                 // wave-uniform
+  bool live = tile < A.ntiles;                       // wave-uniform
   const long long j0 = A.lo + (long long)tile * kTileBins;      // global coarse bin
   const long long j1 = min(j0 + kTileBins, A.lo + A.nsh) - 1;
+  if (live && A.last) {
+    // every ray of the tile already crossed toomuch (tau.c:277-287): nothing
+    // below will ever read e[layer][j] for these bins
+    const bool open = (lane <= j1 - j0) && (A.last[(j0 - A.lo) + lane] < 0);
+    live = __ballot(open) != 0ull;
+  }
   double acc[kTileBins];
 #pragma unroll
   for (int t = 0; t < kTileBins; t++) acc[t] = 0.0;
-  long long nb = 0;
+  long long nb = 0, nev = 0, nsk = 0;
+  const double lim = A.ethresh * A.kmax[r];
+  // counters: a group is counted by the tile that holds its own coarse bin
+  const long long hk0 = j0, hk1 = (j1 == A.nwn - 1) ? (long long)1 << 60 : j1;
 
   if (live)
   for (int b = 0; b < A.niso; b++) {
@@ -398,23 +378,32 @@ void k_accumulate(AccumArgs A)
     const int idst = A.sticky_idop[ri];
     // window of groups that can reach the tile
     const long long psm = A.Y.psmax[ri];
-    long long klo = ((long long)A.osamp * j0 - psm) / A.osamp - 1;
-    long long khi = ((long long)A.osamp * j1 + psm) / A.osamp + 1;
-    if (klo < 0) klo = 0;
+    // groups with iown in [osamp*j0 - psm, osamp*j1 + psm]; keys are iown/osamp
+    const long long lo_f = (long long)A.osamp * j0 - psm;
+    long long klo = lo_f > 0 ? lo_f / A.osamp : 0;
+    long long khi = ((long long)A.osamp * j1 + psm) / A.osamp;
     if (khi > A.nwn - 1) khi = A.nwn - 1;
     const int32_t *cg = A.L.cnt_ge + (long long)b * (A.nwn + 1);
     const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
     const double  *SGr = A.SG    + (long long)c * A.L.ngroups;
     const uint8_t *idr = A.idop8 + (long long)c * A.L.ngroups;
     __builtin_amdgcn_wave_barrier();
+    const double dens = A.Y.density[ri];
     for (int g = ga + lane; g < gz; g += 64) {
-      const double sg_k = SGr[g];
-      if (sg_k == 0.0) continue;
+      double sg_k = SGr[g];
+      const int iown = A.L.giown[g];
+      const bool below = sg_k < lim;                       // extinction.c:467
+      if (A.part) {
+        const long long hk = iown / A.osamp;
+        if (hk >= hk0 && hk <= hk1) { if (below) nsk++; else nev++; }
+      }
+      if (below) continue;
+      sg_k *= dens;                                        // extinction.c:472-473
       int id = idr[g];
       if (id == 0xFF) id = idst;
       const long long ps = s_ps[wv][id];
       const float *prof = A.table + s_po[wv][id] + ps;           // centre of the profile
-      const long long d0 = (long long)A.osamp * j0 - A.L.giown[g];
+      const long long d0 = (long long)A.osamp * j0 - iown;
 #pragma unroll
       for (int t = 0; t < kTileBins; t++) {
         const long long d = d0 + (long long)t * A.osamp;
@@ -431,11 +420,12 @@ void k_accumulate(AccumArgs A)
     }
   }
   if (A.part) {
-    nb = wave_sum_ll(nb);
-    if (lane == 0) s_nb[wv] = nb;
+    nb = wave_sum_ll(nb); nev = wave_sum_ll(nev); nsk = wave_sum_ll(nsk);
+    if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
     __syncthreads();
-    if (threadIdx.x == 0)
-      A.part[(long long)c * gridDim.x + blockIdx.x] = (unsigned long long)(s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
+    if (threadIdx.x < 3)
+      A.part[((long long)c * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+          (unsigned long long)(s_nb[0][threadIdx.x] + s_nb[1][threadIdx.x] + s_nb[2][threadIdx.x] + s_nb[3][threadIdx.x]);
   }
 }
 
@@ -646,14 +636,20 @@ void k_optical_depth(TauArgs T)
   }
   const unsigned long long m = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&T.flags[1], __popcll(m));
-}
-
-// flags[0] <- rays still descending; counts the layers actually swept
-__global__ void k_advance(int *flags, int nc, int eager)
-{
-  if (eager || flags[0] != 0) flags[2] += nc;
-  flags[0] = flags[1];
-  flags[1] = 0;
+  // the last block to arrive publishes the number of rays still descending
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int ticket = atomicAdd(&T.flags[3], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      __threadfence();
+      const int act = atomicAdd(&T.flags[1], 0);
+      T.flags[2] += T.nc;                                // layers swept so far
+      T.flags[1] = 0; T.flags[3] = 0;
+      __threadfence();
+      atomicExch(&T.flags[0], act);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
