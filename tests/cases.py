@@ -7,7 +7,8 @@ import oracle_lib as ol
 from transit_amd.host import Problem
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["eclipse_small", "transit_small", "coadd_thresh", "cloud_scatter", "transit_modm1"]
+CASES = ["eclipse_small", "transit_small", "coadd_thresh", "cloud_scatter", "transit_modm1",
+         "highres_fine", "midres_os4"]
 
 
 class Golden:
@@ -20,8 +21,6 @@ class Golden:
         _, self.e = ol.read_rows_dump(os.path.join(self.dir, "mol_extion.dat"), "radius")     # [layer][wn]
         _, cia = ol.read_rows_dump(os.path.join(self.dir, "CIA.dat"), "wavenumber")           # [wn][layer]
         self.e_cs = cia.T
-        _, tot = ol.read_rows_dump(os.path.join(self.dir, "total_extion.dat"), "wavenumber")
-        self.e_tot = tot.T
         self.swept = (self.e != 0).any(axis=1)          # layers the reference's lazy sweep reached
 
 

@@ -24,7 +24,7 @@ from transit_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref", "transit")
 
 KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "cia_h2he.dat",
-        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "total_extion.dat"]
+        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat"]
 
 CASES = {
     # demo-shaped emission run, narrow band
@@ -42,13 +42,24 @@ CASES = {
     # opaque-disc modulation level and a transparent planet, odd layer count
     "transit_modm1": dict(nlines=4000, wnlow=4000, wnhigh=4030, nlayers=31, solution="transit", seed=11,
                           toomuch=5.0, extra={"modlevel": "-1"}),
+    # high-resolution regime (BASELINE configs[4] in small): output grid far finer than
+    # the lines, no oversampling -> every profile spans hundreds of bins; the Voigt
+    # table is built with the coarse-grid Simpson averaging (voigt.c:427-433)
+    "highres_fine": dict(nlines=1500, wnlow=2500, wnhigh=2502, wndelt=0.002, wnosamp=1, nlayers=24,
+                         solution="eclipse", seed=5, toomuch=10.0),
+    # oversampling 4 on a 0.02 cm-1 grid: wide profiles with a phase-major table
+    "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
+                       solution="transit", seed=17, ncia=2),
 }
 
 
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/transit is missing: run `make -C oracle ref` first")
+    only = set(sys.argv[1:])
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         d = os.path.join(HERE, name)
         tmp = d + ".tmp"
         shutil.rmtree(tmp, ignore_errors=True)

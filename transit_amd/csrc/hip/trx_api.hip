@@ -57,7 +57,8 @@ struct trx_handle {
   int ndop = 0, nlor = 0;
   std::vector<double> adop, alor;                   // +1 sentinel
   std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
-  DevBuf d_adop, d_psize, d_poff, d_tab;
+  DevBuf d_adop, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
+  const float *tabT = nullptr; const long long *poffT = nullptr;
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
   DevBuf d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
@@ -194,6 +195,32 @@ int build_table(trx_handle *h, const trx_static *s)
       hipLaunchKernelGGL(k_voigt_bins_wave, dim3(std::max(1, std::min(256, maxnv)), nj), dim3(64), 0, h->stream,
                          d_jobs.as<ProfileJob>() + j0, h->d_tab.as<float>(), m_limit);
   }
+  // phase-major copy for the wide-profile kernel (identical layout when osamp == 1)
+  if (s->osamp == 1) { h->tabT = h->d_tab.as<float>(); h->poffT = h->d_poff.as<long long>(); }
+  else {
+    std::vector<long long> joffT(jobs.size()), poffT((size_t)s->ndop * s->nlor, 0);
+    long long totT = 0;
+    for (size_t j = 0; j < jobs.size(); j++) { joffT[j] = totT; totT += (long long)s->osamp * ((jobs[j].nv - 1) / s->osamp + 1); }
+    {   // table entries -> job (aliases share the job of the row above)
+      size_t j = 0;
+      for (int i = 0; i < s->ndop; i++)
+        for (int k = 0; k < s->nlor; k++) {
+          const size_t e = (size_t)i * s->nlor + k;
+          if (h->adop[i] * 10.0 < h->alor[k] && i != 0) poffT[e] = poffT[e - s->nlor];
+          else poffT[e] = joffT[j++];
+        }
+    }
+    DevBuf d_joffT;
+    if ((rc = upload(h, d_joffT, joffT)) || (rc = upload(h, h->d_poffT, poffT))) return rc;
+    if ((rc = ensure(h, h->d_tabT, sizeof(float) * (size_t)totT))) return rc;
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
+      const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
+      hipLaunchKernelGGL(k_table_phase_major, dim3(32, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
+                         d_joffT.as<long long>() + j0, h->d_tab.as<float>(), h->d_tabT.as<float>(), s->osamp);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->tabT = h->d_tabT.as<float>(); h->poffT = h->d_poffT.as<long long>();
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(e1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -262,13 +289,15 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     if (giso[g] == giso[g-1] && giown[g] > giown[g-1])
       return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
 
+  std::vector<int32_t> gimod(giown.size()), gidiv(giown.size());
+  for (size_t g = 0; g < giown.size(); g++) { gimod[g] = giown[g] % s->osamp; gidiv[g] = giown[g] / s->osamp; }
   std::vector<double> elow(s->elow, s->elow + n), gf(s->gf, s->gf + n);
   std::vector<int16_t> iso(s->isoid, s->isoid + n);
   int rc;
   if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_elow, elow)) || (rc = upload(h, h->d_gf, gf)) ||
       (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
       (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
-      (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
+      (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gimod, gimod)) || (rc = upload(h, h->d_gidiv, gidiv)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
     return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
   h->h_gwavn = gwavn; h->h_gblock = gblock; h->h_cntge = cntge; h->h_gfirst = gfirst; h->h_gcount = gcount;
@@ -796,10 +825,27 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       A.kmax = h->d_kmax.as<double>(); A.ethresh = o->ethresh;
       A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
       A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>();
-      A.part = prof ? h->d_part3.as<unsigned long long>() : nullptr;
+      A.part = prof ? h->d_part3.as<unsigned long long>() : nullptr; A.part_stride = (int)tblocks;
       A.flags = h->d_flags.as<int>(); A.eager = eager;
       A.last = (!eager && !(dbg && dbg->e)) ? h->d_last.as<int>() : nullptr;
-      hipLaunchKernelGGL(k_accumulate, dim3(tblocks, (unsigned)nc), dim3(256), 0, st, A);
+      // layers whose profiles span >= 64 coarse bins go to the lanes-own-bins kernel
+      unsigned wide_mask = 0;
+      for (int c = 0; c < nc; c++) {
+        long long pm = 0;
+        for (int b = 0; b < niso; b++)
+          if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)(r_top - c) * niso + b]);
+        if ((2 * pm) / h->osamp + 1 >= 64) wide_mask |= 1u << c;
+      }
+      A.skip_mask = wide_mask;
+      if (prof) HIPCHK(h, hipMemsetAsync(h->d_part3.p, 0, 24 * (size_t)nc_max * tblocks, st));
+      if (wide_mask != (nc >= 32 ? 0xffffffffu : ((1u << nc) - 1u)))
+        hipLaunchKernelGGL(k_accumulate, dim3(tblocks, (unsigned)nc), dim3(256), 0, st, A);
+      if (wide_mask) {
+        WideArgs W{}; W.A = A; W.tabT = h->tabT; W.poffT = h->poffT;
+        W.gimod = h->d_gimod.as<int32_t>(); W.gidiv = h->d_gidiv.as<int32_t>(); W.layer_mask = wide_mask;
+        const unsigned wtiles = (unsigned)((nsh + 64 * kWideM - 1) / (64 * kWideM));
+        hipLaunchKernelGGL(k_accumulate_wide, dim3((wtiles + 3) / 4, (unsigned)nc), dim3(256), 0, st, W);
+      }
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     if (prof && h->ngroups > 0) {      // counters (profiling runs only; gated like the sweep itself)

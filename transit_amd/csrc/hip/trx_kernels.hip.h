@@ -329,10 +329,12 @@ struct AccumArgs {
   const long long *poff;            // [ndop][nlor]
   const float   *table;
   double        *e;                 // [layer][nsh]
-  unsigned long long *part;         // [nc][gridDim.x][3] {bins, evaluated, skipped} or null (profiling)
+  unsigned long long *part;         // [nc][part_stride][3] {bins, evaluated, skipped} or null (profiling)
+  int part_stride;
   const int *flags;
   const int *last;                  // [nsh] or null: skip tiles whose rays all stopped above this chunk
   int eager;
+  unsigned skip_mask;               // bit c set: layer c of the chunk belongs to k_accumulate_wide
 };
 
 // grid: x = groups of 4 tiles, y = layer of the chunk
@@ -345,6 +347,7 @@ void k_accumulate(AccumArgs A)
   __shared__ long long s_nb[4][3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.y;
+  if ((A.skip_mask >> c) & 1u) return;
   const int tile = blockIdx.x * 4 + wv;
   const int r = A.r_top - c;
   bool live = tile < A.ntiles;                       // wave-uniform
@@ -424,8 +427,167 @@ void k_accumulate(AccumArgs A)
     if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
     __syncthreads();
     if (threadIdx.x < 3)
-      A.part[((long long)c * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+      A.part[((long long)c * A.part_stride + blockIdx.x) * 3 + threadIdx.x] =
           (unsigned long long)(s_nb[0][threadIdx.x] + s_nb[1][threadIdx.x] + s_nb[2][threadIdx.x] + s_nb[3][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 2b for wide profiles (fine output grids): lanes own bins
+// ---------------------------------------------------------------------------
+// When a profile covers >= ~64 coarse bins (Delta_wn << line width: the
+// high-resolution regime, BASELINE configs[4]) the gather above would revisit
+// every group for thousands of 4-bin tiles.  Here a wavefront owns kWideM*64
+// consecutive bins, one accumulator per (lane, m), and walks the groups of its
+// window in line order, 64 at a time through LDS; the group's scalars are
+// wave-uniform (SGPRs), the table read is one coalesced row segment per m.
+// Bin j reads profile entry q = osamp*j - iown + ps = osamp*(j + kb) + phase, so
+// the table is kept phase-major ("tabT": [phase][k], k = q / osamp): a fixed
+// group walks ONE row with unit stride instead of striding by osamp floats.
+// Each bin is owned by one lane => plain stores, sums in the reference's own
+// (line) order.
+constexpr int kWideM = 4;
+
+struct WideArgs {
+  AccumArgs A;
+  const float     *tabT;            // phase-major copy of the table (== table when osamp == 1)
+  const long long *poffT;           // [ndop][nlor]
+  const int32_t   *gimod, *gidiv;   // [ngroups] iown % osamp, iown / osamp
+  unsigned layer_mask;              // bit c set: layer c of the chunk is done here (clear: k_accumulate)
+};
+
+__global__ __launch_bounds__(256)
+void k_accumulate_wide(WideArgs W)
+{
+  const AccumArgs &A = W.A;
+  if (!A.eager && A.flags[0] == 0) return;
+  const int c = blockIdx.y;
+  if (!((W.layer_mask >> c) & 1u)) return;
+  __shared__ int32_t   s_ps[4][kMaxDop], s_K[4][kMaxDop];
+  __shared__ long long s_po[4][kMaxDop];
+  __shared__ double    s_sg[4][64];
+  __shared__ int32_t   s_im[4][64], s_id[4][64], s_dop[4][64];
+  __shared__ long long s_nb[4][3];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int T = 64 * kWideM;
+  const int tile = blockIdx.x * 4 + wv;
+  const int ntiles = (int)((A.nsh + T - 1) / T);
+  const int r = A.r_top - c;
+  bool live = tile < ntiles;
+  const long long j0 = A.lo + (long long)tile * T;
+  const long long j1 = min(j0 + T, A.lo + A.nsh) - 1;
+  if (live && A.last) {
+    bool open = false;
+    for (int m = 0; m < kWideM; m++) {
+      const long long j = j0 + lane + 64 * m;
+      open |= (j <= j1) && (A.last[j - A.lo] < 0);
+    }
+    live = __ballot(open) != 0ull;
+  }
+  double acc[kWideM];
+#pragma unroll
+  for (int m = 0; m < kWideM; m++) acc[m] = 0.0;
+  long long nb = 0, nev = 0, nsk = 0;
+  const double lim = A.ethresh * A.kmax[r];
+  const int of = A.osamp;
+
+  if (live)
+  for (int b = 0; b < A.niso; b++) {
+    const int gb0 = A.L.gblock[b], gb1 = A.L.gblock[b + 1];
+    if (gb0 == gb1) continue;
+    const int ri = r * A.niso + b;
+    const int il = A.Y.ilor[ri];
+    for (int i = lane; i < A.ndop; i += 64) {
+      const int ps = A.psize[i * A.nlor + il];
+      s_ps[wv][i] = ps;
+      s_K [wv][i] = (2 * ps) / of + 1;
+      s_po[wv][i] = W.poffT[i * A.nlor + il];
+    }
+    const int idst = A.sticky_idop[ri];
+    const long long psm = A.Y.psmax[ri];
+    const long long lo_f = (long long)of * j0 - psm;
+    long long klo = lo_f > 0 ? lo_f / of : 0;
+    long long khi = ((long long)of * j1 + psm) / of;
+    if (khi > A.nwn - 1) khi = A.nwn - 1;
+    const int32_t *cg = A.L.cnt_ge + (long long)b * (A.nwn + 1);
+    const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
+    const double  *SGr = A.SG    + (long long)c * A.L.ngroups;
+    const uint8_t *idr = A.idop8 + (long long)c * A.L.ngroups;
+    const double dens = A.Y.density[ri];
+    __builtin_amdgcn_wave_barrier();
+    for (int gbase = ga; gbase < gz; gbase += 64) {
+      const int g = gbase + lane;
+      if (g < gz) {
+        s_sg[wv][lane] = SGr[g];
+        s_im[wv][lane] = W.gimod[g];
+        s_id[wv][lane] = W.gidiv[g];
+        int id = idr[g];
+        s_dop[wv][lane] = (id == 0xFF) ? idst : id;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = min(64, gz - gbase);
+      for (int i = 0; i < cnt; i++) {
+        // wave-uniform group scalars -> SGPRs
+        const double sg0 = __longlong_as_double(
+            ((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(s_sg[wv][i]) >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(s_sg[wv][i])));
+        const int im  = __builtin_amdgcn_readfirstlane(s_im[wv][i]);
+        const int idv = __builtin_amdgcn_readfirstlane(s_id[wv][i]);
+        const int id  = __builtin_amdgcn_readfirstlane(s_dop[wv][i]);
+        const bool below = sg0 < lim;                        // extinction.c:467
+        if (A.part && idv >= j0 && idv <= j1 && lane == 0) { if (below) nsk++; else nev++; }
+        if (below) continue;
+        const double sg = sg0 * dens;
+        const int ps = __builtin_amdgcn_readfirstlane(s_ps[wv][id]);
+        const int K  = __builtin_amdgcn_readfirstlane(s_K[wv][id]);
+        const long long po = s_po[wv][id];
+        // q = of*j - iown + ps = of*(j + kb) + ph with 0 <= ph < of
+        const int psm_ = ps % of, psd_ = ps / of;
+        int ph = psm_ - im, kb = psd_ - idv;
+        if (ph < 0) { ph += of; kb -= 1; }
+        const int qrem = (2 * ps) - ph;                      // valid iff of*k <= qrem
+        const float *row = W.tabT + po + (long long)ph * K;
+#pragma unroll
+        for (int m = 0; m < kWideM; m++) {
+          const long long j = j0 + lane + 64 * m;
+          const long long k = j + kb;
+          if (j <= j1 && k >= 0 && k < K && (long long)of * k <= qrem) { acc[m] += sg * (double)row[k]; nb++; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < kWideM; m++) {
+      const long long j = j0 + lane + 64 * m;
+      if (j <= j1) A.e[(long long)r * A.nsh + (j - A.lo)] = acc[m];
+    }
+  }
+  if (A.part) {
+    nb = wave_sum_ll(nb); nev = wave_sum_ll(nev); nsk = wave_sum_ll(nsk);
+    if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+      A.part[((long long)c * A.part_stride + blockIdx.x) * 3 + threadIdx.x] =
+          (unsigned long long)(s_nb[0][threadIdx.x] + s_nb[1][threadIdx.x] + s_nb[2][threadIdx.x] + s_nb[3][threadIdx.x]);
+  }
+}
+
+// phase-major copy of one profile: tabT[offT + ph*K + k] = tab[off + osamp*k + ph]
+__global__ __launch_bounds__(256)
+void k_table_phase_major(const ProfileJob *jobs, const long long *joffT, const float *__restrict__ tab,
+                         float *__restrict__ tabT, int of)
+{
+  const ProfileJob J = jobs[blockIdx.y];
+  const long long offT = joffT[blockIdx.y];
+  const int npt = J.nv;                                  // 2*ps + 1
+  const int K = (npt - 1) / of + 1;
+  const long long total = (long long)of * K;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int ph = (int)(t / K), k = (int)(t - (long long)ph * K);
+    const long long q = (long long)of * k + ph;
+    tabT[offT + t] = (q < npt) ? tab[J.off + q] : 0.f;
   }
 }
 
