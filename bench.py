@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--wnlow", type=float, default=2500.0)
     ap.add_argument("--wnhigh", type=float, default=5000.0)
     ap.add_argument("--wnosamp", type=int, default=2160)
+    ap.add_argument("--wndelt", type=float, default=1.0)
     ap.add_argument("--layer-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = full workload)")
@@ -51,7 +52,7 @@ def parse():
 def make_workload(args, tag, nlines, verb=2):
     from transit_amd import synth
     d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%d" % (tag, nlines, args.layers, os.getpid()))
-    synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=args.wnhigh, wndelt=1.0, wnosamp=args.wnosamp,
+    synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=args.wnhigh, wndelt=args.wndelt, wnosamp=args.wnosamp,
                     nlayers=args.layers, solution="eclipse", toomuch=10.0, ethresh=1e-50, nwidth=20.0,
                     raygrid="0 20 40 60 80", ncia=1, seed=1234, extra={"verb": verb})
     return d
@@ -205,8 +206,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]): %g-%g cm-1 @1 cm-1, wnosamp %d, "
-                                   "eclipse, 5 angles, H2-H2 CIA" % (args.wnlow, args.wnhigh, args.wnosamp),
+            "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]): %g-%g cm-1 @%g cm-1, wnosamp %d, "
+                                   "eclipse, 5 angles, H2-H2 CIA" % (args.wnlow, args.wnhigh, args.wndelt, args.wnosamp),
                        "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
                        "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],

@@ -48,9 +48,25 @@ CASES = {
     "highres_fine": dict(nlines=1500, wnlow=2500, wnhigh=2502, wndelt=0.002, wnosamp=1, nlayers=24,
                          solution="eclipse", seed=5, toomuch=10.0),
     # oversampling 4 on a 0.02 cm-1 grid: wide profiles with a phase-major table
+    # three databases, six isotopes, threshold active (the per-layer maximum is taken
+    # over all species at once, extinction.c:421-426 with permol = 0)
+    "multi_species": dict(wnlow=1000, wnhigh=1100, nlayers=22, solution="eclipse", ethresh=1e-7,
+                          toomuch=12.0, dbs="multi"),
     "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
                        solution="transit", seed=17, ncia=2),
 }
+
+
+def multi_species_dbs():
+    """Three line databases (H2O, CH4, CO) with 3 + 2 + 1 isotopes: BASELINE configs[2] in small."""
+    h2o = synth.synth_linedb(1800, 1000, 1100, seed=21, name="HITEMP H2O (synthetic)", molname="H2O",
+                             iso_names=("161", "181", "171"), iso_masses=(18.010565, 20.014811, 19.01478),
+                             iso_ratios=(0.997317, 0.002, 0.000372), iso_split=(0.8, 0.15, 0.05), z_scale=170.0)
+    ch4 = synth.synth_linedb(1500, 1000, 1100, seed=22)
+    co = synth.synth_linedb(700, 1000, 1100, seed=23, name="HITEMP CO (synthetic)", molname="CO",
+                            iso_names=("26",), iso_masses=(27.994915,), iso_ratios=(0.98654,), iso_split=(1.0,),
+                            z_scale=107.0, log_gf=(-10.0, -4.0))
+    return [h2o, ch4, co]
 
 
 def main():
@@ -64,6 +80,8 @@ def main():
         tmp = d + ".tmp"
         shutil.rmtree(tmp, ignore_errors=True)
         kw = dict(kw)
+        if kw.get("dbs") == "multi":
+            kw["dbs"] = multi_species_dbs()
         extra = dict(kw.pop("extra", {}))
         extra.update({"savefiles": "yes"})
         synth.make_case(tmp, extra=extra, **kw)

@@ -1,0 +1,205 @@
+"""Size-independent properties of the HIP path, also at the bench's full size
+(BASELINE configs[1]: 2501 wavenumbers x 100 layers x 10^6 lines), where the
+CPU oracle would take a minute per case."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cases import golden, rel_err
+from transit_amd import _abi, synth
+from transit_amd.engine import Engine
+from transit_amd.host import Problem
+from transit_amd.shard import all_bounds
+
+pytestmark = pytest.mark.gpu
+
+
+def clone_static(st, **arrays):
+    """Copy of a trx_static with some line arrays replaced (arrays kept alive on the copy)."""
+    st2 = _abi.TrxStatic.from_buffer_copy(st)
+    st2._keep = arrays
+    for name, arr in arrays.items():
+        ptr_t = dict(_abi.TrxStatic._fields_)[name]
+        setattr(st2, name, arr.ctypes.data_as(ptr_t))
+    return st2
+
+
+def line_array(st, name, dtype=np.float64):
+    return np.ctypeslib.as_array(getattr(st, name), shape=(st.nlines,)).astype(dtype).copy()
+
+
+@pytest.fixture(scope="module")
+def full_size(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("c2"))
+    synth.make_case(d, nlines=1_000_000, wnlow=2500, wnhigh=5000, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=1234)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    eng = Engine(P.static)
+    out = eng.run(P.atm, P.opts, debug=True)
+    yield P, eng, out
+    eng.close()
+
+
+def test_full_size_optical_depth_is_monotonic_and_cut_consistent(full_size):
+    P, eng, out = full_size
+    tau, last = out["tau"], out["last"]
+    assert np.all(np.isfinite(out["spectrum"])) and np.all(out["spectrum"] > 0)
+    nr = P.nlayer
+    for w in range(0, P.nwn, 37):
+        t = tau[w, : last[w] + 1]
+        assert np.all(np.diff(t) >= -1e-12 * t[-1])             # deeper never gets more transparent
+        assert np.all(tau[w, last[w] + 1:] == 0)                # nothing computed below the cut
+    crossed = tau[np.arange(P.nwn), last] > P.opts.toomuch
+    assert np.all(crossed | (last == nr - 1))
+    before = tau[np.arange(P.nwn), np.maximum(last - 1, 0)]
+    assert np.all((before <= P.opts.toomuch) | (last == 0))
+
+
+def test_full_size_extinction_is_linear_in_gf(full_size):
+    """Scaling every gf by 2 scales every line strength, the layer maximum and the
+    threshold by exactly 2: the molecular extinction must double bit for bit."""
+    P, eng, out = full_size
+    gf2 = line_array(P.static, "gf") * 2.0
+    e2 = Engine(clone_static(P.static, gf=gf2))
+    opts = P.opts
+    opts.eager = 1
+    try:
+        a = eng.run(P.atm, opts, debug=True)["e"]
+        b = e2.run(P.atm, opts, debug=True)["e"]
+    finally:
+        opts.eager = 0
+        e2.close()
+    assert a.max() > 0
+    assert np.array_equal(b, 2.0 * a)
+
+
+def test_full_size_shards_stitch(full_size):
+    P, eng, out = full_size
+    parts = []
+    try:
+        for lo, hi in all_bounds(P.nwn, 4):
+            P.set_shard(lo, hi)
+            e = Engine(P.static)
+            parts.append(e.run(P.atm, P.opts)["spectrum"])
+            e.close()
+    finally:
+        P.set_shard(0, P.nwn)
+    # tile boundaries move with the shard origin, so the per-bin sums (~400 terms) are re-associated
+    assert rel_err(np.concatenate(parts), out["spectrum"]) < 1e-10
+
+
+def test_full_size_against_oracle_on_a_line_subset(full_size):
+    """Oracle parity at the full grid and layer count with 2 % of the lines (what
+    the CPU finishes in seconds); same generator, same atmosphere."""
+    P, _, _ = full_size
+    d = os.path.join(os.path.dirname(P.cwd), "c2_sub")
+    synth.make_case(d, nlines=20_000, wnlow=2500, wnhigh=5000, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=1234)
+    Q = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    hip = Engine(Q.static)
+    got = hip.run(Q.atm, Q.opts, debug=True)
+    hip.close()
+    ora = ol.OracleEngine(Q.static)
+    ref = ora.run(Q.atm, Q.opts, debug=True)
+    ora.close()
+    assert np.array_equal(got["last"], ref["last"])
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9
+    assert rel_err(got["tau"], ref["tau"]) < 1e-9
+
+
+# ---- edge cases on the small fixtures ---------------------------------------------
+def _both(static, P):
+    hip = Engine(static)
+    got = hip.run(P.atm, P.opts, debug=True)
+    hip.close()
+    ora = ol.OracleEngine(static)
+    ref = ora.run(P.atm, P.opts, debug=True)
+    ora.close()
+    return got, ref
+
+
+def test_empty_line_list_is_cia_only():
+    P = golden("eclipse_small").problem
+    st = _abi.TrxStatic.from_buffer_copy(P.static)
+    st.nlines = 0
+    got, ref = _both(st, P)
+    assert np.all(got["e"] == 0)
+    assert np.array_equal(got["last"], ref["last"])
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-12
+
+
+def test_lines_outside_the_band_contribute_nothing():
+    P = golden("eclipse_small").problem
+    wl = line_array(P.static, "wl_um")
+    far = np.sort(1e4 / np.linspace(2700.0, 2800.0, wl.size))        # ascending wavelength, out of range
+    iso = line_array(P.static, "isoid", np.int16)
+    # keep TLI order: isotope blocks ascending, wavelength ascending inside a block
+    for b in np.unique(iso):
+        m = iso == b
+        wl[m] = far[: m.sum()]
+    st = clone_static(P.static, wl_um=wl)
+    got, ref = _both(st, P)
+    assert np.all(got["e"] == 0) and np.all(ref["e"] == 0)
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-12
+
+
+def test_single_line_on_a_grid_point_and_at_the_band_edges():
+    """Three hand-placed lines: exactly on a coarse grid point, on the first and on
+    the last wavenumber of the band (clamped windows, extinction.c:493-496)."""
+    P = golden("eclipse_small").problem
+    st0 = P.static
+    wn = np.array([2560.0, 2530.0, 2500.0])                          # descending = ascending wavelength
+    st = clone_static(st0, wl_um=1e4 / wn, elow=np.array([100.0, 500.0, 1500.0]),
+                      gf=np.array([1e-6, 3e-6, 1e-5]), isoid=np.zeros(3, dtype=np.int16))
+    st.nlines = 3
+    got, ref = _both(st, P)
+    assert (ref["e"] != 0).any()
+    sw = ref["computed"].astype(bool)
+    assert rel_err(got["e"][sw], ref["e"][sw]) < 1e-10
+    assert np.array_equal(got["e"][sw] == 0, ref["e"][sw] == 0)
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-10
+
+
+def test_unsorted_line_list_is_rejected():
+    from transit_amd.engine import EngineError
+    P = golden("eclipse_small").problem
+    wl = line_array(P.static, "wl_um")
+    wl[[10, 11]] = wl[[11, 10]] if wl[10] != wl[11] else (wl[10] * 1.001, wl[10])
+    wl[10], wl[11] = max(wl[10], wl[11]), min(wl[10], wl[11])        # descending pair inside a block
+    with pytest.raises(EngineError) as ei:
+        Engine(clone_static(P.static, wl_um=wl))
+    assert ei.value.code == -7
+
+
+def test_bad_arguments_return_codes():
+    from transit_amd.engine import EngineError
+    P = golden("eclipse_small").problem
+    st = _abi.TrxStatic.from_buffer_copy(P.static)
+    st.abi_version = 99
+    with pytest.raises(EngineError) as ei:
+        Engine(st)
+    assert ei.value.code == -1
+    eng = Engine(P.static)
+    o = _abi.TrxOpts.from_buffer_copy(P.opts)
+    o.ethresh = 0.0
+    with pytest.raises(EngineError):
+        eng.run(P.atm, o)
+    o = _abi.TrxOpts.from_buffer_copy(P.opts)
+    o.solution = 7
+    with pytest.raises(EngineError):
+        eng.run(P.atm, o)
+    # CIA table range: a layer hotter than the table allows -> TRX_E_RANGE, not a crash
+    arr = P.layer_arrays()
+    hot = arr["temp"].copy(); hot[0] = 9000.0
+    a = _abi.TrxAtm.from_buffer_copy(P.atm)
+    a.temp = hot.ctypes.data_as(_abi.c_double_p)
+    with pytest.raises(EngineError) as ei:
+        eng.run(a, P.opts)
+    assert ei.value.code == -5
+    # the handle is still usable afterwards
+    r = eng.run(P.atm, P.opts)
+    assert np.all(np.isfinite(r["spectrum"]))
+    eng.close()
