@@ -72,8 +72,9 @@ struct trx_handle {
   // per-run workspaces (grown on demand)
   int ws_nr = 0, ws_chunk = 0;
   DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags, d_part2, d_part3;
-  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip;
+  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip, d_acc, d_arbuf;
   trx_stats stats{};
+  int hint_layers = 0;       // layers the previous run needed (deepest toomuch crossing + 1)
 };
 
 namespace {
@@ -610,7 +611,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   for (int i = 1; i < nr; i++) if (!(a->radius[i] > a->radius[i-1])) return fail(h, TRX_E_ARG, "radii must ascend");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
-  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 8;
+  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
   nc_max = std::max(3, std::min(nc_max, kMaxChunk));
   const bool eager = o->eager != 0, prof = o->profile != 0;
   int rc;
@@ -682,9 +683,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
   const int gstride = 4 * (nr / 2 + 1);
-  std::vector<double> geom((size_t)(nr + 1) * gstride * 2 + 2 * (size_t)(nr + 1), 0.0);
+  std::vector<double> geom((size_t)(nr + 1) * gstride * 2 + 2 * (size_t)(nr + 1) + 4 * (size_t)nr, 0.0);
   double *gw = &geom[0], *gh0 = gw + (size_t)(nr + 1) * gstride;
   double *mw = gh0 + (nr + 1), *mh0 = mw + (size_t)(nr + 1) * gstride;
+  double *pw = mh0 + (nr + 1);            // pair weights by starting layer (vertical rays)
   {
     std::vector<double> sx(nr + 1);
     for (int rs = 0; rs < nr - 1; rs++) {
@@ -697,6 +699,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       else { const double r0 = rad[0]; for (int i = 1; i < n; i++) sx[i] = std::sqrt(rad[i] * rad[i] - r0 * r0); }
       simpson_weights(sx.data(), n, gw + (size_t)rs * gstride, gh0 + rs);
     }
+    for (int k = 0; k + 2 < nr; k++) { double h0; simpson_weights(a->radius + k, 3, pw + 4 * (size_t)k, &h0); }
     if (o->solution == TRX_SOL_TRANSIT)                       // slantpath.c:399-408, per point count
       for (int cnt = 3; cnt <= nr; cnt++) {
         for (int q = 0; q < cnt; q++) sx[q] = a->radius[nr - 1 - (cnt - 1 - q)] * a->rad_fct;
@@ -718,7 +721,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
       (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
       (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
-      (rc = ensure(h, h->d_status, 16)))
+      (rc = ensure(h, h->d_status, 16)) || (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)) ||
+      (rc = ensure(h, h->d_arbuf, sizeof(double) * 2 * (kMaxChunk + 1))))
     return rc;
   if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4))))
     return rc;
@@ -726,13 +730,18 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))
     return rc;
   if ((rc = upload(h, h->d_ip, ipv))) return rc;
-  HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * nr, st));
   HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 24 * (size_t)nr, st));
   HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
-  { const int f0[4] = {(int)std::min<int64_t>(nsh, 0x7fffffff), 0, 0, 0};
+  HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
+  {   // all-reduce staging: maxima 0, "rays still open" flags 1
+    double ar0[2 * (kMaxChunk + 1)] = {0}; ar0[kMaxChunk] = 1.0; ar0[2 * kMaxChunk + 1] = 1.0;
+    HIPCHK(h, hipMemcpyAsync(h->d_arbuf.p, ar0, sizeof(ar0), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
+  { const int f0[8] = {(int)std::min<int64_t>(nsh, 0x7fffffff), 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(h->d_flags.p, f0, sizeof(f0), hipMemcpyHostToDevice, st)); }
 
   const double *df = h->d_layer_f64.as<double>(); const int32_t *di = h->d_layer_i32.as<int32_t>();
@@ -743,7 +752,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const double *d_press = df + 7 * nli, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
   const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
-               *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride;
+               *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride, *d_pw = d_mh0 + (nr + 1);
 
   // ---- CIA extinction (device) ----------------------------------------------------
   {
@@ -768,7 +777,15 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
   int nchunks = 0;
   for (int r_top = nr - 1; r_top >= 0; ) {
-    const int nc = std::min(nc_max, r_top + 1);
+    // Chunk plan: nc_max layers per step; when the previous spectrum on this handle
+    // stopped at hint_layers (retrieval loops re-run near-identical atmospheres), end a
+    // step exactly there so that no layer below the expected last one is swept in vain.
+    int nc = std::min(nc_max, r_top + 1);
+    {
+      const int swept = nr - 1 - r_top;
+      if (!eager && !h->comm && h->hint_layers > swept && h->hint_layers - swept < nc) nc = std::max(h->hint_layers - swept, swept == 0 ? 3 : 1);
+      nc = std::min(nc, r_top + 1);
+    }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     // groups whose profiles can reach this shard in any layer of the chunk
     // (contiguous per isotope block).  The layer maximum is global
@@ -799,22 +816,24 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     }
     const long long seg_groups = GG.base[GG.n];
     const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
+    double *ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
+    double *ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
+    const double *ggate = h->comm ? ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
     if (seg_groups > 0) {
       hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_groups + 255) / 256)), dim3(256), 0, st,
                          h->L, Y, GG, niso, r_top, nc, h->d_adop.as<double>(), h->ndop, d_wcut,
-                         h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), h->d_kmax.as<unsigned long long>(),
-                         h->d_flags.as<int>(), (int)eager);
+                         h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), (unsigned long long *)ar_cur,
+                         h->d_flags.as<int>(), ggate, (int)eager);
     }
-    if (h->comm) {
-      unsigned long long *km = h->d_kmax.as<unsigned long long>() + (r_top - nc + 1);
-      if (rccl().AllReduce(km, km, (size_t)nc, ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
+    if (h->comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
+      if (rccl().AllReduce(ar_cur, ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
         return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     if (h->ngroups > 0) {
       hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
-                         h->L, Y, niso, r_top, nc, h->d_kmax.as<double>(), o->ethresh, h->d_adop.as<double>(), h->ndop,
-                         d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), (int)eager);
+                         h->L, Y, niso, r_top, nc, ar_cur, o->ethresh, h->d_adop.as<double>(), h->ndop,
+                         d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)eager);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     if (h->ngroups > 0) {
@@ -822,7 +841,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
       A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
       A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
-      A.kmax = h->d_kmax.as<double>(); A.ethresh = o->ethresh;
+      A.kmaxc = ar_cur; A.ethresh = o->ethresh;
       A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
       A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>();
       A.part = prof ? h->d_part3.as<unsigned long long>() : nullptr; A.part_stride = (int)tblocks;
@@ -867,7 +886,11 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
-      hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + kTauW - 1) / kTauW)), dim3(256), 0, st, T);
+      T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = ar_prev;
+      if (o->solution == TRX_SOL_ECLIPSE)
+        hipLaunchKernelGGL(k_optical_depth_vertical, dim3((unsigned)((nsh + 63) / 64)), dim3(64), 0, st, T);
+      else
+        hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + kTauW - 1) / kTauW)), dim3(256), 0, st, T);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     r_top -= nc; nchunks++;
@@ -899,7 +922,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev_end, st));
 
   // ---- results back -----------------------------------------------------------
-  int flags_host[4] = {0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
+  int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
   HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
   if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
@@ -909,6 +932,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   trx_stats &S = h->stats;
   S.layers_swept = flags_host[2];
+  h->hint_layers = flags_host[4];
   S.neval = S.nskip = S.sum_bins = 0;
   for (int r = 0; r < nr; r++) { S.sum_bins += (int64_t)counters[3*r]; S.neval += (int64_t)counters[3*r+1]; S.nskip += (int64_t)counters[3*r+2]; }
   float ms = 0; (void)hipEventElapsedTime(&ms, ev_begin, ev_end); S.ms_run_total = ms;

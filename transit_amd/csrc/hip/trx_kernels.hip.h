@@ -43,6 +43,17 @@ __device__ __forceinline__ int wave_max_i(int v)
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Gate of the line-sweep kernels: rays still descending.  One GPU: the device
+// counter flags[0].  Sharded job: the all-reduced flag of the previous step
+// (ggate, a double that is > 0 while any rank still has open rays), because the
+// per-layer maximum line strength needs every rank's lines as long as ANY rank
+// goes on.
+__device__ __forceinline__ bool sweep_active(const int *flags, const double *ggate, int eager)
+{
+  if (eager) return true;
+  return ggate ? (*ggate > 0.0) : (flags[0] != 0);
+}
+
 __device__ __forceinline__ long long seg_index(const Segments &G, long long t)
 {
   int s = 0;
@@ -191,10 +202,10 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
                    const double *__restrict__ adop, int ndop,
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                    double *__restrict__ SG, uint8_t *__restrict__ idop8,
-                   unsigned long long *__restrict__ kmax_bits,
-                   const int *__restrict__ flags, int eager)
+                   unsigned long long *__restrict__ kmaxc_bits,   // [chunk slot] bits of the running maxima
+                   const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
 {
-  if (!eager && flags[0] == 0) return;
+  if (!sweep_active(flags, ggate, eager)) return;
   __shared__ double s_adop[kMaxDop + 1];
   __shared__ double red[4][kMaxChunk];
   for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
@@ -236,7 +247,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   if (threadIdx.x < nc) {
     const int c = threadIdx.x;
     const double m = fmax(fmax(red[0][c], red[1][c]), fmax(red[2][c], red[3][c]));
-    if (m > 0) atomicMax(&kmax_bits[r_top - c], (unsigned long long)__double_as_longlong(m));
+    if (m > 0) atomicMax(&kmaxc_bits[c], (unsigned long long)__double_as_longlong(m));
   }
 }
 
@@ -250,18 +261,18 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
 // their strengths exactly as pass 1/2a do.
 __global__ __launch_bounds__(64)
 void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
-                    const double *__restrict__ kmax, double ethresh,
+                    const double *__restrict__ kmaxc, double ethresh,
                     const double *__restrict__ adop, int ndop,
                     const int *__restrict__ npre,        // [layer][iso] refreshing groups
                     int *__restrict__ sticky_idop,       // [layer][iso]
-                    const int *__restrict__ flags, int eager)
+                    const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
 {
-  if (!eager && flags[0] == 0) return;
+  if (!sweep_active(flags, ggate, eager)) return;
   const int c = blockIdx.x / niso, b = blockIdx.x - c * niso;
   if (c >= nc) return;
   const int r = r_top - c, ri = r * niso + b, lane = threadIdx.x;
   const int gb0 = L.gblock[b];
-  const double ct = Y.negc_over_t[r], lim = ethresh * kmax[r], f = Y.strength_f[ri];
+  const double ct = Y.negc_over_t[r], lim = ethresh * kmaxc[c], f = Y.strength_f[ri];
   int found = -1;
   for (int base = npre[ri] - 1; base >= 0 && found < 0; base -= 64) {
     const int k = base - lane;
@@ -322,7 +333,7 @@ struct AccumArgs {
   int r_top, nc, ntiles;
   const double  *SG;                // [chunk][ngroups] group strength before threshold and density
   const uint8_t *idop8;             // [chunk][ngroups]
-  const double  *kmax;              // [layer] strongest single line (after the all-reduce, if any)
+  const double  *kmaxc;             // [chunk slot] strongest single line (after the all-reduce, if any)
   double ethresh;
   const int     *sticky_idop;       // [layer][iso]
   const int32_t *psize;             // [ndop][nlor]
@@ -363,7 +374,7 @@ void k_accumulate(AccumArgs A)
 #pragma unroll
   for (int t = 0; t < kTileBins; t++) acc[t] = 0.0;
   long long nb = 0, nev = 0, nsk = 0;
-  const double lim = A.ethresh * A.kmax[r];
+  const double lim = A.ethresh * A.kmaxc[c];
   // counters: a group is counted by the tile that holds its own coarse bin
   const long long hk0 = j0, hk1 = (j1 == A.nwn - 1) ? (long long)1 << 60 : j1;
 
@@ -488,7 +499,7 @@ void k_accumulate_wide(WideArgs W)
 #pragma unroll
   for (int m = 0; m < kWideM; m++) acc[m] = 0.0;
   long long nb = 0, nev = 0, nsk = 0;
-  const double lim = A.ethresh * A.kmax[r];
+  const double lim = A.ethresh * A.kmaxc[c];
   const int of = A.osamp;
 
   if (live)
@@ -666,6 +677,13 @@ struct TauArgs {
   const double *mdens, *nH;          // [nr]
   int *flags;                        // [0] active rays (gate), [1] rays still active after this chunk
   int eager;
+  // vertical (eclipse) rays only: weights of the interval pair that STARTS at layer k,
+  // {2-hratio, hfactor, 2-1/hratio, hsum} from h_k = rad[k+1]-rad[k], and the running
+  // Simpson sums of both parities carried from chunk to chunk
+  const double *pw;                  // [nr][4]
+  double *acc;                       // [2][nsh]
+  // staging of the NEXT step's all-reduce: [kMaxChunk] maxima (zeroed here) + 1 flag
+  double *next_ar;
 };
 
 __device__ __forceinline__ double scat_term(const TauArgs &T, int r, double wn)
@@ -698,6 +716,13 @@ __device__ __forceinline__ double cloud_term(const TauArgs &T, int r, double wn)
   return 0.0;
 }
 
+// every ray of this shard has stopped: keep the next step's all-reduce staging
+// clean (maxima 0, "rays open" flag 0)
+__device__ __forceinline__ void tau_idle(const TauArgs &T)
+{
+  if (blockIdx.x == 0 && threadIdx.x <= kMaxChunk) T.next_ar[threadIdx.x] = 0.0;
+}
+
 // Heights are visited top-down, a chunk of layers per launch (tau.c:235-290).
 // A 256-thread block owns 256/kTauH wavenumbers x kTauH heights:
 //   phase 1 (one lane per wavenumber): total extinction of the chunk's layers
@@ -714,7 +739,7 @@ constexpr int kTauW = 256 / kTauH;        // wavenumbers per block
 __global__ __launch_bounds__(256)
 void k_optical_depth(TauArgs T)
 {
-  if (!T.eager && T.flags[0] == 0) return;
+  if (!T.eager && T.flags[0] == 0) { tau_idle(T); return; }
   __shared__ double s_y0[kTauH][kTauW];
   __shared__ double s_tv[kTauH][kTauW];
   __shared__ int s_alive[kTauW];
@@ -798,6 +823,10 @@ void k_optical_depth(TauArgs T)
   }
   const unsigned long long m = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&T.flags[1], __popcll(m));
+  {
+    const int deep = wave_max_i((hc == 0 && ok && T.last[ok ? w : 0] >= 0) ? T.last[w] + 1 : 0);
+    if ((threadIdx.x & 63) == 0 && deep > T.flags[4]) atomicMax(&T.flags[4], deep);
+  }
   // the last block to arrive publishes the number of rays still descending
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -808,6 +837,86 @@ void k_optical_depth(TauArgs T)
       const int act = atomicAdd(&T.flags[1], 0);
       T.flags[2] += T.nc;                                // layers swept so far
       T.flags[1] = 0; T.flags[3] = 0;
+      for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
+      T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
+      __threadfence();
+      atomicExch(&T.flags[0], act);
+    }
+  }
+}
+
+// Vertical rays (eclipse geometry, eclipse.c:29-105) in O(1) per height.
+// The path abscissa is the radius itself, so the Simpson term of the interval
+// pair that starts at layer k,
+//     P(k) = (y[k](2-hr) + y[k+1] hf + y[k+2](2-1/hr)) hsum,
+// does not depend on where the ray starts, and -- because eclipsetau leaves its
+// bottom-point parabola value in er (eclipse.c:65-66) -- neither do the y's once
+// layer k has been the bottom.  Hence with A(k) = P(k) + A(k+2):
+//     odd  point count:  tau(rs) = A(rs)/6
+//     even point count:  tau(rs) = A(rs+1)/6 + h_rs (y[rs]+y[rs+1])/2
+// which is the reference's sum re-associated (top-down instead of bottom-up) with
+// interval lengths taken as rad[k+1]-rad[k] rather than differences of their running
+// sum: ~1e-15 relative.  One lane per wavenumber walks the chunk's layers.
+__global__ __launch_bounds__(64)
+void k_optical_depth_vertical(TauArgs T)
+{
+  if (!T.eager && T.flags[0] == 0) { tau_idle(T); return; }
+  const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
+  const int nr = T.nr;
+  bool still = false;
+  if (w < T.nsh && T.last[w] < 0) {
+    still = true;
+    const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
+    double a1 = T.acc[w], a2 = T.acc[T.nsh + w];          // A(rs+1), A(rs+2) on entry of a step
+    // y1, y2: (edited) extinction of the two layers above the current bottom
+    double y1 = 0, y2 = 0;
+    if (T.r_top + 1 < nr) y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
+    if (T.r_top + 2 < nr) y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
+    for (int c = 0; c < T.nc; c++) {
+      const int rs = T.r_top - c, ri = nr - 1 - rs, n = nr - rs;
+      const long long k = (long long)rs * T.nsh + w;
+      const double yraw = T.e[k] + scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[k];   // tau.c:231-232
+      double tv, y0 = yraw;
+      if (n == 1) {
+        tv = 0.0;                                           // eclipse.c:45-46
+      } else if (n == 2) {                                  // eclipse.c:65, 68-80 (value not kept)
+        // needs the layer below: it belongs to this chunk (the first chunk has >= 3 layers)
+        const long long kb = (long long)(rs - 1) * T.nsh + w;
+        const double ym = T.e[kb] + scat_term(T, rs - 1, wcgs) + cloud_term(T, rs - 1, wcgs) + T.ecs[kb];
+        const double yp = parab3(T.rad[rs-1], T.rad[rs], ym, yraw, y1, T.rad[rs]);
+        const double *g = T.gw + (long long)rs * T.gstride;
+        tv = T.rad_fct * (((yp * g[0] + ((y1 + yp) / 2.0) * g[1] + y1 * g[2]) * g[3]) / 6.0);
+      } else {
+        y0 = parab3(T.rad[rs], T.rad[rs+1], yraw, y1, y2, T.rad[rs]);      // kept: eclipse.c:66
+        const double *p = T.pw + 4 * rs;
+        const double a0 = (y0 * p[0] + y1 * p[1] + y2 * p[2]) * p[3] + a2;
+        double res = (n & 1) ? a0 / 6.0 : a1 / 6.0 + (T.rad[rs+1] - T.rad[rs]) * (y0 + y1) / 2;
+        tv = T.rad_fct * res;
+        a2 = a1; a1 = a0;
+      }
+      T.er[k] = y0;
+      y2 = y1; y1 = y0;
+      T.tau[(long long)ri * T.nsh + w] = tv;
+      if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
+    }
+    T.acc[w] = a1; T.acc[T.nsh + w] = a2;
+  }
+  const unsigned long long m = __ballot(still);
+  if (threadIdx.x == 0 && m) atomicAdd(&T.flags[1], __popcll(m));
+  {
+    const int deep = wave_max_i((w < T.nsh && T.last[w < T.nsh ? w : 0] >= 0) ? T.last[w] + 1 : 0);
+    if (threadIdx.x == 0 && deep > T.flags[4]) atomicMax(&T.flags[4], deep);
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int ticket = atomicAdd(&T.flags[3], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      __threadfence();
+      const int act = atomicAdd(&T.flags[1], 0);
+      T.flags[2] += T.nc;
+      T.flags[1] = 0; T.flags[3] = 0;
+      for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
+      T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
       __threadfence();
       atomicExch(&T.flags[0], act);
     }
