@@ -61,7 +61,7 @@ struct trx_handle {
   const float *tabT = nullptr; const long long *poffT = nullptr;
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
-  DevBuf d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
+  DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
   LinesDev L{};
   std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
   void *comm = nullptr; int nranks = 1, rank = 0;
@@ -290,13 +290,15 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     if (giso[g] == giso[g-1] && giown[g] > giown[g-1])
       return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
 
+  std::vector<int32_t> lgroup((size_t)n, -1);
+  for (size_t g = 0; g < gfirst.size(); g++) lgroup[(size_t)gfirst[g]] = (int32_t)g;
   std::vector<int32_t> gimod(giown.size()), gidiv(giown.size());
   for (size_t g = 0; g < giown.size(); g++) { gimod[g] = giown[g] % s->osamp; gidiv[g] = giown[g] / s->osamp; }
   std::vector<double> elow(s->elow, s->elow + n), gf(s->gf, s->gf + n);
   std::vector<int16_t> iso(s->isoid, s->isoid + n);
   int rc;
   if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_elow, elow)) || (rc = upload(h, h->d_gf, gf)) ||
-      (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
+      (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
       (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
       (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gimod, gimod)) || (rc = upload(h, h->d_gidiv, gidiv)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
     return rc;
@@ -304,7 +306,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   h->h_gwavn = gwavn; h->h_gblock = gblock; h->h_cntge = cntge; h->h_gfirst = gfirst; h->h_gcount = gcount;
   LinesDev &L = h->L;
   L.nlines = n; L.wavn = h->d_wavn.as<double>(); L.elow = h->d_elow.as<double>(); L.gf = h->d_gf.as<double>();
-  L.iso = h->d_iso.as<int16_t>(); L.inrange = h->d_inr.as<uint8_t>();
+  L.iso = h->d_iso.as<int16_t>(); L.inrange = h->d_inr.as<uint8_t>(); L.lgroup = h->d_lgroup.as<int32_t>();
   L.ngroups = h->ngroups; L.gfirst = h->d_gfirst.as<int32_t>(); L.gcount = h->d_gcount.as<int32_t>();
   L.giown = h->d_giown.as<int32_t>(); L.giso = h->d_giso.as<int16_t>(); L.gwavn = h->d_gwavn.as<double>();
   L.gblock = h->d_gblock.as<int32_t>(); L.cnt_ge = h->d_cntge.as<int32_t>();
@@ -810,7 +812,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
           ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
         }
         if (ga >= gz) continue;
-        GG.start[GG.n] = ga; GG.base[GG.n] = ng_tot; ng_tot += gz - ga; GG.n++;
+        // line range of the groups [ga, gz): anchors and members are consecutive lines
+        const long long la = h->h_gfirst[ga], lz = (long long)h->h_gfirst[gz - 1] + h->h_gcount[gz - 1];
+        GG.start[GG.n] = la; GG.base[GG.n] = ng_tot; ng_tot += lz - la; GG.n++;
       }
       GG.base[GG.n] = ng_tot;
     }

@@ -35,6 +35,7 @@ struct LinesDev {
   const double  *gf;       // [nlines]
   const int16_t *iso;      // [nlines]
   const uint8_t *inrange;  // [nlines] extinction.c:410
+  const int32_t *lgroup;   // [nlines] group index when the line anchors a co-added group, else -1
   int64_t ngroups;
   const int32_t *gfirst;   // [ngroups] first line of the co-added group (extinction.c:449-462)
   const int32_t *gcount;   // [ngroups] members

@@ -197,6 +197,22 @@ void k_voigt_bins_wave(const ProfileJob *jobs, float *table, int m_limit)
 // and per layer the maximum single-line strength (wave max -> one 64-bit
 // atomicMax per block).  The threshold test against ethresh*kmax (:467) needs
 // the finished maximum, so it is applied where SG is consumed (k_accumulate).
+// nearest_index() continued from a previous answer: same result as the bisection
+// of pu/src/iomisc.c:1088-1108 on a strictly increasing grid with a +inf sentinel
+// at a[n] (bracket a[lo] <= v < a[lo+1], then the nearer of the two, ties to lo),
+// but the bracket is walked from `lo`, which is 0-1 steps from layer to layer.
+__device__ __forceinline__ int nearest_from(const double *a, int n, double v, int lo)
+{
+  while (lo + 1 < n && v >= a[lo + 1]) lo++;
+  while (lo > 0 && v < a[lo]) lo--;
+  return (fabs(a[lo + 1] - v) < fabs(a[lo] - v)) ? lo + 1 : lo;
+}
+
+constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are staged in LDS
+
+// One lane per LINE (uniform work: two exponentials per line and layer); the
+// lanes that anchor a co-added group then add their members' strengths out of
+// LDS.  G walks line ranges (contiguous per isotope block).
 __global__ __launch_bounds__(256)
 void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
                    const double *__restrict__ adop, int ndop,
@@ -208,40 +224,70 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   if (!sweep_active(flags, ggate, eager)) return;
   __shared__ double s_adop[kMaxDop + 1];
   __shared__ double red[4][kMaxChunk];
+  __shared__ double s_ct[kMaxChunk];
+  __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
+  __shared__ double s_s[2][256];                         // line strengths of the layer in flight
   for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
-  __syncthreads();
-  const long long g = seg_index(G, (long long)blockIdx.x * 256 + threadIdx.x);
-  const bool ok = g >= 0;
+  if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
+  const int nst = min(niso, kSweepIsoLds);
+  for (int i = threadIdx.x; i < nc * nst; i += 256) {
+    const int c = i / nst, b = i - c * nst, ri = (r_top - c) * niso + b;
+    s_f[c][b] = Y.strength_f[ri]; s_wc[c][b] = wcut[ri]; s_ad[c][b] = Y.alphad[ri];
+  }
+  const long long t0 = (long long)blockIdx.x * 256;
+  const long long ln = seg_index(G, t0 + threadIdx.x);
+  // lanes of one block that belong to the same segment are consecutive lines: lane
+  // tid+m holds line ln+m iff it maps to the same segment (checked below)
+  const long long ln_next_block = seg_index(G, t0 + 256);     // first line after this block (or -1)
+  const bool ok = ln >= 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int first = 0, cnt = 0, iso = 0;
+  int g = -1, cnt = 0, iso = 0;
   double wavn = 0, elow = 0, gf = 0; bool inr = false;
   if (ok) {
-    first = L.gfirst[g]; cnt = L.gcount[g]; iso = L.giso[g];
-    wavn = L.wavn[first]; elow = L.elow[first]; gf = L.gf[first]; inr = L.inrange[first] != 0;
+    wavn = L.wavn[ln]; elow = L.elow[ln]; gf = L.gf[ln]; inr = L.inrange[ln] != 0;
+    iso = L.iso[ln]; g = L.lgroup[ln];
+    if (g >= 0) cnt = L.gcount[g];
   }
+  // members that sit in this block's LDS window: lines ln+1 .. ln+cnt-1 are consecutive
+  // lanes as long as they stay inside the block AND inside the same segment; the anchor
+  // and its members always share a segment (segments are cut at group boundaries)
+  int in_lds = cnt;
+  if (g >= 0 && (int)threadIdx.x + cnt > 256) in_lds = 256 - (int)threadIdx.x;
+  (void)ln_next_block;
+  const bool staged = iso < kSweepIsoLds;
+  int lo = 0;                                               // Doppler-grid bracket carried across layers
+  __syncthreads();
   for (int c = 0; c < nc; c++) {
     const int r = r_top - c;
-    const double ct = Y.negc_over_t[r];
-    double kbest = 0;
-    if (ok) {
-      const double f = Y.strength_f[r * niso + iso];
-      double pk = gf * exp(ct * elow) * (1 - exp(ct * wavn));
-      if (inr) kbest = pk * f;
-      for (int m = 1; m < cnt; m++) {                       // co-added members (extinction.c:449-462)
-        const int ln = first + m;
-        const double sm = L.gf[ln] * exp(ct * L.elow[ln]) * (1 - exp(ct * L.wavn[ln]));
-        if (L.inrange[ln]) kbest = fmax(kbest, sm * f);
-        pk += sm;
+    const double ct = s_ct[c];
+    const int ri = r * niso + iso;
+    const double f = staged ? s_f[c][iso] : (ok ? Y.strength_f[ri] : 0.0);
+    double s = 0;
+    if (ok) s = gf * exp(ct * elow) * (1 - exp(ct * wavn));
+    s_s[c & 1][threadIdx.x] = s;
+    double kbest = inr ? s * f : 0.0;
+    kbest = wave_max(kbest);
+    if (lane == 0) red[wv][c] = kbest;
+    __syncthreads();
+    if (g >= 0) {
+      double pk = s;
+      for (int m = 1; m < in_lds; m++) pk += s_s[c & 1][threadIdx.x + m];
+      for (int m = in_lds; m < cnt; m++) {                  // members beyond the block: recompute
+        const long long lm = ln + m;
+        pk += L.gf[lm] * exp(ct * L.elow[lm]) * (1 - exp(ct * L.wavn[lm]));
       }
       pk *= f;
+      const double wc = staged ? s_wc[c][iso] : wcut[ri];
       uint8_t id = 0xFF;
-      if (wavn >= wcut[r * niso + iso])
-        id = (uint8_t)nearest_index(s_adop, Y.alphad[r * niso + iso] * wavn, 0, ndop);
+      if (wavn >= wc) {
+        const double v = (staged ? s_ad[c][iso] : Y.alphad[ri]) * wavn;
+        const int k = nearest_from(s_adop, ndop, v, lo);
+        lo = k;
+        id = (uint8_t)k;
+      }
       SG[(long long)c * L.ngroups + g] = pk;
       idop8[(long long)c * L.ngroups + g] = id;
     }
-    kbest = wave_max(kbest);
-    if (lane == 0) red[wv][c] = kbest;
   }
   __syncthreads();
   if (threadIdx.x < nc) {
