@@ -120,7 +120,7 @@ def hip_library():
     """Load libtransit_hip.so or raise -- there is no CPU fallback."""
     global _hip
     if _hip is None:
-        path = lib_path("libtransit_hip.so")
+        path = os.environ.get("TRANSIT_HIP_LIB") or lib_path("libtransit_hip.so")   # override: A/B builds
         if not os.path.exists(path):
             raise RuntimeError("HIP extension %s is missing; build it with "
                                "`python -m transit_amd.build` (hipcc --offload-arch=gfx950)" % path)
