@@ -49,6 +49,22 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel):
+    """HBM bytes per (active) launch of `kernel` from the committed rocprofv3 PMC
+    passes (profiles/*pmc_traffic*.json; FETCH_SIZE/WRITE_SIZE collected in separate
+    --pmc runs and corrected as MI355X_MICROARCH.md prescribes).  None when no
+    profile of the current kernels is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return float(d["kernels"]["trx::" + kernel]["hbm_bytes_per_active_launch"])
+    except Exception:
+        return None
+
+
 def make_workload(args, tag, nlines, verb=2):
     from transit_amd import synth
     d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%d" % (tag, nlines, args.layers, os.getpid()))
@@ -212,6 +228,9 @@ def main():
                        "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
                        "parallelism": "wn-shard x%d" % world,
+                       "layer_chunk": args.layer_chunk or 12,
+                       "depth_hint": "chunk plan ends at the previous run's deepest layer (retrieval-loop reuse; "
+                                     "warm-up runs provide it)",
                        "ms_create_total": 1e3 * t_create, "ms_create_voigt_table_kernels": stats["ms_create_table"],
                        "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
                        "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],
@@ -219,7 +238,11 @@ def main():
                        "b_alg_run_bytes": b_alg_run,
                        "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else None,
+                         "note": "achieved = algorithmic bytes of the reference's data flow (SURVEY 8d: 26 B per line "
+                                 "per layer per pass) / measured launch time; the kernel itself reads each line once "
+                                 "per chunk of layers, so its measured traffic is BELOW the algorithmic bytes",
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
                          "launches": launches},
         }

@@ -439,6 +439,177 @@ Rccl &rccl()
   return R;
 }
 
+// ---- per-layer scalars (extinction.c:364-395), shared by trx_run and trx_sweep_permol ----
+struct LayerHost {
+  size_t nli = 0, extra_off = 0;
+  std::vector<double> f64; std::vector<int32_t> i32;
+  const int32_t *psmax = nullptr;
+};
+
+int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *density /* [nmol][nr] */,
+                const double *zpart /* [niso][nr] */, size_t extra_doubles, LayerHost &LH)
+{
+  const int niso = h->niso, nmol = h->nmol;
+  const size_t nli = (size_t)nr * std::max(niso, 1);
+  LH.nli = nli; LH.extra_off = 7 * nli;
+  LH.f64.assign(7 * nli + extra_doubles, 0.0);
+  LH.i32.assign(4 * nli, 0);
+  double *negct = &LH.f64[0], *strength = negct + nr, *dens = strength + nli, *alphad = dens + nli,
+         *alphal = alphad + nli, *wcut = alphal + nli;
+  int32_t *idop0 = &LH.i32[0], *ilor = idop0 + nli, *psmax = ilor + nli, *npre = psmax + nli;
+  LH.psmax = psmax;
+  for (int r = 0; r < nr; r++) {
+    const double temp = temp_k[r];
+    if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
+    negct[r] = -kExpCte * kTliEfct / temp;
+    const double fdoppler = std::sqrt(2 * kKb * temp / kAmu) * kSqrtLn2 / kLs;
+    const double florentz = std::sqrt(2 * kKb * temp / kPi / kAmu) / (kAmu * kLs);
+    for (int i = 0; i < niso; i++) {
+      double al = 0.0;
+      for (int j = 0; j < nmol; j++) {
+        const double csd = h->mol_radius[j] + h->mol_radius[h->iso_imol[i]];
+        al += density[(size_t)j * nr + r] / h->mol_mass[j] * csd * csd *
+              std::sqrt(1 / h->iso_mass[i] + 1 / h->mol_mass[j]);
+      }
+      al *= florentz;
+      const double ad = fdoppler / std::sqrt(h->iso_mass[i]);
+      const size_t k = (size_t)r * niso + i;
+      alphal[k] = al; alphad[k] = ad;
+      idop0[k] = nearest_index(h->adop.data(), ad * h->wn_i, 0, h->ndop);
+      ilor[k]  = nearest_index(h->alor.data(), al, 0, h->nlor);
+      strength[k] = kSigCte * h->iso_ratio[i] / (h->iso_mass[i] * zpart[(size_t)i * nr + r]);
+      dens[k] = density[(size_t)h->iso_imol[i] * nr + r];
+      wcut[k] = doppler_refresh_cut(ad, al);
+      int dlo = idop0[k], dhi = idop0[k];
+      if (h->iso_wmax[i] > 0) {
+        const int a0 = nearest_index(h->adop.data(), ad * h->iso_wmin[i], 0, h->ndop);
+        const int a1 = nearest_index(h->adop.data(), ad * h->iso_wmax[i], 0, h->ndop);
+        dlo = std::min(dlo, std::min(a0, a1)); dhi = std::max(dhi, std::max(a0, a1));
+      }
+      int32_t pm = 0;
+      for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
+      psmax[k] = pm;
+      {   // groups of the block that refresh the Doppler index: wavn >= wcut (descending order)
+        const double *gb = h->h_gwavn.data() + h->h_gblock[i], *ge = h->h_gwavn.data() + h->h_gblock[i + 1];
+        const double wc = wcut[k];
+        npre[k] = (int32_t)(std::partition_point(gb, ge, [wc](double w) { return w >= wc; }) - gb);
+      }
+    }
+  }
+  return TRX_OK;
+}
+
+void layer_dev(trx_handle *h, const LayerHost &LH, int nr, LayerDev &Y, const double *&d_wcut, const int32_t *&d_npre)
+{
+  const double *df = h->d_layer_f64.as<double>(); const int32_t *di = h->d_layer_i32.as<int32_t>();
+  const size_t nli = LH.nli;
+  Y.negc_over_t = df; Y.strength_f = df + nr; Y.density = Y.strength_f + nli; Y.alphad = Y.density + nli;
+  Y.alphal = Y.alphad + nli; d_wcut = Y.alphal + nli;
+  Y.idop0 = di; Y.ilor = di + nli; Y.psmax = Y.ilor + nli; d_npre = Y.psmax + nli;
+}
+
+// ---- one step of the line sweep: strengths (+ all-reduce), sticky index, accumulation ----
+struct SweepMode {
+  bool eager = false, prof = false, skip_done = false, permol = false, use_comm = false;
+  double ethresh = 0; int chunk_index = 0;
+  int nmx = 1; const int32_t *d_iso_mx = nullptr;   // output slot per isotope (per-molecule sweeps)
+  double *d_e = nullptr;                             // [layer][nmx][nsh]
+  double *ar_cur = nullptr, *ar_prev = nullptr;      // maxima of this step / previous step's staging
+};
+
+int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const int32_t *d_npre, const int32_t *psmax,
+                int r_top, int nc, int nc_max, const SweepMode &M, std::vector<hipEvent_t> *ev)
+{
+  hipStream_t st = h->stream;
+  const int niso = h->niso; const int64_t nsh = h->nsh;
+  const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
+  auto mark = [&]() -> int { if (!ev) return 0; hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev->push_back(e); return hipEventRecord(e, st) == hipSuccess ? 0 : -1; };
+  // lines whose profiles can reach this shard in any layer of the step (contiguous per
+  // isotope block).  The layer maximum is global (extinction.c:399-427 runs over every
+  // line): with a communicator each rank reduces its own window and the maxima are
+  // all-reduced in-stream; a shard running on its own scans every line itself.
+  Segments GG{};
+  {
+    long long tot = 0;
+    for (int b = 0; b < niso; b++) {
+      const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
+      if (gb0 == gb1) continue;
+      int ga = gb0, gz = gb1;
+      if (M.use_comm) {
+        long long psm = 0;
+        for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
+        const long long lo_f = (long long)h->osamp * h->lo - psm;
+        long long klo = lo_f > 0 ? lo_f / h->osamp : 0;
+        long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp;
+        if (khi > h->nwn - 1) khi = h->nwn - 1;
+        const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
+        ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
+      }
+      if (ga >= gz) continue;
+      const long long la = h->h_gfirst[ga], lz = (long long)h->h_gfirst[gz - 1] + h->h_gcount[gz - 1];
+      GG.start[GG.n] = la; GG.base[GG.n] = tot; tot += lz - la; GG.n++;
+    }
+    GG.base[GG.n] = tot;
+  }
+  const long long seg_lines = GG.base[GG.n];
+  const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
+  const double *ggate = M.use_comm ? M.ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
+  if (seg_lines > 0) {
+    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
+                       h->L, Y, GG, niso, r_top, nc, h->d_adop.as<double>(), h->ndop, d_wcut,
+                       h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), (unsigned long long *)M.ar_cur,
+                       M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
+  }
+  if (M.use_comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
+    if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
+      return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
+  }
+  if (mark()) return fail(h, TRX_E_HIP, "event");
+  if (h->ngroups > 0) {
+    hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
+                       h->L, Y, niso, r_top, nc, M.ar_cur, M.nmx, M.d_iso_mx, M.ethresh, h->d_adop.as<double>(), h->ndop,
+                       d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)M.eager);
+  }
+  if (mark()) return fail(h, TRX_E_HIP, "event");
+  if (h->ngroups > 0) {
+    AccumArgs A{};
+    A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
+    A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
+    A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
+    A.kmaxc = M.ar_cur; A.ethresh = M.ethresh; A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol;
+    A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
+    A.table = h->d_tab.as<float>(); A.e = M.d_e;
+    A.part = M.prof ? h->d_part3.as<unsigned long long>() : nullptr; A.part_stride = (int)tblocks;
+    A.flags = h->d_flags.as<int>(); A.eager = M.eager;
+    A.last = M.skip_done ? h->d_last.as<int>() : nullptr;
+    // layers whose profiles span >= 64 coarse bins go to the lanes-own-bins kernel
+    unsigned wide_mask = 0;
+    for (int c = 0; c < nc; c++) {
+      long long pm = 0;
+      for (int b = 0; b < niso; b++)
+        if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)(r_top - c) * niso + b]);
+      if ((2 * pm) / h->osamp + 1 >= 64) wide_mask |= 1u << c;
+    }
+    A.skip_mask = wide_mask;
+    if (M.prof) HIPCHK(h, hipMemsetAsync(h->d_part3.p, 0, 24 * (size_t)nc_max * tblocks, st));
+    if (wide_mask != (nc >= 32 ? 0xffffffffu : ((1u << nc) - 1u)))
+      hipLaunchKernelGGL(k_accumulate, dim3(tblocks, (unsigned)nc), dim3(256), 0, st, A);
+    if (wide_mask) {
+      WideArgs W{}; W.A = A; W.tabT = h->tabT; W.poffT = h->poffT;
+      W.gimod = h->d_gimod.as<int32_t>(); W.gidiv = h->d_gidiv.as<int32_t>(); W.layer_mask = wide_mask;
+      const unsigned wtiles = (unsigned)((nsh + 64 * kWideM - 1) / (64 * kWideM));
+      hipLaunchKernelGGL(k_accumulate_wide, dim3((wtiles + 3) / 4, (unsigned)nc), dim3(256), 0, st, W);
+    }
+  }
+  if (mark()) return fail(h, TRX_E_HIP, "event");
+  if (M.prof && h->ngroups > 0) {      // counters (profiling runs only; gated like the sweep itself)
+    for (int k = 0; k < 3; k++)
+      hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
+                         (int)tblocks, 3, k, h->d_counters.as<unsigned long long>(), 3, r_top, h->d_flags.as<int>(), (int)M.eager);
+  }
+  return TRX_OK;
+}
+
 }  // namespace
 
 // ============================================================================
@@ -601,7 +772,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 {
   if (!h || !a || !o) return TRX_E_ARG;
   const auto t_host0 = std::chrono::steady_clock::now();
-  const int nr = a->nlayer, niso = h->niso, nmol = h->nmol;
+  const int nr = a->nlayer, nmol = h->nmol;
   const int64_t nsh = h->nsh;
   if (nr < 3) return fail(h, TRX_E_ARG, "at least three layers are needed");
   if (o->solution != TRX_SOL_ECLIPSE && o->solution != TRX_SOL_TRANSIT) return fail(h, TRX_E_ARG, "unknown solution");
@@ -619,53 +790,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   int rc;
 
   // ---- layer prologue (extinction.c:364-395) --------------------------------
-  const size_t nli = (size_t)nr * std::max(niso, 1);
-  std::vector<double> f64(7 * nli + 8 * (size_t)nr, 0.0);
-  double *negct = &f64[0], *strength = negct + nr, *dens = strength + nli, *alphad = dens + nli,
-         *alphal = alphad + nli, *wcut = alphal + nli, *pad0 = wcut + nli;
-  (void)pad0;
-  std::vector<int32_t> i32(4 * nli, 0);
-  int32_t *idop0 = &i32[0], *ilor = idop0 + nli, *psmax = ilor + nli, *npre = psmax + nli;
-  for (int r = 0; r < nr; r++) {
-    const double temp = a->temp[r];
-    if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
-    negct[r] = -kExpCte * kTliEfct / temp;
-    const double fdoppler = std::sqrt(2 * kKb * temp / kAmu) * kSqrtLn2 / kLs;
-    const double florentz = std::sqrt(2 * kKb * temp / kPi / kAmu) / (kAmu * kLs);
-    for (int i = 0; i < niso; i++) {
-      double al = 0.0;
-      for (int j = 0; j < nmol; j++) {
-        const double csd = h->mol_radius[j] + h->mol_radius[h->iso_imol[i]];
-        al += a->density[(size_t)j * nr + r] / h->mol_mass[j] * csd * csd *
-              std::sqrt(1 / h->iso_mass[i] + 1 / h->mol_mass[j]);
-      }
-      al *= florentz;
-      const double ad = fdoppler / std::sqrt(h->iso_mass[i]);
-      const size_t k = (size_t)r * niso + i;
-      alphal[k] = al; alphad[k] = ad;
-      idop0[k] = nearest_index(h->adop.data(), ad * h->wn_i, 0, h->ndop);
-      ilor[k]  = nearest_index(h->alor.data(), al, 0, h->nlor);
-      strength[k] = kSigCte * h->iso_ratio[i] / (h->iso_mass[i] * a->zpart[(size_t)i * nr + r]);
-      dens[k] = a->density[(size_t)h->iso_imol[i] * nr + r];
-      wcut[k] = doppler_refresh_cut(ad, al);
-      int dlo = idop0[k], dhi = idop0[k];
-      if (h->iso_wmax[i] > 0) {
-        const int a0 = nearest_index(h->adop.data(), ad * h->iso_wmin[i], 0, h->ndop);
-        const int a1 = nearest_index(h->adop.data(), ad * h->iso_wmax[i], 0, h->ndop);
-        dlo = std::min(dlo, std::min(a0, a1)); dhi = std::max(dhi, std::max(a0, a1));
-      }
-      int32_t pm = 0;
-      for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
-      psmax[k] = pm;
-      {   // groups of the block that refresh the Doppler index: wavn >= wcut (descending order)
-        const double *gb = h->h_gwavn.data() + h->h_gblock[i], *ge = h->h_gwavn.data() + h->h_gblock[i + 1];
-        const double wc = wcut[k];
-        npre[k] = (int32_t)(std::partition_point(gb, ge, [wc](double w) { return w >= wc; }) - gb);
-      }
-    }
-  }
+  LayerHost LH;
+  if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
+  const size_t nli = LH.nli;
+  std::vector<double> &f64 = LH.f64;
+  const int32_t *psmax = LH.psmax;
   // layer-only scalars of the scattering / cloud models (tau.c:193-214, extinction.c:617-621)
-  double *press = &f64[7 * nli], *tempk = press + nr, *mdens = tempk + nr, *nH = mdens + nr,
+  double *press = &f64[LH.extra_off], *tempk = press + nr, *mdens = tempk + nr, *nH = mdens + nr,
          *scat_pol = nH + nr, *radv = scat_pol + nr;
   for (int r = 0; r < nr; r++) {
     press[r] = a->press ? a->press[r] : 0.0; tempk[r] = a->temp[r]; radv[r] = a->radius[r];
@@ -728,7 +859,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     return rc;
   if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4))))
     return rc;
-  if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, i32)) || (rc = upload(h, h->d_geom, geom)) ||
+  if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_geom, geom)) ||
       (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))
     return rc;
   if ((rc = upload(h, h->d_ip, ipv))) return rc;
@@ -739,19 +870,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
   HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
   {   // all-reduce staging: maxima 0, "rays still open" flags 1
-    double ar0[2 * (kMaxChunk + 1)] = {0}; ar0[kMaxChunk] = 1.0; ar0[2 * kMaxChunk + 1] = 1.0;
-    HIPCHK(h, hipMemcpyAsync(h->d_arbuf.p, ar0, sizeof(ar0), hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    static const std::vector<double> ar0 = [] { std::vector<double> v(2 * (kMaxChunk + 1), 0.0); v[kMaxChunk] = 1.0; v[2 * kMaxChunk + 1] = 1.0; return v; }();
+    HIPCHK(h, hipMemcpyAsync(h->d_arbuf.p, ar0.data(), ar0.size() * sizeof(double), hipMemcpyHostToDevice, st));
   }
   { const int f0[8] = {(int)std::min<int64_t>(nsh, 0x7fffffff), 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(h->d_flags.p, f0, sizeof(f0), hipMemcpyHostToDevice, st)); }
 
-  const double *df = h->d_layer_f64.as<double>(); const int32_t *di = h->d_layer_i32.as<int32_t>();
-  LayerDev Y{};
-  Y.negc_over_t = df; Y.strength_f = df + nr; Y.density = Y.strength_f + nli; Y.alphad = Y.density + nli;
-  Y.alphal = Y.alphad + nli; const double *d_wcut = Y.alphal + nli;
-  Y.idop0 = di; Y.ilor = di + nli; Y.psmax = Y.ilor + nli; const int32_t *d_npre = Y.psmax + nli;
-  const double *d_press = df + 7 * nli, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
+  const double *df = h->d_layer_f64.as<double>();
+  LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
+  layer_dev(h, LH, nr, Y, d_wcut, d_npre);
+  const double *d_press = df + LH.extra_off, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
   const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride, *d_pw = d_mh0 + (nr + 1);
@@ -776,7 +904,6 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev_begin, st));
 
   // ---- top-down sweep in chunks of layers (tau.c:235-290) ----
-  const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
   int nchunks = 0;
   for (int r_top = nr - 1; r_top >= 0; ) {
     // Chunk plan: nc_max layers per step; when the previous spectrum on this handle
@@ -789,93 +916,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       nc = std::min(nc, r_top + 1);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    // groups whose profiles can reach this shard in any layer of the chunk
-    // (contiguous per isotope block).  The layer maximum is global
-    // (extinction.c:399-427 runs over every line): with a communicator each rank
-    // reduces its own window and the maxima are all-reduced in-stream; a shard
-    // running on its own scans every group itself.
-    Segments GG{};
     {
-      long long ng_tot = 0;
-      for (int b = 0; b < niso; b++) {
-        const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
-        if (gb0 == gb1) continue;
-        int ga = gb0, gz = gb1;
-        if (h->comm) {
-          long long psm = 0;
-          for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
-          const long long lo_f = (long long)h->osamp * h->lo - psm;
-          long long klo = lo_f > 0 ? lo_f / h->osamp : 0;
-          long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp;
-          if (khi > h->nwn - 1) khi = h->nwn - 1;
-          const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
-          ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
-        }
-        if (ga >= gz) continue;
-        // line range of the groups [ga, gz): anchors and members are consecutive lines
-        const long long la = h->h_gfirst[ga], lz = (long long)h->h_gfirst[gz - 1] + h->h_gcount[gz - 1];
-        GG.start[GG.n] = la; GG.base[GG.n] = ng_tot; ng_tot += lz - la; GG.n++;
-      }
-      GG.base[GG.n] = ng_tot;
+      SweepMode M{};
+      M.eager = eager; M.prof = prof; M.ethresh = o->ethresh; M.chunk_index = nchunks;
+      M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
+      M.d_e = h->d_e.as<double>(); M.use_comm = h->comm != nullptr;
+      M.ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
+      M.ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
+      if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, psmax, r_top, nc, nc_max, M, prof ? &ev : nullptr))) return rc;
     }
-    const long long seg_groups = GG.base[GG.n];
-    const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
-    double *ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
     double *ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
-    const double *ggate = h->comm ? ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
-    if (seg_groups > 0) {
-      hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_groups + 255) / 256)), dim3(256), 0, st,
-                         h->L, Y, GG, niso, r_top, nc, h->d_adop.as<double>(), h->ndop, d_wcut,
-                         h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), (unsigned long long *)ar_cur,
-                         h->d_flags.as<int>(), ggate, (int)eager);
-    }
-    if (h->comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
-      if (rccl().AllReduce(ar_cur, ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
-        return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
-    }
-    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    if (h->ngroups > 0) {
-      hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
-                         h->L, Y, niso, r_top, nc, ar_cur, o->ethresh, h->d_adop.as<double>(), h->ndop,
-                         d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)eager);
-    }
-    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    if (h->ngroups > 0) {
-      AccumArgs A{};
-      A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
-      A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
-      A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
-      A.kmaxc = ar_cur; A.ethresh = o->ethresh;
-      A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
-      A.table = h->d_tab.as<float>(); A.e = h->d_e.as<double>();
-      A.part = prof ? h->d_part3.as<unsigned long long>() : nullptr; A.part_stride = (int)tblocks;
-      A.flags = h->d_flags.as<int>(); A.eager = eager;
-      A.last = (!eager && !(dbg && dbg->e)) ? h->d_last.as<int>() : nullptr;
-      // layers whose profiles span >= 64 coarse bins go to the lanes-own-bins kernel
-      unsigned wide_mask = 0;
-      for (int c = 0; c < nc; c++) {
-        long long pm = 0;
-        for (int b = 0; b < niso; b++)
-          if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)(r_top - c) * niso + b]);
-        if ((2 * pm) / h->osamp + 1 >= 64) wide_mask |= 1u << c;
-      }
-      A.skip_mask = wide_mask;
-      if (prof) HIPCHK(h, hipMemsetAsync(h->d_part3.p, 0, 24 * (size_t)nc_max * tblocks, st));
-      if (wide_mask != (nc >= 32 ? 0xffffffffu : ((1u << nc) - 1u)))
-        hipLaunchKernelGGL(k_accumulate, dim3(tblocks, (unsigned)nc), dim3(256), 0, st, A);
-      if (wide_mask) {
-        WideArgs W{}; W.A = A; W.tabT = h->tabT; W.poffT = h->poffT;
-        W.gimod = h->d_gimod.as<int32_t>(); W.gidiv = h->d_gidiv.as<int32_t>(); W.layer_mask = wide_mask;
-        const unsigned wtiles = (unsigned)((nsh + 64 * kWideM - 1) / (64 * kWideM));
-        hipLaunchKernelGGL(k_accumulate_wide, dim3((wtiles + 3) / 4, (unsigned)nc), dim3(256), 0, st, W);
-      }
-    }
-    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    if (prof && h->ngroups > 0) {      // counters (profiling runs only; gated like the sweep itself)
-      for (int k = 0; k < 3; k++)
-        hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
-                           (int)tblocks, 3, k, h->d_counters.as<unsigned long long>(), 3, r_top, h->d_flags.as<int>(), (int)eager);
-    }
     if (nchunks == 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
     {
       TauArgs T{};

@@ -218,7 +218,8 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
                    const double *__restrict__ adop, int ndop,
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                    double *__restrict__ SG, uint8_t *__restrict__ idop8,
-                   unsigned long long *__restrict__ kmaxc_bits,   // [chunk slot] bits of the running maxima
+                   unsigned long long *__restrict__ kmaxc_bits,   // [chunk slot][nmx] bits of the running maxima
+                   int nmx, const int32_t *__restrict__ iso_mx,   // output slots (per-molecule sweeps), else 1/null
                    const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
 {
   if (!sweep_active(flags, ggate, eager)) return;
@@ -266,8 +267,16 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
     if (ok) s = gf * exp(ct * elow) * (1 - exp(ct * wavn));
     s_s[c & 1][threadIdx.x] = s;
     double kbest = inr ? s * f : 0.0;
-    kbest = wave_max(kbest);
-    if (lane == 0) red[wv][c] = kbest;
+    if (nmx == 1) {
+      kbest = wave_max(kbest);
+      if (lane == 0) red[wv][c] = kbest;
+    } else if (kbest > 0) {
+      // per-molecule maxima (extinction.c:406-407, permol): a wave can straddle two
+      // molecules, so each qualifying lane updates its own slot (offline build path)
+      const unsigned long long kb = (unsigned long long)__double_as_longlong(kbest);
+      unsigned long long *slot = &kmaxc_bits[c * nmx + iso_mx[iso]];
+      if (kb > *slot) atomicMax(slot, kb);
+    }
     __syncthreads();
     if (g >= 0) {
       double pk = s;
@@ -290,7 +299,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
     }
   }
   __syncthreads();
-  if (threadIdx.x < nc) {
+  if (nmx == 1 && threadIdx.x < nc) {
     const int c = threadIdx.x;
     const double m = fmax(fmax(red[0][c], red[1][c]), fmax(red[2][c], red[3][c]));
     if (m > 0) atomicMax(&kmaxc_bits[c], (unsigned long long)__double_as_longlong(m));
@@ -307,7 +316,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
 // their strengths exactly as pass 1/2a do.
 __global__ __launch_bounds__(64)
 void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
-                    const double *__restrict__ kmaxc, double ethresh,
+                    const double *__restrict__ kmaxc, int nmx, const int32_t *__restrict__ iso_mx, double ethresh,
                     const double *__restrict__ adop, int ndop,
                     const int *__restrict__ npre,        // [layer][iso] refreshing groups
                     int *__restrict__ sticky_idop,       // [layer][iso]
@@ -318,7 +327,7 @@ void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
   if (c >= nc) return;
   const int r = r_top - c, ri = r * niso + b, lane = threadIdx.x;
   const int gb0 = L.gblock[b];
-  const double ct = Y.negc_over_t[r], lim = ethresh * kmaxc[c], f = Y.strength_f[ri];
+  const double ct = Y.negc_over_t[r], lim = ethresh * kmaxc[nmx == 1 ? c : c * nmx + iso_mx[b]], f = Y.strength_f[ri];
   int found = -1;
   for (int base = npre[ri] - 1; base >= 0 && found < 0; base -= 64) {
     const int k = base - lane;
@@ -379,8 +388,10 @@ struct AccumArgs {
   int r_top, nc, ntiles;
   const double  *SG;                // [chunk][ngroups] group strength before threshold and density
   const uint8_t *idop8;             // [chunk][ngroups]
-  const double  *kmaxc;             // [chunk slot] strongest single line (after the all-reduce, if any)
+  const double  *kmaxc;             // [chunk slot][nmx] strongest single line (after the all-reduce, if any)
   double ethresh;
+  int nmx; const int32_t *iso_mx;   // per-molecule sweeps: output slot of every isotope (else 1 / null)
+  int permol;                       // 1: no density factor, one output row per slot (extinction.c:472, 507)
   const int     *sticky_idop;       // [layer][iso]
   const int32_t *psize;             // [ndop][nlor]
   const long long *poff;            // [ndop][nlor]
@@ -420,14 +431,25 @@ void k_accumulate(AccumArgs A)
 #pragma unroll
   for (int t = 0; t < kTileBins; t++) acc[t] = 0.0;
   long long nb = 0, nev = 0, nsk = 0;
-  const double lim = A.ethresh * A.kmaxc[c];
   // counters: a group is counted by the tile that holds its own coarse bin
   const long long hk0 = j0, hk1 = (j1 == A.nwn - 1) ? (long long)1 << 60 : j1;
+  int cur_mx = -1;                                    // output slot being accumulated
+  auto flush = [&](int mx) {
+#pragma unroll
+    for (int t = 0; t < kTileBins; t++) {
+      const double s = wave_sum(acc[t]);
+      if (lane == 0 && j0 + t <= j1) A.e[((long long)r * A.nmx + mx) * A.nsh + (j0 - A.lo) + t] = s;
+      acc[t] = 0.0;
+    }
+  };
 
   if (live)
   for (int b = 0; b < A.niso; b++) {
     const int gb0 = A.L.gblock[b], gb1 = A.L.gblock[b + 1];
     if (gb0 == gb1) continue;
+    const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
+    if (mx != cur_mx) { if (cur_mx >= 0) flush(cur_mx); cur_mx = mx; }
+    const double lim = A.ethresh * A.kmaxc[c * A.nmx + mx];
     const int ri = r * A.niso + b;
     const int il = A.Y.ilor[ri];
     // profile column of this (layer, isotope): size and offset per Doppler index
@@ -448,7 +470,7 @@ void k_accumulate(AccumArgs A)
     const double  *SGr = A.SG    + (long long)c * A.L.ngroups;
     const uint8_t *idr = A.idop8 + (long long)c * A.L.ngroups;
     __builtin_amdgcn_wave_barrier();
-    const double dens = A.Y.density[ri];
+    const double dens = A.permol ? 1.0 : A.Y.density[ri];
     for (int g = ga + lane; g < gz; g += 64) {
       double sg_k = SGr[g];
       const int iown = A.L.giown[g];
@@ -458,7 +480,7 @@ void k_accumulate(AccumArgs A)
         if (hk >= hk0 && hk <= hk1) { if (below) nsk++; else nev++; }
       }
       if (below) continue;
-      sg_k *= dens;                                        // extinction.c:472-473
+      if (!A.permol) sg_k *= dens;                         // extinction.c:472-473
       int id = idr[g];
       if (id == 0xFF) id = idst;
       const long long ps = s_ps[wv][id];
@@ -472,13 +494,7 @@ void k_accumulate(AccumArgs A)
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (live) {
-#pragma unroll
-    for (int t = 0; t < kTileBins; t++) {
-      const double s = wave_sum(acc[t]);
-      if (lane == 0 && j0 + t <= j1) A.e[(long long)r * A.nsh + (j0 - A.lo) + t] = s;
-    }
-  }
+  if (live && cur_mx >= 0) flush(cur_mx);
   if (A.part) {
     nb = wave_sum_ll(nb); nev = wave_sum_ll(nev); nsk = wave_sum_ll(nsk);
     if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
@@ -545,13 +561,24 @@ void k_accumulate_wide(WideArgs W)
 #pragma unroll
   for (int m = 0; m < kWideM; m++) acc[m] = 0.0;
   long long nb = 0, nev = 0, nsk = 0;
-  const double lim = A.ethresh * A.kmaxc[c];
   const int of = A.osamp;
+  int cur_mx = -1;
+  auto flush = [&](int mx) {
+#pragma unroll
+    for (int m = 0; m < kWideM; m++) {
+      const long long j = j0 + lane + 64 * m;
+      if (j <= j1) A.e[((long long)r * A.nmx + mx) * A.nsh + (j - A.lo)] = acc[m];
+      acc[m] = 0.0;
+    }
+  };
 
   if (live)
   for (int b = 0; b < A.niso; b++) {
     const int gb0 = A.L.gblock[b], gb1 = A.L.gblock[b + 1];
     if (gb0 == gb1) continue;
+    const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
+    if (mx != cur_mx) { if (cur_mx >= 0) flush(cur_mx); cur_mx = mx; }
+    const double lim = A.ethresh * A.kmaxc[c * A.nmx + mx];
     const int ri = r * A.niso + b;
     const int il = A.Y.ilor[ri];
     for (int i = lane; i < A.ndop; i += 64) {
@@ -570,7 +597,7 @@ void k_accumulate_wide(WideArgs W)
     const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
     const double  *SGr = A.SG    + (long long)c * A.L.ngroups;
     const uint8_t *idr = A.idop8 + (long long)c * A.L.ngroups;
-    const double dens = A.Y.density[ri];
+    const double dens = A.permol ? 1.0 : A.Y.density[ri];
     __builtin_amdgcn_wave_barrier();
     for (int gbase = ga; gbase < gz; gbase += 64) {
       const int g = gbase + lane;
@@ -614,13 +641,7 @@ void k_accumulate_wide(WideArgs W)
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (live) {
-#pragma unroll
-    for (int m = 0; m < kWideM; m++) {
-      const long long j = j0 + lane + 64 * m;
-      if (j <= j1) A.e[(long long)r * A.nsh + (j - A.lo)] = acc[m];
-    }
-  }
+  if (live && cur_mx >= 0) flush(cur_mx);
   if (A.part) {
     nb = wave_sum_ll(nb); nev = wave_sum_ll(nev); nsk = wave_sum_ll(nsk);
     if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
