@@ -57,6 +57,18 @@ typedef struct {
   const double *cs;       /* [nwave][ntemp] cm-1 amagat^-nspec                 */
 } trx_cia;
 
+/* Pre-computed opacity grid (reference struct opacity, structures_tr.h:154-171;
+ * file layout opacity.c:405-421): extinction per unit density of each molecule
+ * on (layer, temperature, wavenumber).  When trx_static.ogrid is set, trx_run
+ * interpolates it in temperature (interpolmolext, extinction.c:535-581) instead
+ * of sweeping the line list. */
+typedef struct {
+  int64_t nmol, ntemp, nlayer, nwave;
+  const int32_t *mol_index;  /* [nmol] atmosphere species index of each grid molecule */
+  const double  *temp;       /* [ntemp] K, ascending                                   */
+  const double  *o;          /* [nlayer][ntemp][nmol][nwave] cm2 g-1 ... cm-1 per g cm-3 */
+} trx_opacity_grid;
+
 /* Everything that does not change between spectra
  * (reference: transit_init(), transit.c:25-74). */
 typedef struct {
@@ -110,6 +122,9 @@ typedef struct {
    * a global quantity) is agreed by one small in-stream all-reduce per step. */
   void   *comm;
   int32_t nranks, rank;
+
+  /* optional pre-computed opacity grid (NULL: line-by-line)                   */
+  const trx_opacity_grid *ogrid;
 } trx_static;
 
 /* Per-spectrum atmosphere, already on transit's layer grid, bottom layer first
@@ -205,6 +220,17 @@ int  trx_run    (trx_handle *h, const trx_atm *atm, const trx_opts *opts,
 int  trx_run_device(trx_handle *h, const trx_atm *atm, const trx_opts *opts,
                     void *d_spectrum, trx_debug *dbg);
 void trx_destroy(trx_handle *h);
+
+/* The per-layer operator of the reference in its per-molecule form,
+ *   computemolext(tr, kiso, temp, density, Z, permol = 1)   (extinction.c:282)
+ * batched over nv independent thermodynamic states -- what calcopacity()
+ * (opacity.c:387-403) loops over (layer x temperature) to fill an opacity grid.
+ * iso_slot[i] = output row of isotope i (isotopes of one molecule share a row and
+ * must be contiguous); out is [nv][nslot][wn_hi-wn_lo], extinction per unit
+ * density (no density factor, extinction.c:472), thresholded per molecule. */
+int  trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp /* [nv] */,
+                      const double *density /* [nmol][nv] */, const double *zpart /* [niso][nv] */,
+                      double ethresh, int32_t nslot, const int32_t *iso_slot /* [niso] */, double *out);
 
 int  trx_get_stats(const trx_handle *h, trx_stats *out);
 

@@ -42,6 +42,18 @@ void trh_set_radius(trh_problem *p, double refradius);       /* transit.c:98  */
 void trh_set_cloudtop(trh_problem *p, double cloudtop);      /* transit.c:103 */
 void trh_set_scattering(trh_problem *p, int flag, double logext); /* transit.c:112 */
 
+/* Opacity-grid mode (--opacityfile, reference opacity.c:9-214).
+ * If the file exists it was read by trh_load and trh_static()->ogrid points at it.
+ * If it does not, trh_needs_opacity_build() is 1: ask for the (layer x temperature)
+ * states with trh_grid_request, run them through trx_sweep_permol (the batched
+ * computemolext(permol=1) of calcopacity, opacity.c:387-403) and hand the result to
+ * trh_install_opacity, which writes the file (opacity.c:405-421) and switches the
+ * problem to grid mode -- the reference, too, goes on with the grid it just made. */
+int  trh_needs_opacity_build(const trh_problem *p);
+int  trh_grid_request(const trh_problem *p, int32_t *nv, const double **temp, const double **density,
+                      const double **zpart, int32_t *nslot, const int32_t **iso_slot);
+int  trh_install_opacity(trh_problem *p, const double *o /* [nv][nslot][nwn] */);
+
 /* writers in the reference's formats */
 int  trh_write_spectrum(const trh_problem *p, const double *spectrum, const char *path /* NULL = cfg outspec */);
 int  trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *last, const char *path);

@@ -288,6 +288,7 @@ struct trxo_handle {
   double *iso_mass, *iso_ratio; int32_t *iso_imol;
   double *mol_mass, *mol_radius, *mol_pol; int32_t *mol_is_h2;
   trx_cia *cia;
+  trx_opacity_grid grid;
   /* Voigt table (struct opacity, structures_tr.h:154-171) */
   double *adop, *alor;
   int64_t *psize;          /* [ndop*nlor] half sizes */
@@ -394,6 +395,14 @@ int trxo_create(const trx_static *st, trxo_handle **out)
   h->st.iso_mass = h->iso_mass; h->st.iso_ratio = h->iso_ratio; h->st.iso_imol = h->iso_imol;
   h->st.mol_mass = h->mol_mass; h->st.mol_radius = h->mol_radius; h->st.mol_pol = h->mol_pol;
   h->st.mol_is_h2 = h->mol_is_h2; h->st.cia = h->cia;
+  if (st->ogrid) {
+    const trx_opacity_grid *g = st->ogrid;
+    h->grid = *g;
+    h->grid.mol_index = dupmem(g->mol_index, sizeof(int32_t)*g->nmol);
+    h->grid.temp = dupmem(g->temp, sizeof(double)*g->ntemp);
+    h->grid.o = dupmem(g->o, sizeof(double)*g->nlayer*g->ntemp*g->nmol*g->nwave);
+    h->st.ogrid = &h->grid;
+  }
   int rc = build_table(h);
   if (rc != TRX_OK) { trxo_destroy(h); return rc; }
   *out = h;
@@ -412,6 +421,7 @@ void trxo_destroy(trxo_handle *h)
     }
     free(h->cia);
   }
+  if (h->st.ogrid) { free((void*)h->grid.mol_index); free((void*)h->grid.temp); free((void*)h->grid.o); }
   free(h->adop); free(h->alor); free(h->psize); free(h->poff); free(h->tab);
   free(h);
 }
@@ -444,8 +454,9 @@ int trxo_width_grids(const trxo_handle *h, double *adop, double *alor)
 
 /* transit/src/extinction.c:282-529 (computemolext, permol = 0).
  * kout[0..nwn) receives the molecular extinction of the layer. */
-static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, double temp,
-                             const double *dens /* [nmol] */, const double *zp /* [niso] */)
+static void layer_extinction(trxo_handle *h, double ethresh, double *kout, double temp,
+                             const double *dens /* [nmol] */, const double *zp /* [niso] */,
+                             int nslot, const int32_t *iso_slot /* NULL: collapsed (permol = 0) */)
 {
   const trx_static *s = &h->st;
   const int niso = s->niso, nmol = s->nmol, nl = s->nlor, ofac = s->osamp;
@@ -457,7 +468,8 @@ static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, do
 
   double *alphal = calloc(niso, sizeof(double)), *alphad = calloc(niso, sizeof(double));
   int *idop = calloc(niso, sizeof(int)), *ilor = calloc(niso, sizeof(int));
-  for (int64_t j = 0; j < nwn; j++) kout[j] = 0.0;
+  const int permol = iso_slot != NULL;
+  for (int64_t j = 0; j < nwn * (permol ? nslot : 1); j++) kout[j] = 0.0;
 
   /* widths: extinction.c:364-395 */
   const double fdoppler = sqrt(2*C_KB*temp/C_AMU) * C_SQRTLN2 / C_LS;
@@ -475,8 +487,8 @@ static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, do
     ilor[i] = trxo_nearest(h->alor, alphal[i],     0, s->nlor);
   }
 
-  /* pass 1: strongest line, extinction.c:399-427 (single bucket, permol=0) */
-  double kmax = 0;
+  /* pass 1: strongest line per output slot, extinction.c:399-427 (one bucket when permol=0) */
+  double *kmaxv = calloc(permol ? nslot : 1, sizeof(double));
   int64_t ninr = 0;
   for (int64_t ln = 0; ln < nlines; ln++) {
     const double wavn = 1.0 / (s->wl_um[ln] * TLI_WFCT);
@@ -486,7 +498,8 @@ static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, do
     const double pk = s->iso_ratio[i] * C_SIGCTE * s->gf[ln] *
                       exp(-C_EXPCTE*TLI_EFCT*s->elow[ln]/temp) *
                       (1 - exp(-C_EXPCTE*wavn/temp)) / s->iso_mass[i] / zp[i];
-    if (kmax == 0) kmax = pk; else kmax = fmax(kmax, pk);
+    const int mslot = permol ? iso_slot[i] : 0;
+    if (kmaxv[mslot] == 0) kmaxv[mslot] = pk; else kmaxv[mslot] = fmax(kmaxv[mslot], pk);
   }
   h->stats.nlines_inrange = ninr;
 
@@ -513,8 +526,10 @@ static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, do
       } else break;
     }
     pk *= C_SIGCTE * s->iso_ratio[i] / (s->iso_mass[i] * zp[i]);
-    if (pk < o->ethresh * kmax) { nskip++; continue; }
-    pk *= dens[s->iso_imol[i]];
+    const int mslot = permol ? iso_slot[i] : 0;
+    if (pk < ethresh * kmaxv[mslot]) { nskip++; continue; }
+    if (!permol) pk *= dens[s->iso_imol[i]];
+    double *krow = kout + (size_t)mslot * nwn;
 
     const int idwn = (int)((wavn - wn0) / dwn);
     if (alphad[i]*wavn/alphal[i] >= 1e-1)            /* sticky per isotope :480-483 */
@@ -531,7 +546,7 @@ static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, do
     int bj = (int)(ofac*minj - offset);
     for (long j = minj; j <= maxj; ++j) {
       if (bj > 2*ps) break;
-      if (bj >= 0) { kout[j] += pk * prof[bj]; nbins++; }
+      if (bj >= 0) { krow[j] += pk * prof[bj]; nbins++; }
       bj += ofac;
     }
     neval++;
@@ -540,7 +555,7 @@ static void layer_extinction(trxo_handle *h, const trx_opts *o, double *kout, do
   h->stats.nskip += nskip;
   h->stats.neval += neval;
   h->stats.sum_bins += nbins;
-  free(alphal); free(alphad); free(idop); free(ilor);
+  free(alphal); free(alphad); free(idop); free(ilor); free(kmaxv);
 #undef OWN
 }
 
@@ -796,6 +811,52 @@ static double modulation_rad(const double *tau, long last, double toomuch, const
 }
 
 /* ------------------------------------------------------------------------ */
+/* opacity grid                                                             */
+/* ------------------------------------------------------------------------ */
+
+/* transit/src/opacity.c:387-403 (the loop body of calcopacity): the per-layer
+ * operator in its per-molecule form, for nv independent states. */
+int trxo_sweep_permol(trxo_handle *h, int32_t nv, const double *temp, const double *density,
+                      const double *zpart, double ethresh, int32_t nslot, const int32_t *iso_slot,
+                      double *out)
+{
+  if (!h || nv < 1 || !temp || !density || !zpart || nslot < 1 || !iso_slot || !out) return TRX_E_ARG;
+  const trx_static *s = &h->st;
+  double *dens = malloc(sizeof(double)*s->nmol), *zp = malloc(sizeof(double)*(s->niso > 0 ? s->niso : 1));
+  h->stats.neval = h->stats.nskip = h->stats.sum_bins = 0;
+  for (int v = 0; v < nv; v++) {
+    for (int m = 0; m < s->nmol; m++) dens[m] = density[(size_t)m*nv + v];
+    for (int i = 0; i < s->niso; i++) zp[i]   = zpart[(size_t)i*nv + v];
+    layer_extinction(h, ethresh, out + (size_t)v*nslot*s->nwn, temp[v], dens, zp, nslot, iso_slot);
+  }
+  free(dens); free(zp);
+  return TRX_OK;
+}
+
+/* transit/src/extinction.c:535-581 (interpolmolext): linear in temperature,
+ * times the density of each molecule. */
+static void grid_extinction(const trxo_handle *h, const trx_atm *a, long r, double *kout)
+{
+  const trx_opacity_grid *g = h->st.ogrid;
+  const long nwn = h->st.nwn, nr = a->nlayer, nt = g->ntemp, nm = g->nmol;
+  const double temp = a->temp[r];
+  double *gt = malloc(sizeof(double)*(nt + 1));
+  memcpy(gt, g->temp, sizeof(double)*nt); gt[nt] = HUGE_VAL;     /* searched with hi = Ntemp (:562) */
+  int it = trxo_nearest(gt, temp, 0, (int)nt);
+  if (temp < gt[it]) it--;
+  for (long i = 0; i < nwn; i++) {
+    kout[i] = 0.0;
+    for (long m = 0; m < nm; m++) {
+      const double *olo = g->o + (((size_t)r*nt + it    )*nm + m)*nwn;
+      const double *ohi = g->o + (((size_t)r*nt + it + 1)*nm + m)*nwn;
+      const double ext = (olo[i] * (gt[it+1] - temp) + ohi[i] * (temp - gt[it])) / (gt[it+1] - gt[it]);
+      kout[i] += a->density[(size_t)g->mol_index[m]*nr + r] * ext;
+    }
+  }
+  free(gt);
+}
+
+/* ------------------------------------------------------------------------ */
 /* one spectrum                                                             */
 /* ------------------------------------------------------------------------ */
 
@@ -826,6 +887,12 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
   double *rad = malloc(sizeof(double)*nr);
   memcpy(rad, a->radius, sizeof(double)*nr);
 
+  if (s->ogrid) {
+    const trx_opacity_grid *g = s->ogrid;
+    if (g->nwave != nwn || g->nlayer != nr || g->ntemp < 2) { rc = TRX_E_ARG; goto done; }
+    for (long i = 0; i < nr; i++)
+      if (a->temp[i] < g->temp[0] || !(a->temp[i] < g->temp[g->ntemp-1])) { rc = TRX_E_RANGE; goto done; }
+  }
   if ((rc = cia_extinction(h, a, o, ecs)) != TRX_OK) goto done;
 
   /* heights (eclipse) / impact parameters (transit) from the top down:
@@ -836,7 +903,8 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
 #define SWEEP(L) do { \
     for (int m_ = 0; m_ < nmol; m_++) dens[m_] = a->density[m_*nr + (L)]; \
     for (int i_ = 0; i_ < niso; i_++) zp[i_]   = a->zpart[i_*nr + (L)];   \
-    layer_extinction(h, o, e + (size_t)(L)*nwn, a->temp[(L)], dens, zp);  \
+    if (s->ogrid) grid_extinction(h, a, (L), e + (size_t)(L)*nwn);            \
+    else layer_extinction(h, o->ethresh, e + (size_t)(L)*nwn, a->temp[(L)], dens, zp, 1, NULL); \
     comp[(L)] = 1; } while (0)
 
   if (!comp[nr-1]) SWEEP(nr-1);                            /* tau.c:158-177 */

@@ -52,6 +52,11 @@ CASES = {
     # over all species at once, extinction.c:421-426 with permol = 0)
     "multi_species": dict(wnlow=1000, wnhigh=1100, nlayers=22, solution="eclipse", ethresh=1e-7,
                           toomuch=12.0, dbs="multi"),
+    # opacity-grid mode: the first run builds the grid file (calcopacity), writes it and
+    # computes the spectrum from it (interpolmolext); kept as opacity_ref.dat
+    "opacity_grid": dict(nlines=2500, wnlow=2500, wnhigh=2540, nlayers=16, solution="eclipse", seed=31,
+                         ethresh=1e-6, dbs="multi2",
+                         extra={"opacityfile": "opac.dat", "tlow": "1100", "thigh": "1900", "tempdelt": "200"}),
     "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
                        solution="transit", seed=17, ncia=2),
 }
@@ -82,6 +87,11 @@ def main():
         kw = dict(kw)
         if kw.get("dbs") == "multi":
             kw["dbs"] = multi_species_dbs()
+        if kw.get("dbs") == "multi2":      # two molecules, three isotopes, in the 2500-2540 band
+            kw["dbs"] = [synth.synth_linedb(1500, 2500, 2540, seed=41),
+                         synth.synth_linedb(900, 2500, 2540, seed=42, name="HITEMP CO (synthetic)", molname="CO",
+                                            iso_names=("26",), iso_masses=(27.994915,), iso_ratios=(0.98654,),
+                                            iso_split=(1.0,), z_scale=107.0, log_gf=(-10.0, -4.0))]
         extra = dict(kw.pop("extra", {}))
         extra.update({"savefiles": "yes"})
         synth.make_case(tmp, extra=extra, **kw)
@@ -93,6 +103,8 @@ def main():
         for f in KEEP:
             if os.path.exists(os.path.join(tmp, f)):
                 shutil.copy(os.path.join(tmp, f), os.path.join(d, f))
+        if os.path.exists(os.path.join(tmp, "opac.dat")):
+            shutil.copy(os.path.join(tmp, "opac.dat"), os.path.join(d, "opacity_ref.dat"))
         shutil.rmtree(tmp)
         print("%-16s -> %s" % (name, ", ".join(sorted(os.listdir(d)))))
 

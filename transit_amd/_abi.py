@@ -25,6 +25,11 @@ class TrxCia(C.Structure):
                 ("ntemp", C.c_int32), ("wn", c_double_p), ("temp", c_double_p), ("cs", c_double_p)]
 
 
+class TrxOpacityGrid(C.Structure):
+    _fields_ = [("nmol", C.c_int64), ("ntemp", C.c_int64), ("nlayer", C.c_int64), ("nwave", C.c_int64),
+                ("mol_index", c_int32_p), ("temp", c_double_p), ("o", c_double_p)]
+
+
 class TrxStatic(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("device", C.c_int32),
@@ -41,6 +46,7 @@ class TrxStatic(C.Structure):
         ("mol_pol", c_double_p), ("mol_is_h2", c_int32_p),
         ("ncia", C.c_int32), ("cia", C.POINTER(TrxCia)),
         ("comm", C.c_void_p), ("nranks", C.c_int32), ("rank", C.c_int32),
+        ("ogrid", C.POINTER(TrxOpacityGrid)),
     ]
 
 
@@ -103,4 +109,7 @@ def bind_engine_api(lib, prefix: str = "trx_"):
     f("table_copy").restype = C.c_int
     f("width_grids").argtypes = [C.c_void_p, c_double_p, c_double_p]
     f("width_grids").restype = C.c_int
+    f("sweep_permol").argtypes = [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_double,
+                                  C.c_int32, c_int32_p, c_double_p]
+    f("sweep_permol").restype = C.c_int
     return lib

@@ -73,6 +73,9 @@ struct trx_handle {
   int ws_nr = 0, ws_chunk = 0;
   DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags, d_part2, d_part3;
   DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip, d_acc, d_arbuf;
+  // opacity grid (optional)
+  bool has_grid = false; long og_nmol = 0, og_ntemp = 0, og_nlayer = 0, og_nwave = 0;
+  std::vector<double> og_temp; std::vector<int32_t> og_molidx; DevBuf d_og_o, d_og_layer, d_og_itemp, d_iso_mx, d_pm, d_kmaxpm;
   trx_stats stats{};
   int hint_layers = 0;       // layers the previous run needed (deepest toomuch crossing + 1)
 };
@@ -718,6 +721,17 @@ int trx_create(const trx_static *s, trx_handle **out)
     if (c.ntemp > kMaxCiaTemps) return bail(TRX_E_UNSUPPORTED);
     h->cia.push_back(std::move(t));
   }
+  if (s->ogrid) {
+    const trx_opacity_grid *g = s->ogrid;
+    if (g->nmol < 1 || g->ntemp < 2 || g->nlayer < 1 || g->nwave != s->nwn || !g->o || !g->temp || !g->mol_index) return bail(TRX_E_ARG);
+    for (long m = 0; m < g->nmol; m++) if (g->mol_index[m] < 0 || g->mol_index[m] >= s->nmol) return bail(TRX_E_ARG);
+    h->has_grid = true; h->og_nmol = g->nmol; h->og_ntemp = g->ntemp; h->og_nlayer = g->nlayer; h->og_nwave = g->nwave;
+    h->og_temp.assign(g->temp, g->temp + g->ntemp); h->og_temp.push_back(HUGE_VAL);   // searched with hi = Ntemp (extinction.c:562)
+    h->og_molidx.assign(g->mol_index, g->mol_index + g->nmol);
+    const size_t no = (size_t)g->nlayer * g->ntemp * g->nmol * g->nwave;
+    if ((rc = ensure(h, h->d_og_o, sizeof(double) * no))) return bail(rc);
+    if (hipMemcpy(h->d_og_o.p, g->o, sizeof(double) * no, hipMemcpyHostToDevice) != hipSuccess) return bail(TRX_E_HIP);
+  }
   for (auto &c : h->cia)
     if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs))) return bail(rc);
   if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
@@ -884,6 +898,25 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride, *d_pw = d_mh0 + (nr + 1);
 
+  // ---- opacity grid: temperature bracket and weights per layer (extinction.c:549-574) ----
+  std::vector<double> og_layer; std::vector<int> og_itemp;
+  if (h->has_grid) {
+    if (h->og_nlayer != nr) return fail(h, TRX_E_ARG, "opacity grid has a different number of layers");
+    const int nt = (int)h->og_ntemp, nm = (int)h->og_nmol;
+    og_layer.assign((size_t)(3 + nm) * nr, 0.0); og_itemp.assign(nr, 0);
+    for (int r = 0; r < nr; r++) {
+      const double temp = a->temp[r];
+      if (temp < h->og_temp[0] || !(temp < h->og_temp[nt - 1])) return fail(h, TRX_E_RANGE, "layer temperature outside the opacity grid");
+      int it = nearest_index(h->og_temp.data(), temp, 0, nt);
+      if (temp < h->og_temp[it]) it--;
+      og_itemp[r] = it;
+      og_layer[r] = h->og_temp[it + 1] - temp; og_layer[nr + r] = temp - h->og_temp[it];
+      og_layer[2 * (size_t)nr + r] = h->og_temp[it + 1] - h->og_temp[it];
+      for (int m = 0; m < nm; m++) og_layer[(size_t)(3 + m) * nr + r] = a->density[(size_t)h->og_molidx[m] * nr + r];
+    }
+    if ((rc = upload(h, h->d_og_layer, og_layer)) || (rc = upload(h, h->d_og_itemp, og_itemp))) return rc;
+  }
+
   // ---- CIA extinction (device) ----------------------------------------------------
   {
     // on a second stream: only the first optical-depth kernel needs e_cs, so the
@@ -916,7 +949,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       nc = std::min(nc, r_top + 1);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
-    {
+    if (h->has_grid) {
+      GridArgs Gd{};
+      Gd.o = h->d_og_o.as<double>(); Gd.nt = (int)h->og_ntemp; Gd.nm = (int)h->og_nmol; Gd.nr = nr;
+      Gd.nwave = h->og_nwave; Gd.lo = h->lo; Gd.nsh = nsh; Gd.r_top = r_top; Gd.nc = nc;
+      Gd.itemp = h->d_og_itemp.as<int>();
+      Gd.w_lo = h->d_og_layer.as<double>(); Gd.w_hi = Gd.w_lo + nr; Gd.dg = Gd.w_hi + nr; Gd.dens = Gd.dg + nr;
+      Gd.e = h->d_e.as<double>(); Gd.flags = h->d_flags.as<int>(); Gd.eager = eager;
+      hipLaunchKernelGGL(k_grid_extinction, dim3((unsigned)((nsh + 255) / 256), (unsigned)nc), dim3(256), 0, st, Gd);
+      if (prof) for (int k = 0; k < 3; k++) if (mark()) return fail(h, TRX_E_HIP, "event");
+    } else {
       SweepMode M{};
       M.eager = eager; M.prof = prof; M.ethresh = o->ethresh; M.chunk_index = nchunks;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
@@ -1023,6 +1065,49 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
   if (status_host[0] == 1) return fail(h, TRX_E_NOTREACHED, "optical depth never reached toomuch (modlevel -1)");
   if (status_host[0] == 2) return fail(h, TRX_E_ARG, "fewer than three points for the radial integration");
+  return TRX_OK;
+}
+
+int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double *density, const double *zpart,
+                     double ethresh, int32_t nslot, const int32_t *iso_slot, double *out)
+{
+  if (!h || nv < 1 || !temp || !density || !zpart || !out || nslot < 1 || !iso_slot) return TRX_E_ARG;
+  if (!(ethresh > 0)) return fail(h, TRX_E_ARG, "ethresh must be positive");
+  const int niso = h->niso; const int64_t nsh = h->nsh;
+  for (int i = 0; i < niso; i++) {
+    if (iso_slot[i] < 0 || iso_slot[i] >= nslot) return fail(h, TRX_E_ARG, "isotope slot out of range");
+    if (i > 0 && iso_slot[i] < iso_slot[i-1]) return fail(h, TRX_E_UNSUPPORTED, "isotopes of one molecule must be contiguous");
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  int rc;
+  LayerHost LH;
+  if ((rc = prep_layers(h, nv, temp, density, zpart, 0, LH))) return rc;
+  const int nc_max = 12;
+  const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
+  std::vector<int32_t> slots(iso_slot, iso_slot + std::max(niso, 1));
+  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * nc_max)) || (rc = ensure(h, h->d_idop8, gr_b * nc_max)) ||
+      (rc = ensure(h, h->d_sticky, sizeof(int) * LH.nli)) || (rc = ensure(h, h->d_flags, 64)) ||
+      (rc = ensure(h, h->d_pm, sizeof(double) * (size_t)nv * nslot * nsh)) ||
+      (rc = ensure(h, h->d_kmaxpm, sizeof(double) * (size_t)kMaxChunk * nslot)) ||
+      (rc = upload(h, h->d_layer_f64, LH.f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_iso_mx, slots)))
+    return rc;
+  HIPCHK(h, hipMemsetAsync(h->d_pm.p, 0, sizeof(double) * (size_t)nv * nslot * nsh, st));
+  LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
+  layer_dev(h, LH, nv, Y, d_wcut, d_npre);
+  int nchunks = 0;
+  for (int r_top = nv - 1; r_top >= 0; ) {
+    const int nc = std::min(nc_max, r_top + 1);
+    HIPCHK(h, hipMemsetAsync(h->d_kmaxpm.p, 0, sizeof(double) * (size_t)kMaxChunk * nslot, st));
+    SweepMode M{};
+    M.eager = true; M.ethresh = ethresh; M.chunk_index = nchunks; M.nmx = nslot; M.d_iso_mx = h->d_iso_mx.as<int32_t>();
+    M.permol = true; M.d_e = h->d_pm.as<double>(); M.ar_cur = h->d_kmaxpm.as<double>(); M.ar_prev = nullptr;
+    if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, LH.psmax, r_top, nc, nc_max, M, nullptr))) return rc;
+    r_top -= nc; nchunks++;
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, h->d_pm.p, sizeof(double) * (size_t)nv * nslot * nsh, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
   return TRX_OK;
 }
 

@@ -670,6 +670,39 @@ void k_table_phase_major(const ProfileJob *jobs, const long long *joffT, const f
 }
 
 // ---------------------------------------------------------------------------
+// opacity-grid mode: extinction by temperature interpolation
+// ---------------------------------------------------------------------------
+// extinction.c:535-581 (interpolmolext): e[r][w] = sum_m rho_m(r) * linear-in-T
+// interpolation of the grid o[layer][temp][mol][wn].  One lane per (wn, layer).
+struct GridArgs {
+  const double *o; int nt, nm, nr; long long nwave, lo, nsh;
+  int r_top, nc;
+  const int *itemp;            // [nr] lower temperature node
+  const double *w_lo, *w_hi, *dg;   // [nr] (g1 - T), (T - g0), (g1 - g0)
+  const double *dens;          // [nm][nr] density of each grid molecule
+  double *e;                   // [nr][nsh]
+  const int *flags; int eager;
+};
+
+__global__ __launch_bounds__(256)
+void k_grid_extinction(GridArgs G)
+{
+  if (!G.eager && G.flags[0] == 0) return;
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= G.nsh) return;
+  const int r = G.r_top - (int)blockIdx.y;
+  const int it = G.itemp[r];
+  double acc = 0.0;
+  for (int m = 0; m < G.nm; m++) {
+    const double olo = G.o[(((long long)r * G.nt + it    ) * G.nm + m) * G.nwave + G.lo + w];
+    const double ohi = G.o[(((long long)r * G.nt + it + 1) * G.nm + m) * G.nwave + G.lo + w];
+    const double ext = (olo * G.w_lo[r] + ohi * G.w_hi[r]) / G.dg[r];
+    acc += G.dens[(long long)m * G.nr + r] * ext;
+  }
+  G.e[(long long)r * G.nsh + w] = acc;
+}
+
+// ---------------------------------------------------------------------------
 // CIA / cross-section extinction
 // ---------------------------------------------------------------------------
 // crosssec.c:272-344 (interpcs) + :354-428 (bicubicinterpolate): natural cubic

@@ -134,6 +134,15 @@ struct trh_problem {
   // BART re-entry
   double p0 = 0, r0 = 0, gsurf = 0;
 
+  // opacity grid (struct opacity, structures_tr.h:154-171)
+  bool grid_mode = false, needs_build = false;
+  std::string opa_path;
+  std::vector<double> og_temp, og_press, og_wns, og_o; std::vector<int32_t> og_molid, og_molidx;
+  long og_nmol = 0, og_ntemp = 0, og_nlayer = 0, og_nwave = 0;
+  trx_opacity_grid og_pod{};
+  // build request: nv = nlayer*ntemp states
+  std::vector<double> rq_temp, rq_dens, rq_z; std::vector<int32_t> rq_slot; int rq_nslot = 0;
+
   trx_static st{}; trx_atm atm{}; trx_opts opts{};
   std::string err;
 };
@@ -576,6 +585,97 @@ void hydrostatic_radii(trh_problem &P)
   }
 }
 
+
+// opacity.c:433-503 (readopacity): 4 longs, molID ints, temp/press/wns doubles, o[layer][temp][mol][wn]
+void read_opacity(trh_problem &P, const std::string &path)
+{
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) throw Fail(TRX_E_ARG, "cannot open opacity file '" + path + "'");
+  long dims[4];
+  if (std::fread(dims, sizeof(long), 4, fp) != 4) { std::fclose(fp); throw Fail(TRX_E_ARG, "opacity file truncated"); }
+  P.og_nmol = dims[0]; P.og_ntemp = dims[1]; P.og_nlayer = dims[2]; P.og_nwave = dims[3];
+  if (P.og_nmol < 1 || P.og_ntemp < 2 || P.og_nlayer < 1 || P.og_nwave < 1) { std::fclose(fp); throw Fail(TRX_E_ARG, "bad opacity-file dimensions"); }
+  std::vector<int> ids((size_t)P.og_nmol);
+  P.og_temp.resize((size_t)P.og_ntemp); P.og_press.resize((size_t)P.og_nlayer); P.og_wns.resize((size_t)P.og_nwave);
+  const size_t no = (size_t)P.og_nlayer * P.og_ntemp * P.og_nmol * P.og_nwave;
+  P.og_o.resize(no);
+  bool ok = std::fread(ids.data(), sizeof(int), ids.size(), fp) == ids.size() &&
+            std::fread(P.og_temp.data(), 8, P.og_temp.size(), fp) == P.og_temp.size() &&
+            std::fread(P.og_press.data(), 8, P.og_press.size(), fp) == P.og_press.size() &&
+            std::fread(P.og_wns.data(), 8, P.og_wns.size(), fp) == P.og_wns.size() &&
+            std::fread(P.og_o.data(), 8, no, fp) == no;
+  std::fclose(fp);
+  if (!ok) throw Fail(TRX_E_ARG, "opacity file truncated");
+  P.og_molid.assign(ids.begin(), ids.end());
+}
+
+// makesample.c:613-636 (maketempsample) + opacity.c:297-403: the (layer x temperature) states
+void make_grid_request(trh_problem &P)
+{
+  const double ti = num(P, "tlow"), tf = num(P, "thigh"), td = num(P, "tempdelt");
+  if (tf < ti || td <= 0) throw Fail(TRX_E_ARG, "wrong temperature sampling (tlow, thigh, tempdelt)");
+  const int64_t nt = sample_count(ti, tf, td, 1);
+  P.og_temp.resize((size_t)nt);
+  for (int64_t k = 0; k < nt; k++) P.og_temp[(size_t)k] = ti + (double)k * td;
+  if (P.og_temp.front() < P.tli_tmin) throw Fail(TRX_E_RANGE, "opacity-grid temperature below the TLI range");
+  if (P.og_temp.back() > P.tli_tmax) throw Fail(TRX_E_RANGE, "opacity-grid temperature above the TLI range");
+  const size_t nr = P.rad.size(), nm = P.species.size(), ni = P.iso_mass.size();
+  P.og_ntemp = (long)nt; P.og_nlayer = (long)nr; P.og_nwave = (long)P.nwn;
+  P.og_press.resize(nr);
+  for (size_t r = 0; r < nr; r++) P.og_press[r] = P.p[r] * P.p_fct;
+  P.og_wns.resize((size_t)P.nwn);
+  for (int64_t k = 0; k < P.nwn; k++) P.og_wns[(size_t)k] = P.wn_i + (double)k * P.wn_d;
+  // molecules with line transitions, in isotope order (opacity.c:348-361)
+  P.og_molid.clear(); P.og_molidx.clear(); P.rq_slot.assign(ni, 0);
+  for (size_t i = 0; i < ni; i++) {
+    const int id = P.mol_id[P.iso_imol[i]];
+    int slot = -1;
+    for (size_t k = 0; k < P.og_molid.size(); k++) if (P.og_molid[k] == id) slot = (int)k;
+    if (slot < 0) { slot = (int)P.og_molid.size(); P.og_molid.push_back(id); P.og_molidx.push_back(P.iso_imol[i]); }
+    P.rq_slot[i] = slot;
+  }
+  P.og_nmol = (long)P.og_molid.size(); P.rq_nslot = (int)P.og_molid.size();
+  for (size_t i = 1; i < ni; i++)
+    if (P.rq_slot[i] < P.rq_slot[i-1]) throw Fail(TRX_E_UNSUPPORTED, "isotopes of one molecule must be contiguous in the TLI");
+  // partition function on the grid temperatures (opacity.c:324-339: spline_init + splinterp_pt)
+  std::vector<double> ziso(ni * (size_t)nt);
+  for (size_t i = 0; i < ni; i++) {
+    const std::vector<double> &T = P.dbs[P.iso_db[i]].T;
+    std::vector<double> z(T.size()), u(T.size()), v(T.size());
+    trx::spline_second_derivs(z.data(), T.data(), P.iso_z[i].data(), (long)T.size(), u.data(), v.data());
+    for (int64_t k = 0; k < nt; k++)
+      ziso[i * nt + k] = trx::spline_eval_pt(z.data(), (long)T.size(), T.data(), P.iso_z[i].data(), P.og_temp[(size_t)k]);
+  }
+  const size_t nv = nr * (size_t)nt;
+  P.rq_temp.resize(nv); P.rq_dens.resize(nm * nv); P.rq_z.resize(ni * nv);
+  for (size_t r = 0; r < nr; r++)
+    for (int64_t t = 0; t < nt; t++) {
+      const size_t v = r * nt + t;
+      P.rq_temp[v] = P.og_temp[(size_t)t];
+      for (size_t j = 0; j < nm; j++) {                   // stateeqnford, opacity.c:393-394
+        const double rho = trx::kAmu * P.q[j * nr + r] * P.og_press[r] / trx::kKb / P.og_temp[(size_t)t];
+        P.rq_dens[j * nv + v] = P.by_mass ? rho * P.mm[r] : rho * P.mol_mass[j];
+      }
+      for (size_t i = 0; i < ni; i++) P.rq_z[i * nv + v] = ziso[i * nt + t];
+    }
+}
+
+void set_grid_pod(trh_problem &P)
+{
+  // molecule IDs -> atmosphere species (extinction.c:575)
+  P.og_molidx.assign(P.og_molid.size(), -1);
+  for (size_t k = 0; k < P.og_molid.size(); k++) {
+    for (size_t m = 0; m < P.mol_id.size(); m++) if (P.mol_id[m] == P.og_molid[k]) P.og_molidx[k] = (int32_t)m;
+    if (P.og_molidx[k] < 0) throw Fail(TRX_E_ARG, "opacity-file molecule is not an atmosphere species");
+  }
+  if (P.og_nlayer != (long)P.rad.size() || P.og_nwave != (long)P.nwn)
+    throw Fail(TRX_E_ARG, "opacity file does not match the layer / wavenumber sampling of this run");
+  P.og_pod = trx_opacity_grid{};
+  P.og_pod.nmol = P.og_nmol; P.og_pod.ntemp = P.og_ntemp; P.og_pod.nlayer = P.og_nlayer; P.og_pod.nwave = P.og_nwave;
+  P.og_pod.mol_index = P.og_molidx.data(); P.og_pod.temp = P.og_temp.data(); P.og_pod.o = P.og_o.data();
+  P.grid_mode = true;
+}
+
 void fill_pods(trh_problem &P)
 {
   trx_static &s = P.st;
@@ -602,7 +702,7 @@ void fill_pods(trh_problem &P)
     P.cia_pod.push_back(t);
   }
   s.ncia = (int)P.cia_pod.size(); s.cia = P.cia_pod.data();
-  s.comm = nullptr; s.nranks = 1; s.rank = 0;
+  s.comm = nullptr; s.nranks = 1; s.rank = 0; s.ogrid = P.grid_mode ? &P.og_pod : nullptr;
 
   trx_atm &a = P.atm;
   a = trx_atm{};
@@ -671,14 +771,21 @@ void load(trh_problem &P, int argc, const char *const *argv)
     throw Fail(TRX_E_ARG, "no atmospheric file specified");
   P.allowq = (float)num(P, "allowq");
   read_atmosphere(P, join_path(P.base_dir, str(P, "atm")), join_path(P.base_dir, str(P, "molfile")));
-  if (has(P, "linedb")) read_tli(P, join_path(P.base_dir, str(P, "linedb")));
+  bool have_grid = false;
+  if (has(P, "opacityfile")) {
+    P.opa_path = join_path(P.base_dir, str(P, "opacityfile"));
+    if (FILE *f = std::fopen(P.opa_path.c_str(), "rb")) { std::fclose(f); have_grid = true; }
+  }
+  // the TLI is only read when there is no opacity file yet (readlineinfo.c:584-596)
+  if (has(P, "linedb") && !have_grid) read_tli(P, join_path(P.base_dir, str(P, "linedb")));
   make_layer_sampling(P);
+  if (have_grid) { read_opacity(P, P.opa_path); set_grid_pod(P); }
+  else if (has(P, "opacityfile")) { make_grid_request(P); P.needs_build = true; }
   if (has(P, "csfile")) {
     std::string tok; std::istringstream is(str(P, "csfile"));
     while (std::getline(is, tok, ',')) if (!tok.empty()) read_cia(P, join_path(P.base_dir, tok));
   }
   P.p0 = num(P, "refpress"); P.r0 = num(P, "refradius"); P.gsurf = num(P, "gsurf");
-  if (has(P, "opacityfile")) throw Fail(TRX_E_UNSUPPORTED, "opacity-grid mode is not implemented yet");
   fill_pods(P);
 }
 
@@ -735,6 +842,45 @@ void trh_set_cloudtop(trh_problem *p, double c)
 { if (p) { p->opts.cloud_top = c; p->opts.cloud_bot = c + 10; p->opts.cloud_ext = 100; p->opts.cloud_flag = 1; } }
 void trh_set_scattering(trh_problem *p, int flag, double logext)
 { if (p) { p->opts.scat_flag = flag; p->opts.scat_logext = logext; } }
+
+int trh_needs_opacity_build(const trh_problem *p) { return p && p->needs_build ? 1 : 0; }
+
+int trh_grid_request(const trh_problem *p, int32_t *nv, const double **temp, const double **density,
+                     const double **zpart, int32_t *nslot, const int32_t **iso_slot)
+{
+  if (!p || !p->needs_build) return TRX_E_ARG;
+  if (nv) *nv = (int32_t)p->rq_temp.size();
+  if (temp) *temp = p->rq_temp.data();
+  if (density) *density = p->rq_dens.data();
+  if (zpart) *zpart = p->rq_z.data();
+  if (nslot) *nslot = p->rq_nslot;
+  if (iso_slot) *iso_slot = p->rq_slot.data();
+  return TRX_OK;
+}
+
+int trh_install_opacity(trh_problem *p, const double *o)
+{
+  if (!p || !o || !p->needs_build) return TRX_E_ARG;
+  const size_t no = (size_t)p->og_nlayer * p->og_ntemp * p->og_nmol * p->og_nwave;
+  p->og_o.assign(o, o + no);
+  // opacity.c:405-421
+  FILE *fp = std::fopen(p->opa_path.c_str(), "wb");
+  if (!fp) return TRX_E_ARG;
+  const long dims[4] = {p->og_nmol, p->og_ntemp, p->og_nlayer, p->og_nwave};
+  std::vector<int> ids(p->og_molid.begin(), p->og_molid.end());
+  bool ok = std::fwrite(dims, sizeof(long), 4, fp) == 4 &&
+            std::fwrite(ids.data(), sizeof(int), ids.size(), fp) == ids.size() &&
+            std::fwrite(p->og_temp.data(), 8, p->og_temp.size(), fp) == p->og_temp.size() &&
+            std::fwrite(p->og_press.data(), 8, p->og_press.size(), fp) == p->og_press.size() &&
+            std::fwrite(p->og_wns.data(), 8, p->og_wns.size(), fp) == p->og_wns.size() &&
+            std::fwrite(p->og_o.data(), 8, no, fp) == no;
+  std::fclose(fp);
+  if (!ok) return TRX_E_ARG;
+  try { set_grid_pod(*p); } catch (const Fail &f) { p->err = f.what(); return f.code; }
+  p->needs_build = false;
+  p->st.ogrid = &p->og_pod;
+  return TRX_OK;
+}
 
 const char *trh_option(const trh_problem *p, const char *name)
 {

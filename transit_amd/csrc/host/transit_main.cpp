@@ -30,13 +30,31 @@ int main(int argc, char **argv)
   const int verblevel = verb ? std::atoi(verb) : 2;
   if (verblevel > 3) std::printf("Check point: 00 - 04 inputs read and sampled:  dt = %.4f sec.\n\n", now_s() - t0);
 
-  if (trh_option(P, "justOpacity")) { trh_free(P); return EXIT_SUCCESS; }   // transit.c:133-136
-
   t0 = now_s();
   trx_handle *h = nullptr;
   rc = trx_create(trh_static(P), &h);
   if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: trx_create failed: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE; }
   if (verblevel > 3) std::printf("Check point: 00 - 05 opacity (Voigt table on device, line list resident):  dt = %.4f sec.\n\n", now_s() - t0);
+
+  // --opacityfile names a file that does not exist yet: build the grid on the GPU
+  // (calcopacity, opacity.c:282-427), write it, and go on with it as the reference does
+  if (trh_needs_opacity_build(P)) {
+    t0 = now_s();
+    int32_t nv = 0, nslot = 0; const double *gt, *gd, *gz; const int32_t *gs;
+    trh_grid_request(P, &nv, &gt, &gd, &gz, &nslot, &gs);
+    std::vector<double> grid((size_t)nv * nslot * trh_nwn(P));
+    rc = trx_sweep_permol(h, nv, gt, gd, gz, trh_opts(P)->ethresh, nslot, gs, grid.data());
+    if (rc == TRX_OK) rc = trh_install_opacity(P, grid.data());
+    if (rc != TRX_OK) {
+      std::fprintf(stderr, "transit_hip: opacity-grid build failed: %s (%s)\n", trx_strerror(rc), trx_last_error(h));
+      trx_destroy(h); trh_free(P); return EXIT_FAILURE;
+    }
+    if (verblevel > 3) std::printf("Check point: 00 - 05 opacity grid (%d states x %d molecules):  dt = %.4f sec.\n\n", nv, nslot, now_s() - t0);
+    trx_destroy(h); h = nullptr;
+    rc = trx_create(trh_static(P), &h);          // same problem, now in grid mode
+    if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: trx_create failed: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE; }
+  }
+  if (trh_option(P, "justOpacity")) { trx_destroy(h); trh_free(P); return EXIT_SUCCESS; }   // transit.c:133-136
 
   const int64_t nwn = trh_nwn(P);
   const int nr = trh_atm(P)->nlayer;

@@ -82,6 +82,23 @@ class CEngine:
             raise EngineError(rc, self._p + "run", self._last_error())
         return out
 
+    def sweep_permol(self, nv, temp, density, zpart, ethresh, nslot, iso_slot) -> np.ndarray:
+        """computemolext(permol=1) for nv states: returns o[nv][nslot][nwn]."""
+        out = np.zeros((nv, nslot, self.nwn))
+        rc = self._f("sweep_permol")(self._h, nv, temp, density, zpart, float(ethresh), nslot, iso_slot,
+                                     out.ctypes.data_as(_abi.c_double_p))
+        if rc != 0:
+            raise EngineError(rc, self._p + "sweep_permol", self._last_error())
+        return out
+
+    def build_opacity_grid(self, problem) -> np.ndarray:
+        """calcopacity(): sweep the (layer x temperature) states of `problem`, let the
+        host side write the file and switch the problem to grid mode."""
+        nv, t, d, z, nslot, sl = problem.grid_request()
+        o = self.sweep_permol(nv, t, d, z, problem.opts.ethresh, nslot, sl)
+        problem.install_opacity(o)
+        return o
+
     def stats(self) -> Dict[str, float]:
         s = _abi.TrxStats()
         rc = self._f("get_stats")(self._h, C.byref(s))

@@ -48,6 +48,14 @@ def _load():
         lib.trh_write_spectrum.restype = C.c_int
         lib.trh_write_toomuch.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_int64_p, C.c_char_p]
         lib.trh_write_toomuch.restype = C.c_int
+        lib.trh_needs_opacity_build.argtypes = [C.c_void_p]
+        lib.trh_needs_opacity_build.restype = C.c_int
+        lib.trh_grid_request.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_abi.c_double_p),
+                                         C.POINTER(_abi.c_double_p), C.POINTER(_abi.c_double_p),
+                                         C.POINTER(C.c_int32), C.POINTER(_abi.c_int32_p)]
+        lib.trh_grid_request.restype = C.c_int
+        lib.trh_install_opacity.argtypes = [C.c_void_p, _abi.c_double_p]
+        lib.trh_install_opacity.restype = C.c_int
         lib.trh_option.argtypes = [C.c_void_p, C.c_char_p]
         lib.trh_option.restype = C.c_char_p
         _lib = lib
@@ -152,6 +160,35 @@ class Problem:
             os.chdir(old)
         if rc != 0:
             raise HostError(rc, "write_spectrum failed")
+
+    # -- opacity-grid mode (--opacityfile) -------------------------------------
+    @property
+    def needs_opacity_build(self) -> bool:
+        return bool(_load().trh_needs_opacity_build(self._h))
+
+    def grid_request(self):
+        """The (layer x temperature) states calcopacity() sweeps, as the argument
+        pack of trx_sweep_permol: (nv, temp, density, zpart, nslot, iso_slot)."""
+        nv, nslot = C.c_int32(), C.c_int32()
+        t, d, z = _abi.c_double_p(), _abi.c_double_p(), _abi.c_double_p()
+        sl = _abi.c_int32_p()
+        rc = _load().trh_grid_request(self._h, C.byref(nv), C.byref(t), C.byref(d), C.byref(z),
+                                      C.byref(nslot), C.byref(sl))
+        if rc != 0:
+            raise HostError(rc, "no opacity-grid build is pending")
+        return nv.value, t, d, z, nslot.value, sl
+
+    def install_opacity(self, o: np.ndarray):
+        """Write the grid file (opacity.c:405-421) and switch to grid mode."""
+        o = np.ascontiguousarray(o, dtype=np.float64)
+        old = os.getcwd()
+        try:
+            os.chdir(self.cwd)
+            rc = _load().trh_install_opacity(self._h, o.ctypes.data_as(_abi.c_double_p))
+        finally:
+            os.chdir(old)
+        if rc != 0:
+            raise HostError(rc, "install_opacity failed")
 
     # numpy views of the per-layer arrays (copies)
     def layer_arrays(self):
