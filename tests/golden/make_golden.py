@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 from transit_amd import synth  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "transit")
+REF_REENTRY = os.path.join(ROOT, "oracle", "_ref", "transit_reentry")   # oracle/ref_reentry_main.c
 
 KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "cia_h2he.dat",
         "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat"]
@@ -57,6 +58,17 @@ CASES = {
     "opacity_grid": dict(nlines=2500, wnlow=2500, wnhigh=2540, nlayers=16, solution="eclipse", seed=31,
                          ethresh=1e-6, dbs="multi2",
                          extra={"opacityfile": "opac.dat", "tlow": "1100", "thigh": "1900", "tempdelt": "200"}),
+    # library API re-entry (BART): transit_init once, run_transit(T, abundances) three times
+    # (reloadatm + radpress + makeradsample, readatm.c:722-865); see oracle/ref_reentry_main.c
+    "reentry": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="eclipse", seed=55,
+                    reentry=True, extra={"refpress": "0.1", "gsurf": "1000.0"}),
+    # same in transmission geometry.  Kept with a LOOSE tolerance on purpose: with the
+    # hydrostatic radii of radpress() the reference's impact parameter b = r*fct/fct does not
+    # always round back to r, its bracket search (slantpath.c:36) then lands one layer low
+    # and reads the extinction of a layer its lazy sweep may not have filled yet
+    # (tau.c:238-274) -- a wavenumber-order-dependent 1e-4 effect
+    "reentry_transit": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="transit", seed=55,
+                            reentry=True, extra={"refpress": "0.1", "gsurf": "1000.0"}),
     "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
                        solution="transit", seed=17, ncia=2),
 }
@@ -94,7 +106,32 @@ def main():
                                             iso_split=(1.0,), z_scale=107.0, log_gf=(-10.0, -4.0))]
         extra = dict(kw.pop("extra", {}))
         extra.update({"savefiles": "yes"})
+        reentry = kw.pop("reentry", False)
+        if reentry:
+            import numpy as np
+            atm = synth.demo_atmosphere(kw["nlayers"])
+            k0 = int(np.argmin(np.abs(atm.pressure - 0.1)))
+            extra["refradius"] = "%.3f" % atm.radius[k0]
+            kw["atm"] = atm
         synth.make_case(tmp, extra=extra, **kw)
+        if reentry:
+            nl, nm = len(atm.radius), len(atm.species)
+            runs = []
+            q = atm.abundance.T.copy()                     # [nmol][nlayer]
+            runs.append(np.concatenate([atm.temperature, q.ravel()]))
+            q2 = q.copy(); q2[atm.species.index("CH4")] *= 3.0
+            runs.append(np.concatenate([atm.temperature + 50.0, q2.ravel()]))
+            q3 = q.copy(); q3[atm.species.index("H2O")] *= 0.5
+            t3 = atm.temperature * (1.0 - 0.04 * np.linspace(0, 1, nl))
+            runs.append(np.concatenate([t3, q3.ravel()]))
+            with open(os.path.join(tmp, "reentry_inputs.txt"), "w") as f:
+                for r in runs:
+                    f.write(" ".join("%.17g" % v for v in r) + "\n")
+        if reentry:
+            log = subprocess.run([REF_REENTRY, "case.cfg", "reentry_inputs.txt", "reentry_out"], cwd=tmp,
+                                 capture_output=True, text=True)
+            if log.returncode != 0:
+                sys.exit("reference re-entry driver failed:\n%s\n%s" % (log.stdout[-2000:], log.stderr[-2000:]))
         log = subprocess.run([REF, "-c", "case.cfg"], cwd=tmp, capture_output=True, text=True)
         if log.returncode != 0:
             sys.exit("reference failed on %s:\n%s\n%s" % (name, log.stdout[-2000:], log.stderr[-2000:]))
@@ -102,6 +139,9 @@ def main():
         os.makedirs(d)
         for f in KEEP:
             if os.path.exists(os.path.join(tmp, f)):
+                shutil.copy(os.path.join(tmp, f), os.path.join(d, f))
+        for f in sorted(os.listdir(tmp)):
+            if f.startswith("reentry_"):
                 shutil.copy(os.path.join(tmp, f), os.path.join(d, f))
         if os.path.exists(os.path.join(tmp, "opac.dat")):
             shutil.copy(os.path.join(tmp, "opac.dat"), os.path.join(d, "opacity_ref.dat"))
