@@ -1,0 +1,150 @@
+"""Host side (C++: transit_amd/csrc/host): the reference's CLI/cfg surface, file
+readers and samplings -- everything transit_init() does before the spectrum path."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from cases import GOLDEN, golden
+from transit_amd import synth
+from transit_amd.host import HostError, Problem
+
+CASE = os.path.join(GOLDEN, "eclipse_small")
+
+
+def copy_case(tmp_path, name="eclipse_small"):
+    d = tmp_path / name
+    shutil.copytree(os.path.join(GOLDEN, name), d)
+    return d
+
+
+def test_defaults_match_the_reference_table():
+    """argum.c:112-320 default strings."""
+    P = Problem(["--atm", "case.atm", "--linedb", "case.tli", "--molfile", "molecules.dat",
+                 "--wnlow", "2500", "--wnhigh", "2510", "--wndelt", "1", "--wnfct", "1"], cwd=CASE)
+    assert P.option("toomuch") == "20" and P.opts.toomuch == 20.0
+    assert P.opts.ethresh == 1e-8
+    assert P.static.osamp == 2160 and P.static.ndop == 60 and P.static.nlor == 60
+    assert np.float32(P.static.dmin) == np.float32(1e-3) and np.float32(P.static.lmax) == np.float32(10.0)
+    assert P.static.timesalpha == 20.0
+    assert P.opts.solution == 0 and P.opts.nangles == 5
+    assert P.static.ncia == 0                      # no csfile given
+    assert P.nwn == 11 and P.static.nown == 10 * 2160 + 1
+
+
+def test_cfg_tokens_are_matched_as_prefixes_first_hit_wins(tmp_path):
+    """procopt.c:675: strncmp(name, token, len(token)) in table order."""
+    d = copy_case(tmp_path)
+    cfg = (d / "case.cfg").read_text()
+    assert "ethresh 1e-50" in cfg                  # the demo cfg itself relies on 'ethresh' -> 'ethreshold'
+    import re
+    cfg = cfg.replace("solution eclipse", "sol eclipse")
+    cfg = re.sub(r"toomuch \S+", "toom 7.5", cfg)
+    (d / "case.cfg").write_text(cfg)
+    P = Problem.from_cfg(str(d / "case.cfg"))
+    assert P.opts.ethresh == 1e-50 and P.opts.toomuch == 7.5 and P.opts.solution == 0
+    # 'wn' is a prefix of wnlow, wnhigh, wndelt, wnosamp, wnfct: the first in the table wins
+    (d / "case.cfg").write_text(cfg + "wn 2501\n")
+    assert Problem.from_cfg(str(d / "case.cfg")).static.wn_i == 2501.0
+
+
+def test_command_line_overrides_the_cfg_in_order(tmp_path):
+    d = copy_case(tmp_path)
+    P = Problem(["-c", "case.cfg", "--toomuch", "3", "--solution", "transit"], cwd=str(d))
+    assert P.opts.toomuch == 3.0 and P.opts.solution == 1 and P.opts.nangles == 0
+    P = Problem(["--toomuch", "3", "-c", "case.cfg"], cwd=str(d))     # cfg comes later: it wins
+    assert P.opts.toomuch == 10.0
+
+
+def test_wavelength_limits_give_the_reference_grid(tmp_path):
+    """makesample.c:318-363: wn_i = 1/(wlhigh*wlfct), n = ((1+1e-8) f - i)/d + 1."""
+    d = copy_case(tmp_path)
+    cfg = (d / "case.cfg").read_text()
+    cfg = "\n".join(l for l in cfg.split("\n") if not l.startswith(("wnlow", "wnhigh", "wnfct")))
+    (d / "case.cfg").write_text(cfg + "\nwlhigh 4.0\nwllow 3.90625\n")
+    P = Problem.from_cfg(str(d / "case.cfg"))
+    assert P.static.wn_i == 1.0 / (4.0 * 1e-4)
+    f = 1.0 / (3.90625 * 1e-4)
+    assert P.nwn == int(((1.0 + 1e-8) * f - P.static.wn_i) / 1.0 + 1)
+    assert P.static.nown == (P.nwn - 1) * 2160 + 1
+
+
+def test_errors_are_codes_not_exits(tmp_path):
+    d = copy_case(tmp_path)
+    with pytest.raises(HostError) as e:
+        Problem(["-c", "nosuch.cfg"], cwd=str(d))
+    assert e.value.code == -1
+    with pytest.raises(HostError):
+        Problem(["-c", "case.cfg", "--frobnicate", "1"], cwd=str(d))
+    with pytest.raises(HostError):
+        Problem(["-c", "case.cfg", "--solution", "sideways"], cwd=str(d))
+    with pytest.raises(HostError):
+        Problem(["-c", "case.cfg", "--ethreshold", "0"], cwd=str(d))
+    with pytest.raises(HostError):                       # argum.c:812: nwidth < 1
+        Problem(["-c", "case.cfg", "--nwidth", "0.5"], cwd=str(d))
+    with pytest.raises(HostError) as e:                  # crosssec.c:251-259: CIA must cover the band
+        Problem(["-c", "case.cfg", "--wnhigh", "9000"], cwd=str(d))
+    assert e.value.code in (-1, -5)
+    (d / "molecules.dat").write_text("# empty\n 105 H2 2.01588 2.89 02 0.787 x\n")
+    with pytest.raises(HostError):                       # readatm.c:697-703: unknown species
+        Problem.from_cfg(str(d / "case.cfg"))
+
+
+def test_top_down_atmosphere_is_resorted(tmp_path):
+    """readatm.c:583-617."""
+    d = copy_case(tmp_path)
+    lines = (d / "case.atm").read_text().split("\n")
+    k = next(i for i, l in enumerate(lines) if l.startswith("#Radius")) + 1
+    data = [l for l in lines[k:] if l.strip()]
+    (d / "case.atm").write_text("\n".join(lines[:k] + data[::-1]) + "\n")
+    a = Problem.from_cfg(str(d / "case.cfg")).layer_arrays()
+    b = golden("eclipse_small").problem.layer_arrays()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_mass_abundances_use_the_mean_molecular_mass(tmp_path):
+    """transit.h:58-69 (stateeqnford) and readatm.c:137-146 (checkaddmm)."""
+    d = copy_case(tmp_path)
+    atm = synth.demo_atmosphere(30)
+    masses = {m[1]: m[2] for m in synth.MOLECULE_TABLE}
+    mvec = np.array([masses[s] for s in atm.species])
+    qn = atm.abundance
+    mu = (qn * mvec).sum(axis=1, keepdims=True)
+    atm_m = synth.Atmosphere(atm.species, atm.radius, atm.pressure, atm.temperature,
+                             np.array([[float("%.4e" % v) for v in row] for row in qn * mvec / mu]), by_mass=True)
+    synth.write_atm(str(d / "case.atm"), atm_m)
+    a = Problem.from_cfg(str(d / "case.cfg")).layer_arrays()
+    q = atm_m.abundance
+    mm = 1.0 / (q / mvec).sum(axis=1)
+    p, t = atm.pressure * 1e6, atm.temperature
+    rho = 1.66053886e-24 * q.T * p / 1.380658e-16 / t * mm
+    assert np.max(np.abs(a["density"][:, :-1] / rho[:, :-1] - 1)) < 1e-14     # top layer carries spline round-off
+
+
+def test_tli_range_selection_drops_lines_outside_the_band(tmp_path):
+    """readlineinfo.c:496-526: per-isotope bracket of [1/wn_f, 1/wn_i]."""
+    d = copy_case(tmp_path)
+    P = Problem(["-c", "case.cfg", "--wnlow", "2520", "--wnhigh", "2540"], cwd=str(d))
+    full = golden("eclipse_small").problem.static.nlines
+    n = P.static.nlines
+    assert 0 < n < full
+    wl = np.ctypeslib.as_array(P.static.wl_um, shape=(n,))
+    wn = 1e4 / wl
+    iso = np.ctypeslib.as_array(P.static.isoid, shape=(n,))
+    for b in np.unique(iso):                         # at most one neighbour beyond each end per isotope
+        w = wn[iso == b]
+        assert np.sum(w > 2540) <= 1 and np.sum(w < 2520) <= 1
+        assert np.all(np.diff(w) <= 0)               # wavelength ascending = wavenumber descending
+
+
+def test_multi_database_tli_and_species_mapping():
+    P = golden("multi_species").problem
+    st = P.static
+    assert st.niso == 6
+    imol = np.ctypeslib.as_array(st.iso_imol, shape=(6,))
+    species = synth.DEMO_SPECIES
+    assert [species[i] for i in imol] == ["H2O", "H2O", "H2O", "CH4", "CH4", "CO"]
+    z = P.layer_arrays()["zpart"]
+    assert z.shape == (6, P.nlayer) and np.all(z > 0)
