@@ -203,3 +203,25 @@ def test_bad_arguments_return_codes():
     r = eng.run(P.atm, P.opts)
     assert np.all(np.isfinite(r["spectrum"]))
     eng.close()
+
+
+def test_many_isotopes_against_oracle(tmp_path):
+    """Ten isotopes in two databases (more than the per-layer scalars staged in LDS)."""
+    names = tuple("i%d" % k for k in range(7))
+    db1 = synth.synth_linedb(2100, 2500, 2530, seed=3, name="A", molname="H2O", iso_names=names,
+                             iso_masses=tuple(18.0 + 0.3 * k for k in range(7)),
+                             iso_ratios=tuple(0.5 / (k + 1) for k in range(7)),
+                             iso_split=(0.3, 0.2, 0.15, 0.1, 0.1, 0.1, 0.05), z_scale=170.0)
+    db2 = synth.synth_linedb(900, 2500, 2530, seed=4, name="B", molname="CO2", iso_names=("626", "636", "628"),
+                             iso_masses=(43.98983, 44.993185, 45.994076), iso_ratios=(0.984204, 0.011057, 0.003947),
+                             iso_split=(0.6, 0.3, 0.1), z_scale=286.0)
+    d = str(tmp_path / "iso10")
+    synth.make_case(d, wnlow=2500, wnhigh=2530, nlayers=18, solution="eclipse", ethresh=1e-5, toomuch=9.0,
+                    dbs=[db1, db2])
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    assert P.static.niso == 10
+    got, ref = _both(P.static, P)
+    sw = ref["computed"].astype(bool)
+    assert np.array_equal(got["last"], ref["last"])
+    assert rel_err(got["e"][sw], ref["e"][sw]) < 1e-9
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9

@@ -228,6 +228,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   __shared__ double s_ct[kMaxChunk];
   __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
   __shared__ double s_s[2][256];                         // line strengths of the layer in flight
+  __shared__ double s_k[2][256];                         // per-line candidates for the layer maximum
   for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
   if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
   const int nst = min(niso, kSweepIsoLds);
@@ -268,8 +269,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
     s_s[c & 1][threadIdx.x] = s;
     double kbest = inr ? s * f : 0.0;
     if (nmx == 1) {
-      kbest = wave_max(kbest);
-      if (lane == 0) red[wv][c] = kbest;
+      s_k[c & 1][threadIdx.x] = kbest;                   // reduced by wave 0 after the barrier
     } else if (kbest > 0) {
       // per-molecule maxima (extinction.c:406-407, permol): a wave can straddle two
       // molecules, so each qualifying lane updates its own slot (offline build path)
@@ -278,6 +278,11 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
       if (kb > *slot) atomicMax(slot, kb);
     }
     __syncthreads();
+    if (nmx == 1 && wv == 0) {
+      const double *k = s_k[c & 1];
+      const double m = wave_max(fmax(fmax(k[lane], k[lane + 64]), fmax(k[lane + 128], k[lane + 192])));
+      if (lane == 0) red[0][c] = m;
+    }
     if (g >= 0) {
       double pk = s;
       for (int m = 1; m < in_lds; m++) pk += s_s[c & 1][threadIdx.x + m];
@@ -301,7 +306,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   __syncthreads();
   if (nmx == 1 && threadIdx.x < nc) {
     const int c = threadIdx.x;
-    const double m = fmax(fmax(red[0][c], red[1][c]), fmax(red[2][c], red[3][c]));
+    const double m = red[0][c];
     if (m > 0) atomicMax(&kmaxc_bits[c], (unsigned long long)__double_as_longlong(m));
   }
 }
