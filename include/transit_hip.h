@@ -199,7 +199,7 @@ typedef struct {
   double  ms_k_sweep;      /* sum over launches of k_group_sweep (+ all-reduce)   */
   double  ms_k_sticky;     /* sum over launches of k_sticky_index                */
   double  ms_k_accum;     /* sum over launches of k_accumulate                 */
-  int64_t sweep_launches; /* launches of each sweep kernel that did work       */
+  int64_t sweep_launches; /* launches of each sweep kernel (gated no-op ones too) */
   double  ms_tau;         /* optical-depth kernels                             */
   double  ms_cia;         /* host wall time of the CIA interpolation            */
   double  ms_host_total;  /* host wall time of the whole trx_run call           */

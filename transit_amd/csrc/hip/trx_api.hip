@@ -1036,12 +1036,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   S.ms_k_sweep = S.ms_k_sticky = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
   if (prof) {
-    const int swept_chunks = std::min(nchunks, (int)((S.layers_swept + nc_max - 1) / nc_max));
+    // every launch counts (also the ~4 us gated ones after all rays stopped), so that
+    // sum / launches is the average a kernel trace reports
     for (int c = 0; c < nchunks; c++) {
       float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
       (void)hipEventElapsedTime(&t1, ev[5*c], ev[5*c+1]); (void)hipEventElapsedTime(&t2, ev[5*c+1], ev[5*c+2]);
       (void)hipEventElapsedTime(&t3, ev[5*c+2], ev[5*c+3]); (void)hipEventElapsedTime(&t4, ev[5*c+3], ev[5*c+4]);
-      if (c < swept_chunks) { S.ms_k_sweep += t1; S.ms_k_sticky += t2; S.ms_k_accum += t3; S.sweep_launches++; }
+      S.ms_k_sweep += t1; S.ms_k_sticky += t2; S.ms_k_accum += t3; S.sweep_launches++;
       S.ms_tau += t4;
     }
     S.ms_sweep = S.ms_k_sweep + S.ms_k_sticky + S.ms_k_accum;
