@@ -50,7 +50,7 @@ def parse():
 
 
 def measured_traffic(kernel):
-    """HBM bytes per (active) launch of `kernel` from the committed rocprofv3 PMC
+    """HBM bytes per launch (all launches, like avg_launch_ms) of `kernel` from the committed rocprofv3 PMC
     passes (profiles/*pmc_traffic*.json; FETCH_SIZE/WRITE_SIZE collected in separate
     --pmc runs and corrected as MI355X_MICROARCH.md prescribes).  None when no
     profile of the current kernels is committed."""
@@ -60,7 +60,8 @@ def measured_traffic(kernel):
         return None
     try:
         d = json.load(open(files[-1]))
-        return float(d["kernels"]["trx::" + kernel]["hbm_bytes_per_active_launch"])
+        k = d["kernels"]["trx::" + kernel]
+        return float(k.get("hbm_bytes_per_launch", k.get("hbm_bytes_per_active_launch")))
     except Exception:
         return None
 
