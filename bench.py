@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--wnosamp", type=int, default=2160)
     ap.add_argument("--wndelt", type=float, default=1.0)
     ap.add_argument("--layer-chunk", type=int, default=0)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N>1: weak = every GPU gets its own CH4-demo-sized slice (band and line list grow with N); "
+                         "strong = the one CH4-demo run split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = full workload)")
     return ap.parse_args()
@@ -66,10 +69,12 @@ def measured_traffic(kernel):
         return None
 
 
-def make_workload(args, tag, nlines, verb=2):
+def make_workload(args, tag, nlines, verb=2, wnhigh=None, unique=True):
     from transit_amd import synth
-    d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%d" % (tag, nlines, args.layers, os.getpid()))
-    synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=args.wnhigh, wndelt=args.wndelt, wnosamp=args.wnosamp,
+    d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%s" % (
+        tag, nlines, args.layers, os.getpid() if unique else os.environ.get("MASTER_PORT", "0")))
+    synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=wnhigh or args.wnhigh, wndelt=args.wndelt,
+                    wnosamp=args.wnosamp,
                     nlayers=args.layers, solution="eclipse", toomuch=10.0, ethresh=1e-50, nwidth=20.0,
                     raygrid="0 20 40 60 80", ncia=1, seed=1234, extra={"verb": verb})
     return d
@@ -143,7 +148,20 @@ def main():
     from transit_amd.shard import shard_bounds
     from transit_amd import dist as tdist
 
-    d = make_workload(args, "r%d" % rank, args.lines)
+    # N=1: the CH4-demo run.  N>1, weak: the band and the line list grow N-fold at the
+    # same resolution and line density, so every GPU owns one CH4-demo-sized slice of one
+    # spectrum (2501 bins, ~1e6 lines + halo).  N>1, strong: the N=1 run split N ways.
+    grow = world if args.scaling == "weak" else 1
+    wnhigh = args.wnlow + grow * (args.wnhigh - args.wnlow)
+    if world > 1:       # one copy of the input files, written by rank 0
+        if rank == 0:
+            d = make_workload(args, "w%d" % world, grow * args.lines, wnhigh=wnhigh, unique=False)
+        dist.barrier()
+        if rank != 0:
+            d = os.path.join(tempfile.gettempdir(), "transit_bench_w%d_%d_%d_%s" % (
+                world, grow * args.lines, args.layers, os.environ.get("MASTER_PORT", "0")))
+    else:
+        d = make_workload(args, "r0", args.lines)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
     nwn, nlayer = P.nwn, P.nlayer
     lo, hi = shard_bounds(nwn, world, rank)
@@ -191,7 +209,7 @@ def main():
 
     # one profiled run for the per-kernel event timings and the counters
     opts.profile = 1
-    r = eng.run(P.atm, opts, debug=True)
+    r = eng.run(P.atm, opts, debug=("last",))
     opts.profile = 0
     stats = eng.stats()
     layers_needed = int(r["last"].max()) + 1
@@ -215,16 +233,19 @@ def main():
         alg = {"k_group_sweep": 52.0 * L * R, "k_sticky_index": 0.0,
                "k_accumulate": 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
         ach = alg[dom] / launches / (kern[dom] / launches * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
-        b_alg_run = 52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * nwn + 8.0 * nwn * (1 + nang)
+        # rank 0's share (its lines, bins and slice); x world for the job when N>1
+        b_alg_run = world * (52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * (hi - lo) + 8.0 * (hi - lo) * (1 + nang))
         out = {
             "metric": "wavenumber-points*layers/sec (CH4 2-4um emission spectrum)",
             "value": nwn * layers_needed / (ms_step * 1e-3),
             "unit": "wavenumber-points*layers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]): %g-%g cm-1 @%g cm-1, wnosamp %d, "
-                                   "eclipse, 5 angles, H2-H2 CIA" % (args.wnlow, args.wnhigh, args.wndelt, args.wnosamp),
+            "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]%s): %g-%g cm-1 @%g cm-1, wnosamp %d, "
+                                   "eclipse, 5 angles, H2-H2 CIA" % (
+                                       ", band and line list x%d: one demo-sized slice per GPU" % grow if grow > 1 else "",
+                                       args.wnlow, wnhigh, args.wndelt, args.wnosamp),
                        "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
                        "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
@@ -237,7 +258,8 @@ def main():
                        "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],
                        "ms_host_cia": stats["ms_cia"], "ms_host_total_profiled_run": stats["ms_host_total"],
                        "b_alg_run_bytes": b_alg_run,
-                       "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9},
+                       "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9,
+                       "line_layer_bins_per_s": world * stats["sum_bins"] / (ms_step * 1e-3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else None,

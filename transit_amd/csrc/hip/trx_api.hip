@@ -66,7 +66,7 @@ struct trx_handle {
   std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
   void *comm = nullptr; int nranks = 1, rank = 0;
   // CIA (host copies)
-  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs; DevBuf d_wn, d_temp, d_cs; };
+  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw; };
   std::vector<Cia> cia;
   DevBuf d_cia_ws, d_cia_dens; std::vector<double> h_cia_dens;
   // per-run workspaces (grown on demand)
@@ -331,7 +331,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
   for (int i = 0; i < nr; i++)
     if (a->temp[i] < tmin || a->temp[i] > tmax) return fail(h, TRX_E_RANGE, "layer temperature outside the CIA tables");
   int rc;
-  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 4 * nwmax * (size_t)nr))) return rc;
+  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 3 * nwmax * (size_t)nr))) return rc;
   if ((rc = ensure(h, h->d_cia_dens, sizeof(double) * (size_t)nr * h->cia.size()))) return rc;
   std::vector<double> &dens = h->h_cia_dens;     // member: must outlive the async copy
   dens.resize((size_t)nr * h->cia.size());
@@ -362,10 +362,11 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     while (a->temp[fj] < fx2) fj++;
     for (int j = 0; j < lj; j++) if (a->temp[j] > lx2) lj = j;
     if (fi >= li || fj >= lj) continue;
-    CiaDev C{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>()};
-    double *mid = h->d_cia_ws.as<double>(), *z2 = mid + nwmax * nr, *u = z2 + nwmax * nr, *v = u + nwmax * nr;
-    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)((C.nwave + 63) / 64)), dim3(64), 0, cst, C, nr, d_tlay, fj, lj, mid);
-    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, cst, C, nr, fj, lj, mid, z2, u, v);
+    CiaDev C{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>(),
+             c.d_zt.as<double>(), c.d_uw.as<double>()};
+    double *mid = h->d_cia_ws.as<double>(), *z2 = mid + nwmax * nr, *v = z2 + nwmax * nr;
+    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)C.nwave * nr + 255) / 256)), dim3(256), 0, cst, C, nr, d_tlay, fj, lj, mid);
+    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, cst, C, nr, fj, lj, mid, z2, v);
     hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li - fi + 255) / 256), (unsigned)(lj - fj)), dim3(256), 0, cst,
                        C, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi, li, fj, mid, z2,
                        h->d_cia_dens.as<double>() + n * nr, h->d_ecs.as<double>());
@@ -718,7 +719,18 @@ int trx_create(const trx_static *s, trx_handle **out)
     trx_handle::Cia t; t.nspec = c.nspec; t.mol[0] = c.mol[0]; t.mol[1] = c.mol[1];
     t.wn.assign(c.wn, c.wn + c.nwave); t.temp.assign(c.temp, c.temp + c.ntemp);
     t.cs.assign(c.cs, c.cs + (size_t)c.nwave * c.ntemp);
-    if (c.ntemp > kMaxCiaTemps) return bail(TRX_E_UNSUPPORTED);
+    // table-only halves of the two natural splines (spline_init, pu/src/spline.c:186-206):
+    // second derivatives along T of every row, and the pivots of the wavenumber sweep
+    {
+      const size_t nw = (size_t)c.nwave, nt = (size_t)c.ntemp;
+      std::vector<double> u(std::max(nw, nt)), v(std::max(nw, nt));
+      t.zt.resize(nw * nt);
+      for (size_t i = 0; i < nw; i++)
+        spline_second_derivs(t.zt.data() + i * nt, t.temp.data(), t.cs.data() + i * nt, (long)nt, u.data(), v.data());
+      std::vector<double> zdummy(nw), ydummy(nw, 0.0);
+      t.uw.assign(nw, 0.0);
+      spline_second_derivs(zdummy.data(), t.wn.data(), ydummy.data(), (long)nw, t.uw.data(), v.data());
+    }
     h->cia.push_back(std::move(t));
   }
   if (s->ogrid) {
@@ -733,7 +745,8 @@ int trx_create(const trx_static *s, trx_handle **out)
     if (hipMemcpy(h->d_og_o.p, g->o, sizeof(double) * no, hipMemcpyHostToDevice) != hipSuccess) return bail(TRX_E_HIP);
   }
   for (auto &c : h->cia)
-    if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs))) return bail(rc);
+    if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs)) ||
+        (rc = upload(h, c.d_zt, c.zt)) || (rc = upload(h, c.d_uw, c.uw))) return bail(rc);
   if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
   if ((rc = prepare_lines(h, s)) != TRX_OK) { std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
   *out = h;
@@ -1053,12 +1066,15 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (dbg) {
     if (dbg->e)    HIPCHK(h, hipMemcpy(dbg->e, h->d_e.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
     if (dbg->e_cs) HIPCHK(h, hipMemcpy(dbg->e_cs, h->d_ecs.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-    if (dbg->tau || dbg->last) {
-      std::vector<double> t((size_t)nr * nsh); std::vector<int> l(nsh);
+    if (dbg->tau) {
+      std::vector<double> t((size_t)nr * nsh);
       HIPCHK(h, hipMemcpy(t.data(), h->d_tau.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+      for (int64_t w = 0; w < nsh; w++) for (int i = 0; i < nr; i++) dbg->tau[(size_t)w * nr + i] = t[(size_t)i * nsh + w];
+    }
+    if (dbg->last) {
+      std::vector<int> l(nsh);
       HIPCHK(h, hipMemcpy(l.data(), h->d_last.p, sizeof(int) * nsh, hipMemcpyDeviceToHost));
-      if (dbg->tau) for (int64_t w = 0; w < nsh; w++) for (int i = 0; i < nr; i++) dbg->tau[(size_t)w * nr + i] = t[(size_t)i * nsh + w];
-      if (dbg->last) for (int64_t w = 0; w < nsh; w++) dbg->last[w] = l[w];
+      for (int64_t w = 0; w < nsh; w++) dbg->last[w] = l[w];
     }
     if (dbg->intens && o->solution == TRX_SOL_ECLIPSE)
       HIPCHK(h, hipMemcpy(dbg->intens, h->d_intens.p, sizeof(double) * o->nangles * nsh, hipMemcpyDeviceToHost));

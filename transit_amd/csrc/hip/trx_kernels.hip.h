@@ -713,33 +713,71 @@ void k_grid_extinction(GridArgs G)
 // crosssec.c:272-344 (interpcs) + :354-428 (bicubicinterpolate): natural cubic
 // splines (pu/src/spline.c), first along temperature for every table row, then
 // along wavenumber for every layer; no extrapolation; negative values dropped.
-constexpr int kMaxCiaTemps = 64;
-struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs; };
+// The table-only halves of both splines are computed once at trx_create
+// (zt = second derivatives along T of every table row, uw = the tridiagonal
+// pivots u[] of the wavenumber spline, which depend on the wn grid alone).
+struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs, *zt, *uw; };
 
-// one lane per table row: spline in T, evaluated at the layer temperatures.
+// one lane per (table row, layer): the T spline evaluated at the layer temperature.
 // mid is [nwave][nr] so that the next kernel walks it with unit stride per lane.
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_cia_rows(CiaDev C, int nr, const double *__restrict__ tlay, int fj, int lj,
                 double *__restrict__ mid)
 {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= C.nwave) return;
-  double z[kMaxCiaTemps], u[kMaxCiaTemps], v[kMaxCiaTemps];
-  const double *row = C.cs + (long long)i * C.ntemp;
-  spline_second_derivs(z, C.temp, row, C.ntemp, u, v);
-  for (int j = fj; j < lj; j++)
-    mid[(long long)i * nr + j] = spline_eval_pt(z, C.ntemp, C.temp, row, tlay[j]);
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)C.nwave * nr) return;
+  const int i = (int)(idx / nr), j = (int)(idx - (long long)i * nr);
+  if (j < fj || j >= lj) return;
+  mid[idx] = spline_eval_pt(C.zt + (long long)i * C.ntemp, C.ntemp, C.temp, C.cs + (long long)i * C.ntemp, tlay[j]);
 }
 
-// one lane per layer: second derivatives of the wavenumber spline (sequential
-// tridiagonal sweep over the table rows); z2/u/v are [nwave][nr].
+// one lane per layer: second derivatives of the wavenumber spline -- the
+// sequential tridiagonal sweep of spline_second_derivs (trx_numerics.h) with the
+// pivots read from uw and next step's operands loaded one step ahead, so that a
+// step costs its dependent mul-div-sub chain and not a memory round trip.
+// z2/v are [nwave][nr].
 __global__ __launch_bounds__(64)
 void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ mid,
-                  double *__restrict__ z2, double *__restrict__ u, double *__restrict__ v)
+                  double *__restrict__ z2, double *__restrict__ v)
 {
   const int j = fj + blockIdx.x * 64 + threadIdx.x;
   if (j >= lj) return;
-  spline_second_derivs(z2 + j, C.wn, mid + j, C.nwave, u + j, v + j, nr, 1, nr, nr);
+  const long n = C.nwave;
+  const double *__restrict__ x = C.wn, *__restrict__ uw = C.uw;
+  const double *y = mid + j; double *z = z2 + j, *vv = v + j;
+  double vp = 0;
+  if (n > 2) {
+    const double h0 = x[1] - x[0], h1 = x[2] - x[1];
+    const double b0 = (y[1L*nr] - y[0]) / h0, b1 = (y[2L*nr] - y[1L*nr]) / h1;
+    vp = 6 * (b1 - b0);
+    vv[1L*nr] = vp;
+  }
+  if (n > 3) {
+    double xi = x[2], yi = y[2L*nr];
+    double him = xi - x[1], bim = (yi - y[1L*nr]) / him;
+    double xn = x[3], yn = y[3L*nr], up = uw[1];
+    for (long i = 2; i < n - 1; i++) {
+      const long ip = (i + 2 < n) ? i + 2 : n - 1;          // operands of the next step
+      const double xnn = x[ip], ynn = y[ip*nr], un = uw[i];
+      const double hi = xn - xi, bi = (yn - yi) / hi;
+      const double vn = 6*(bi - bim) - vp*him/up;
+      vv[i*nr] = vn;
+      vp = vn; up = un; him = hi; bim = bi; xi = xn; yi = yn; xn = xnn; yn = ynn;
+    }
+  }
+  z[0] = 0; z[(n-1)*nr] = 0;
+  if (n > 2) {
+    double zn = 0, xn = x[n-1];
+    double xi = x[n-2], vi = vv[(n-2)*nr], ui = uw[n-2];
+    for (long i = n - 2; i > 0; i--) {
+      const long im = (i > 1) ? i - 1 : 1;
+      const double xm = x[im], vm = vv[im*nr], um = uw[im];
+      const double hi = xn - xi;
+      const double zi = (vi - hi*zn) / ui;
+      z[i*nr] = zi;
+      zn = zi; xn = xi; xi = xm; vi = vm; ui = um;
+    }
+  }
 }
 
 // one lane per (wavenumber, layer): evaluate, scale by the density product, add

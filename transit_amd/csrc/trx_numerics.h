@@ -80,22 +80,41 @@ TRX_HD void spline_second_derivs(double *z, const double *x, const double *y, lo
                                  double *u, double *v, long zs = 1, long xs = 1, long ys = 1,
                                  long us = 1)
 {
+  // The recurrences carry u[i-1], v[i-1], z[i+1] and the previous interval in
+  // registers: same operations in the same order as the reference, without a
+  // store->load round trip per step (the arrays may alias as far as the compiler knows).
+  double up = 0, vp = 0;
   if (n > 2) {
     const double h0 = x[1*xs] - x[0], h1 = x[2*xs] - x[1*xs];
     const double b0 = (y[1*ys] - y[0]) / h0, b1 = (y[2*ys] - y[1*ys]) / h1;
-    u[1*us] = 2 * (h1 + h0);
-    v[1*us] = 6 * (b1 - b0);
+    up = 2 * (h1 + h0);
+    vp = 6 * (b1 - b0);
+    u[1*us] = up;
+    v[1*us] = vp;
   }
-  for (long i = 2; i < n - 1; i++) {
-    const double hi  = x[(i+1)*xs] - x[i*xs], him = x[i*xs] - x[(i-1)*xs];
-    const double bi  = (y[(i+1)*ys] - y[i*ys]) / hi, bim = (y[i*ys] - y[(i-1)*ys]) / him;
-    u[i*us] = 2*(hi + him) - him*him/u[(i-1)*us];
-    v[i*us] = 6*(bi - bim) - v[(i-1)*us]*him/u[(i-1)*us];
+  if (n > 3) {
+    double xi = x[2*xs], yi = y[2*ys];
+    double him = xi - x[1*xs], bim = (yi - y[1*ys]) / him;
+    for (long i = 2; i < n - 1; i++) {
+      const double xn = x[(i+1)*xs], yn = y[(i+1)*ys];
+      const double hi = xn - xi, bi = (yn - yi) / hi;
+      const double un = 2*(hi + him) - him*him/up;
+      const double vn = 6*(bi - bim) - vp*him/up;
+      u[i*us] = un;
+      v[i*us] = vn;
+      up = un; vp = vn; him = hi; bim = bi; xi = xn; yi = yn;
+    }
   }
   z[0] = 0; z[(n-1)*zs] = 0;
-  for (long i = n - 2; i > 0; i--) {
-    const double hi = x[(i+1)*xs] - x[i*xs];
-    z[i*zs] = (v[i*us] - hi*z[(i+1)*zs]) / u[i*us];
+  if (n > 2) {
+    double zn = 0, xn = x[(n-1)*xs];
+    for (long i = n - 2; i > 0; i--) {
+      const double xi = x[i*xs];
+      const double hi = xn - xi;
+      const double zi = (v[i*us] - hi*zn) / u[i*us];
+      z[i*zs] = zi;
+      zn = zi; xn = xi;
+    }
   }
 }
 

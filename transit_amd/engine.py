@@ -59,22 +59,24 @@ class CEngine:
     def nwn(self) -> int:
         return self.hi - self.lo if self._p == "trx_" else self.nwn_total
 
-    def run(self, atm: _abi.TrxAtm, opts: _abi.TrxOpts, debug: bool = False,
+    def run(self, atm: _abi.TrxAtm, opts: _abi.TrxOpts, debug=False,
             n_out: Optional[int] = None) -> Dict[str, np.ndarray]:
+        """trx_run.  debug=True also returns every intermediate of trx_debug; a tuple of
+        names ("e", "e_cs", "tau", "last", "intens", "computed") returns just those."""
         n = n_out if n_out is not None else self.nwn
         nl, na = int(atm.nlayer), max(int(opts.nangles), 1)
         out = {"spectrum": np.zeros(n)}
         dbg = None
         if debug:
-            out.update(e=np.zeros((nl, n)), e_cs=np.zeros((nl, n)), tau=np.zeros((n, nl)),
-                       last=np.zeros(n, dtype=np.int64), intens=np.zeros((na, n)),
-                       computed=np.zeros(nl, dtype=np.uint8))
-            dbg = _abi.TrxDebug(out["e"].ctypes.data_as(_abi.c_double_p),
-                                out["e_cs"].ctypes.data_as(_abi.c_double_p),
-                                out["tau"].ctypes.data_as(_abi.c_double_p),
-                                out["last"].ctypes.data_as(_abi.c_int64_p),
-                                out["intens"].ctypes.data_as(_abi.c_double_p),
-                                out["computed"].ctypes.data_as(_abi.c_uint8_p))
+            want = ("e", "e_cs", "tau", "last", "intens", "computed") if debug is True else tuple(debug)
+            make = {"e": lambda: np.zeros((nl, n)), "e_cs": lambda: np.zeros((nl, n)),
+                    "tau": lambda: np.zeros((n, nl)), "last": lambda: np.zeros(n, dtype=np.int64),
+                    "intens": lambda: np.zeros((na, n)), "computed": lambda: np.zeros(nl, dtype=np.uint8)}
+            types = {"last": _abi.c_int64_p, "computed": _abi.c_uint8_p}
+            for k in want:
+                out[k] = make[k]()
+            ptr = lambda k: out[k].ctypes.data_as(types.get(k, _abi.c_double_p)) if k in out else None
+            dbg = _abi.TrxDebug(ptr("e"), ptr("e_cs"), ptr("tau"), ptr("last"), ptr("intens"), ptr("computed"))
         rc = self._f("run")(self._h, C.byref(atm), C.byref(opts),
                             out["spectrum"].ctypes.data_as(_abi.c_double_p),
                             C.byref(dbg) if dbg is not None else None)
