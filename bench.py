@@ -29,6 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_VALU_TFLOPS = 78.6        # MI355X vector fp64 (spec; half the guide's 157.3 TFLOPS vector fp32)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -269,6 +270,16 @@ def main():
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
                          "launches": launches},
         }
+        if dom == "k_accumulate" and ach > HBM_PEAK_GBS:
+            # wide-profile regime (fine grids): neighbouring lines re-read the same profile rows, which
+            # therefore come out of L1/L2 -- the 4 B per accumulated bin never reach HBM and an HBM
+            # fraction would exceed 1.  The kernel is then bound by the fp64 vector pipe
+            # (cvt + mul + add per term; mul/add = 2 flop); peak = MI355X vector fp64 spec.
+            tf = 2.0 * stats["sum_bins"] / (kern[dom] * 1e-3) / 1e12
+            out["roofline"].update(bound="fp64-valu", achieved=tf, peak=FP64_VALU_TFLOPS, unit="TFLOP/s",
+                                   frac=tf / FP64_VALU_TFLOPS, alg_table_GBs_from_cache=ach,
+                                   note="table rows served from L1/L2 (reused by neighbouring lines); "
+                                        "achieved = 2 flop per accumulated bin / launch time")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, full)

@@ -58,7 +58,9 @@ struct trx_handle {
   std::vector<double> adop, alor;                   // +1 sentinel
   std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
   DevBuf d_adop, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
-  const float *tabT = nullptr; const long long *poffT = nullptr;
+  // both tables carry kTabPad zero floats in front and behind: k_accumulate_wide reads whole
+  // 4-float lane segments around a profile row and masks what lies outside the row
+  float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
   DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
@@ -179,7 +181,9 @@ int build_table(trx_handle *h, const trx_static *s)
   HIPCHK(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_voigt_coef), coef, sizeof(coef), 0, hipMemcpyHostToDevice, h->stream));
   DevBuf d_jobs;
   if ((rc = upload(h, d_jobs, jobs))) return rc;
-  if ((rc = ensure(h, h->d_tab, sizeof(float) * (size_t)h->tab_n))) return rc;
+  if ((rc = ensure(h, h->d_tab, sizeof(float) * ((size_t)h->tab_n + 2 * kTabPad)))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->d_tab.p, 0, sizeof(float) * ((size_t)h->tab_n + 2 * kTabPad), h->stream));
+  h->tab = h->d_tab.as<float>() + kTabPad;
   std::vector<int32_t> ps32(h->psize.begin(), h->psize.end());
   if ((rc = upload(h, h->d_psize, ps32))) return rc;
   if ((rc = upload(h, h->d_poff, h->poff))) return rc;
@@ -194,13 +198,13 @@ int build_table(trx_handle *h, const trx_static *s)
     for (int j = 0; j < nj; j++) { maxnv = std::max(maxnv, jobs[j0 + j].nv); any_wave |= (jobs[j0 + j].regime == 2 && jobs[j0 + j].m > m_limit); }
     const int gx = std::max(1, std::min(64, (maxnv + 255) / 256));
     hipLaunchKernelGGL(k_voigt_bins, dim3(gx, nj), dim3(256), 0, h->stream,
-                       d_jobs.as<ProfileJob>() + j0, h->d_tab.as<float>(), m_limit);
+                       d_jobs.as<ProfileJob>() + j0, h->tab, m_limit);
     if (any_wave)
       hipLaunchKernelGGL(k_voigt_bins_wave, dim3(std::max(1, std::min(256, maxnv)), nj), dim3(64), 0, h->stream,
-                         d_jobs.as<ProfileJob>() + j0, h->d_tab.as<float>(), m_limit);
+                         d_jobs.as<ProfileJob>() + j0, h->tab, m_limit);
   }
   // phase-major copy for the wide-profile kernel (identical layout when osamp == 1)
-  if (s->osamp == 1) { h->tabT = h->d_tab.as<float>(); h->poffT = h->d_poff.as<long long>(); }
+  if (s->osamp == 1) { h->tabT = h->tab; h->poffT = h->d_poff.as<long long>(); }
   else {
     std::vector<long long> joffT(jobs.size()), poffT((size_t)s->ndop * s->nlor, 0);
     long long totT = 0;
@@ -216,14 +220,15 @@ int build_table(trx_handle *h, const trx_static *s)
     }
     DevBuf d_joffT;
     if ((rc = upload(h, d_joffT, joffT)) || (rc = upload(h, h->d_poffT, poffT))) return rc;
-    if ((rc = ensure(h, h->d_tabT, sizeof(float) * (size_t)totT))) return rc;
+    if ((rc = ensure(h, h->d_tabT, sizeof(float) * ((size_t)totT + 2 * kTabPad)))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_tabT.p, 0, sizeof(float) * ((size_t)totT + 2 * kTabPad), h->stream));
     for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
       const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
       hipLaunchKernelGGL(k_table_phase_major, dim3(32, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
-                         d_joffT.as<long long>() + j0, h->d_tab.as<float>(), h->d_tabT.as<float>(), s->osamp);
+                         d_joffT.as<long long>() + j0, h->tab, h->d_tabT.as<float>() + kTabPad, s->osamp);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->tabT = h->d_tabT.as<float>(); h->poffT = h->d_poffT.as<long long>();
+    h->tabT = h->d_tabT.as<float>() + kTabPad; h->poffT = h->d_poffT.as<long long>();
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -582,7 +587,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
     A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
     A.kmaxc = M.ar_cur; A.ethresh = M.ethresh; A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol;
     A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
-    A.table = h->d_tab.as<float>(); A.e = M.d_e;
+    A.table = h->tab; A.e = M.d_e;
     A.part = M.prof ? h->d_part3.as<unsigned long long>() : nullptr; A.part_stride = (int)tblocks;
     A.flags = h->d_flags.as<int>(); A.eager = M.eager;
     A.last = M.skip_done ? h->d_last.as<int>() : nullptr;
@@ -782,7 +787,7 @@ int trx_table_copy(const trx_handle *hc, float *out)
   trx_handle *h = const_cast<trx_handle *>(hc);
   if (!h || !out) return TRX_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpy(out, h->d_tab.p, sizeof(float) * (size_t)h->tab_n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out, h->tab, sizeof(float) * (size_t)h->tab_n, hipMemcpyDeviceToHost));
   return TRX_OK;
 }
 
@@ -996,10 +1001,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
       T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = ar_prev;
-      if (o->solution == TRX_SOL_ECLIPSE)
-        hipLaunchKernelGGL(k_optical_depth_vertical, dim3((unsigned)((nsh + 63) / 64)), dim3(64), 0, st, T);
-      else
-        hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)((nsh + kTauW - 1) / kTauW)), dim3(256), 0, st, T);
+      if (o->solution == TRX_SOL_ECLIPSE) {
+        // small shards: one wave per block spreads the (latency-bound) chains over more CUs
+        const int bs = nsh <= 64 * 1024 ? 64 : 256;
+        hipLaunchKernelGGL(k_optical_depth_vertical, dim3((unsigned)std::min<int64_t>((nsh + bs - 1) / bs, kTauMaxBlocks)),
+                           dim3(bs), 0, st, T);
+      } else
+        hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
+                           dim3(256), 0, st, T);
     }
     if (prof && mark()) return fail(h, TRX_E_HIP, "event");
     r_top -= nc; nchunks++;

@@ -515,16 +515,27 @@ void k_accumulate(AccumArgs A)
 // ---------------------------------------------------------------------------
 // When a profile covers >= ~64 coarse bins (Delta_wn << line width: the
 // high-resolution regime, BASELINE configs[4]) the gather above would revisit
-// every group for thousands of 4-bin tiles.  Here a wavefront owns kWideM*64
-// consecutive bins, one accumulator per (lane, m), and walks the groups of its
-// window in line order, 64 at a time through LDS; the group's scalars are
-// wave-uniform (SGPRs), the table read is one coalesced row segment per m.
+// every group for thousands of 4-bin tiles.  Here a wavefront owns 256
+// consecutive bins, four consecutive bins per lane, and walks the groups of its
+// window in line order, 64 at a time:
+//   phase A (one lane per group): threshold test, profile lookup, the group's
+//     valid bin range inside the tile [ta, tb] and the table offset of the tile's
+//     first bin -- all the integer arithmetic of extinction.c:476-501, once per
+//     group; survivors are compacted into LDS in line order;
+//   phase B (lanes = bins): per surviving group ONE 16-byte table load per lane
+//     and four multiply-adds; groups whose profile covers the whole tile (almost
+//     all of them when profiles are much wider than 256 bins) take no masks.
 // Bin j reads profile entry q = osamp*j - iown + ps = osamp*(j + kb) + phase, so
 // the table is kept phase-major ("tabT": [phase][k], k = q / osamp): a fixed
-// group walks ONE row with unit stride instead of striding by osamp floats.
+// group walks ONE row with unit stride instead of striding by osamp floats, and
+// neighbouring groups (sorted by wavenumber) re-read nearly the same row segment
+// out of L1.  Lanes load their four floats unconditionally -- the tables are
+// padded by kTabPad zeros at both ends -- and what lies outside [ta, tb] is masked.
 // Each bin is owned by one lane => plain stores, sums in the reference's own
 // (line) order.
 constexpr int kWideM = 4;
+constexpr int kWideT = 64 * kWideM;
+static_assert(kWideT <= kTabPad, "table padding must cover one wide tile");
 
 struct WideArgs {
   AccumArgs A;
@@ -534,6 +545,28 @@ struct WideArgs {
   unsigned layer_mask;              // bit c set: layer c of the chunk is done here (clear: k_accumulate)
 };
 
+struct alignas(4) WideQuad { float v[4]; };
+
+__device__ __forceinline__ WideQuad wide_load(const float *p)
+{
+  WideQuad q;
+  __builtin_memcpy(&q, p, sizeof(q));      // 4-byte aligned 16-byte load (global_load_dwordx4)
+  return q;
+}
+
+__device__ __forceinline__ void wide_apply(double (&acc)[kWideM], double sg, const WideQuad &q, int tt, int t0)
+{
+  const int ta = tt & 0xFFFF, tb = tt >> 16;
+  if (ta == 0 && tb == kWideT - 1) {                         // wave-uniform: the profile covers the tile
+#pragma unroll
+    for (int m = 0; m < kWideM; m++) acc[m] += sg * (double)q.v[m];
+  } else {
+#pragma unroll
+    for (int m = 0; m < kWideM; m++)
+      if (t0 + m >= ta && t0 + m <= tb) acc[m] += sg * (double)q.v[m];
+  }
+}
+
 __global__ __launch_bounds__(256)
 void k_accumulate_wide(WideArgs W)
 {
@@ -541,25 +574,25 @@ void k_accumulate_wide(WideArgs W)
   if (!A.eager && A.flags[0] == 0) return;
   const int c = blockIdx.y;
   if (!((W.layer_mask >> c) & 1u)) return;
-  __shared__ int32_t   s_ps[4][kMaxDop], s_K[4][kMaxDop];
+  __shared__ int32_t   s_K[4][kMaxDop], s_psd[4][kMaxDop], s_psm[4][kMaxDop], s_r2[4][kMaxDop];
   __shared__ long long s_po[4][kMaxDop];
   __shared__ double    s_sg[4][64];
-  __shared__ int32_t   s_im[4][64], s_id[4][64], s_dop[4][64];
+  __shared__ long long s_off[4][64];
+  __shared__ int32_t   s_tt[4][64];
   __shared__ long long s_nb[4][3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  constexpr int T = 64 * kWideM;
   const int tile = blockIdx.x * 4 + wv;
-  const int ntiles = (int)((A.nsh + T - 1) / T);
+  const int ntiles = (int)((A.nsh + kWideT - 1) / kWideT);
   const int r = A.r_top - c;
   bool live = tile < ntiles;
-  const long long j0 = A.lo + (long long)tile * T;
-  const long long j1 = min(j0 + T, A.lo + A.nsh) - 1;
+  const long long j0 = A.lo + (long long)tile * kWideT;
+  const long long j1 = min(j0 + kWideT, A.lo + A.nsh) - 1;
+  const int jcount = (int)(j1 - j0 + 1);                     // bins of this tile (< kWideT in the last one)
+  const int t0 = kWideM * lane;                              // this lane's first bin, tile-relative
   if (live && A.last) {
     bool open = false;
-    for (int m = 0; m < kWideM; m++) {
-      const long long j = j0 + lane + 64 * m;
-      open |= (j <= j1) && (A.last[j - A.lo] < 0);
-    }
+#pragma unroll
+    for (int m = 0; m < kWideM; m++) open |= (t0 + m < jcount) && (A.last[j0 - A.lo + t0 + m] < 0);
     live = __ballot(open) != 0ull;
   }
   double acc[kWideM];
@@ -569,10 +602,10 @@ void k_accumulate_wide(WideArgs W)
   const int of = A.osamp;
   int cur_mx = -1;
   auto flush = [&](int mx) {
+    double *dst = A.e + ((long long)r * A.nmx + mx) * A.nsh + (j0 - A.lo) + t0;
 #pragma unroll
     for (int m = 0; m < kWideM; m++) {
-      const long long j = j0 + lane + 64 * m;
-      if (j <= j1) A.e[((long long)r * A.nmx + mx) * A.nsh + (j - A.lo)] = acc[m];
+      if (t0 + m < jcount) dst[m] = acc[m];
       acc[m] = 0.0;
     }
   };
@@ -586,10 +619,13 @@ void k_accumulate_wide(WideArgs W)
     const double lim = A.ethresh * A.kmaxc[c * A.nmx + mx];
     const int ri = r * A.niso + b;
     const int il = A.Y.ilor[ri];
+    __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < A.ndop; i += 64) {
       const int ps = A.psize[i * A.nlor + il];
-      s_ps[wv][i] = ps;
       s_K [wv][i] = (2 * ps) / of + 1;
+      s_r2[wv][i] = (2 * ps) % of;
+      s_psd[wv][i] = ps / of;
+      s_psm[wv][i] = ps % of;
       s_po[wv][i] = W.poffT[i * A.nlor + il];
     }
     const int idst = A.sticky_idop[ri];
@@ -605,43 +641,60 @@ void k_accumulate_wide(WideArgs W)
     const double dens = A.permol ? 1.0 : A.Y.density[ri];
     __builtin_amdgcn_wave_barrier();
     for (int gbase = ga; gbase < gz; gbase += 64) {
+      // ---- phase A: one lane per group
       const int g = gbase + lane;
+      bool keep = false;
+      double sg = 0; long long off = 0; int tt = 0;
       if (g < gz) {
-        s_sg[wv][lane] = SGr[g];
-        s_im[wv][lane] = W.gimod[g];
-        s_id[wv][lane] = W.gidiv[g];
-        int id = idr[g];
-        s_dop[wv][lane] = (id == 0xFF) ? idst : id;
+        const double sg0 = SGr[g];
+        const int im = W.gimod[g], idv = W.gidiv[g];
+        const bool below = sg0 < lim;                        // extinction.c:467
+        if (A.part && idv >= j0 && idv <= j1) { if (below) nsk++; else nev++; }
+        if (!below) {
+          int id = idr[g];
+          if (id == 0xFF) id = idst;
+          const int K = s_K[wv][id];
+          // q = of*j - iown + ps = of*(j + kb) + ph with 0 <= ph < of
+          int ph = s_psm[wv][id] - im, kb = s_psd[wv][id] - idv;
+          if (ph < 0) { ph += of; kb -= 1; }
+          // valid k = j + kb: 0 <= k and of*k + ph <= 2*ps
+          const int kv = (ph <= s_r2[wv][id]) ? K - 1 : K - 2;
+          const long long kk0 = j0 + kb;                     // k of the tile's first bin
+          const long long ta = kk0 < 0 ? -kk0 : 0;
+          long long tb = (long long)kv - kk0;
+          if (tb > jcount - 1) tb = jcount - 1;
+          if (ta <= tb) {
+            keep = true;
+            sg = sg0 * dens;                                 // extinction.c:472-473
+            off = s_po[wv][id] + (long long)ph * K + kk0;
+            tt = (int)ta | ((int)tb << 16);
+            nb += tb - ta + 1;
+          }
+        }
+      }
+      const unsigned long long km = __ballot(keep);
+      const int n = __popcll(km);
+      if (keep) {
+        const int pos = __popcll(km & ((1ull << lane) - 1ull));
+        s_sg[wv][pos] = sg; s_off[wv][pos] = off; s_tt[wv][pos] = tt;
       }
       __builtin_amdgcn_wave_barrier();
-      const int cnt = min(64, gz - gbase);
-      for (int i = 0; i < cnt; i++) {
-        // wave-uniform group scalars -> SGPRs
-        const double sg0 = __longlong_as_double(
-            ((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(s_sg[wv][i]) >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(s_sg[wv][i])));
-        const int im  = __builtin_amdgcn_readfirstlane(s_im[wv][i]);
-        const int idv = __builtin_amdgcn_readfirstlane(s_id[wv][i]);
-        const int id  = __builtin_amdgcn_readfirstlane(s_dop[wv][i]);
-        const bool below = sg0 < lim;                        // extinction.c:467
-        if (A.part && idv >= j0 && idv <= j1 && lane == 0) { if (below) nsk++; else nev++; }
-        if (below) continue;
-        const double sg = sg0 * dens;
-        const int ps = __builtin_amdgcn_readfirstlane(s_ps[wv][id]);
-        const int K  = __builtin_amdgcn_readfirstlane(s_K[wv][id]);
-        const long long po = s_po[wv][id];
-        // q = of*j - iown + ps = of*(j + kb) + ph with 0 <= ph < of
-        const int psm_ = ps % of, psd_ = ps / of;
-        int ph = psm_ - im, kb = psd_ - idv;
-        if (ph < 0) { ph += of; kb -= 1; }
-        const int qrem = (2 * ps) - ph;                      // valid iff of*k <= qrem
-        const float *row = W.tabT + po + (long long)ph * K;
-#pragma unroll
-        for (int m = 0; m < kWideM; m++) {
-          const long long j = j0 + lane + 64 * m;
-          const long long k = j + kb;
-          if (j <= j1 && k >= 0 && k < K && (long long)of * k <= qrem) { acc[m] += sg * (double)row[k]; nb++; }
-        }
+      // ---- phase B: lanes = bins, groups in line order, four table loads in flight
+      const float *base = W.tabT + t0;
+      int i = 0;
+      for (; i + 4 <= n; i += 4) {
+        const WideQuad q0 = wide_load(base + s_off[wv][i]);
+        const WideQuad q1 = wide_load(base + s_off[wv][i + 1]);
+        const WideQuad q2 = wide_load(base + s_off[wv][i + 2]);
+        const WideQuad q3 = wide_load(base + s_off[wv][i + 3]);
+        wide_apply(acc, s_sg[wv][i],     q0, s_tt[wv][i],     t0);
+        wide_apply(acc, s_sg[wv][i + 1], q1, s_tt[wv][i + 1], t0);
+        wide_apply(acc, s_sg[wv][i + 2], q2, s_tt[wv][i + 2], t0);
+        wide_apply(acc, s_sg[wv][i + 3], q3, s_tt[wv][i + 3], t0);
+      }
+      for (; i < n; i++) {
+        const WideQuad q0 = wide_load(base + s_off[wv][i]);
+        wide_apply(acc, s_sg[wv][i], q0, s_tt[wv][i], t0);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -866,6 +919,40 @@ __device__ __forceinline__ void tau_idle(const TauArgs &T)
   if (blockIdx.x == 0 && threadIdx.x <= kMaxChunk) T.next_ar[threadIdx.x] = 0.0;
 }
 
+// End of an optical-depth launch: every block adds its number of rays that are still
+// descending and its deepest stopping height ONCE (blocks loop over tiles, so the
+// same-address atomics stay in the low thousands at any grid size); the last block to
+// arrive publishes the total for the gating of the next step's kernels.
+constexpr int kTauMaxBlocks = 2048;
+
+__device__ __forceinline__ void tau_publish(const TauArgs &T, int nstill, int deep)
+{
+  __shared__ int s_still[4], s_deep[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+  nstill = (int)wave_sum_ll(nstill);
+  deep = wave_max_i(deep);
+  if (lane == 0) { s_still[wv] = nstill; s_deep[wv] = deep; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int st = 0, dp = 0;
+    for (int k = 0; k < nwv; k++) { st += s_still[k]; dp = max(dp, s_deep[k]); }
+    if (st) atomicAdd(&T.flags[1], st);
+    if (dp > T.flags[4]) atomicMax(&T.flags[4], dp);
+    __threadfence();
+    const int ticket = atomicAdd(&T.flags[3], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      __threadfence();
+      const int act = atomicAdd(&T.flags[1], 0);
+      T.flags[2] += T.nc;                                // layers swept so far
+      T.flags[1] = 0; T.flags[3] = 0;
+      for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
+      T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
+      __threadfence();
+      atomicExch(&T.flags[0], act);
+    }
+  }
+}
+
 // Heights are visited top-down, a chunk of layers per launch (tau.c:235-290).
 // A 256-thread block owns 256/kTauH wavenumbers x kTauH heights:
 //   phase 1 (one lane per wavenumber): total extinction of the chunk's layers
@@ -887,9 +974,12 @@ void k_optical_depth(TauArgs T)
   __shared__ double s_tv[kTauH][kTauW];
   __shared__ int s_alive[kTauW];
   const int wi = threadIdx.x % kTauW, hc = threadIdx.x / kTauW;
-  const long long w = (long long)blockIdx.x * kTauW + wi;
-  const bool ok = w < T.nsh;
   const int nr = T.nr;
+  const long long ntiles = (T.nsh + kTauW - 1) / kTauW;
+  int nstill = 0, deep = 0;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const long long w = tile * kTauW + wi;
+  const bool ok = w < T.nsh;
 
   if (hc == 0) {
     const bool alive = ok && T.last[w] < 0;
@@ -954,38 +1044,20 @@ void k_optical_depth(TauArgs T)
   }
   __syncthreads();
 
-  bool still = false;
   if (hc == 0 && s_alive[wi]) {
-    still = true;
+    bool still = true;
     for (int c = 0; c < T.nc; c++) {
       const int ri = nr - 1 - (T.r_top - c);
       const double tv = s_tv[c][wi];
       T.tau[(long long)ri * T.nsh + w] = tv;
       if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
     }
+    nstill += still;
   }
-  const unsigned long long m = __ballot(still);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&T.flags[1], __popcll(m));
-  {
-    const int deep = wave_max_i((hc == 0 && ok && T.last[ok ? w : 0] >= 0) ? T.last[w] + 1 : 0);
-    if ((threadIdx.x & 63) == 0 && deep > T.flags[4]) atomicMax(&T.flags[4], deep);
+  if (hc == 0 && ok && T.last[w] >= 0) deep = max(deep, T.last[w] + 1);
+  __syncthreads();                                       // s_y0/s_tv/s_alive are reused by the next tile
   }
-  // the last block to arrive publishes the number of rays still descending
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const int ticket = atomicAdd(&T.flags[3], 1);
-    if (ticket == (int)gridDim.x - 1) {
-      __threadfence();
-      const int act = atomicAdd(&T.flags[1], 0);
-      T.flags[2] += T.nc;                                // layers swept so far
-      T.flags[1] = 0; T.flags[3] = 0;
-      for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
-      T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
-      __threadfence();
-      atomicExch(&T.flags[0], act);
-    }
-  }
+  tau_publish(T, nstill, deep);
 }
 
 // Vertical rays (eclipse geometry, eclipse.c:29-105) in O(1) per height.
@@ -1000,15 +1072,15 @@ void k_optical_depth(TauArgs T)
 // which is the reference's sum re-associated (top-down instead of bottom-up) with
 // interval lengths taken as rad[k+1]-rad[k] rather than differences of their running
 // sum: ~1e-15 relative.  One lane per wavenumber walks the chunk's layers.
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_optical_depth_vertical(TauArgs T)
 {
   if (!T.eager && T.flags[0] == 0) { tau_idle(T); return; }
-  const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
   const int nr = T.nr;
-  bool still = false;
-  if (w < T.nsh && T.last[w] < 0) {
-    still = true;
+  int nstill = 0, deep = 0;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
+  if (T.last[w] < 0) {
+    bool still = true;
     const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
     double a1 = T.acc[w], a2 = T.acc[T.nsh + w];          // A(rs+1), A(rs+2) on entry of a step
     // y1, y2: (edited) extinction of the two layers above the current bottom
@@ -1043,27 +1115,11 @@ void k_optical_depth_vertical(TauArgs T)
       if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
     }
     T.acc[w] = a1; T.acc[T.nsh + w] = a2;
+    nstill += still;
   }
-  const unsigned long long m = __ballot(still);
-  if (threadIdx.x == 0 && m) atomicAdd(&T.flags[1], __popcll(m));
-  {
-    const int deep = wave_max_i((w < T.nsh && T.last[w < T.nsh ? w : 0] >= 0) ? T.last[w] + 1 : 0);
-    if (threadIdx.x == 0 && deep > T.flags[4]) atomicMax(&T.flags[4], deep);
+  if (T.last[w] >= 0) deep = max(deep, T.last[w] + 1);
   }
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const int ticket = atomicAdd(&T.flags[3], 1);
-    if (ticket == (int)gridDim.x - 1) {
-      __threadfence();
-      const int act = atomicAdd(&T.flags[1], 0);
-      T.flags[2] += T.nc;
-      T.flags[1] = 0; T.flags[3] = 0;
-      for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
-      T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
-      __threadfence();
-      atomicExch(&T.flags[0], act);
-    }
-  }
+  tau_publish(T, nstill, deep);
 }
 
 // ---------------------------------------------------------------------------
