@@ -57,7 +57,7 @@ struct trx_handle {
   int ndop = 0, nlor = 0;
   std::vector<double> adop, alor;                   // +1 sentinel
   std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
-  DevBuf d_adop, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
+  DevBuf d_adop, d_dopthr, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
   // both tables carry kTabPad zero floats in front and behind: k_accumulate_wide reads whole
   // 4-float lane segments around a profile row and masks what lies outside the row
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
@@ -188,6 +188,28 @@ int build_table(trx_handle *h, const trx_static *s)
   if ((rc = upload(h, h->d_psize, ps32))) return rc;
   if ((rc = upload(h, h->d_poff, h->poff))) return rc;
   if ((rc = upload(h, h->d_adop, h->adop))) return rc;
+  {
+    // exact steps of the nearest-index function on the Doppler grid (index_from in the
+    // kernels): thr[k] = smallest double v with nearest_index(adop, v, 0, ndop) >= k,
+    // found by bisection on the bit patterns of the (positive) doubles
+    const int nd = s->ndop;
+    std::vector<double> thr((size_t)nd + 1);
+    thr[0] = -HUGE_VAL; thr[nd] = HUGE_VAL;
+    auto idx = [&](double v) { return nearest_index(h->adop.data(), v, 0, nd); };
+    for (int k = 1; k < nd; k++) {
+      uint64_t a, b; double x;
+      std::memcpy(&a, &h->adop[k - 1], 8); std::memcpy(&b, &h->adop[k], 8);      // idx(a) < k <= idx(b)
+      while (b - a > 1) {
+        const uint64_t m = a + (b - a) / 2;
+        std::memcpy(&x, &m, 8);
+        if (idx(x) >= k) b = m; else a = m;
+      }
+      std::memcpy(&thr[k], &b, 8);
+      if (idx(thr[k]) != k || idx(std::nextafter(thr[k], 0.0)) != k - 1)
+        return fail(h, TRX_E_ARG, "Doppler-width grid is not strictly increasing");
+    }
+    if ((rc = upload(h, h->d_dopthr, thr))) return rc;
+  }
   hipEvent_t e0, e1;
   HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
   HIPCHK(h, hipEventRecord(e0, h->stream));
@@ -565,7 +587,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   const double *ggate = M.use_comm ? M.ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
   if (seg_lines > 0) {
     hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
-                       h->L, Y, GG, niso, r_top, nc, h->d_adop.as<double>(), h->ndop, d_wcut,
+                       h->L, Y, GG, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, d_wcut,
                        h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), (unsigned long long *)M.ar_cur,
                        M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
   }

@@ -31,11 +31,27 @@ __device__ __forceinline__ double wave_sum(double v)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Wave maximum of non-negative doubles without LDS traffic: rotate-and-max inside
+// the four rows of 16 lanes (DPP row_ror 1,2,4,8 leaves every lane with its row's
+// maximum), then the four row results through SGPRs.  Result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dpp_f64<0x121>(v));      // row_ror:1
+  v = fmax(v, dpp_f64<0x122>(v));      // row_ror:2
+  v = fmax(v, dpp_f64<0x124>(v));      // row_ror:4
+  v = fmax(v, dpp_f64<0x128>(v));      // row_ror:8
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i(int v)
 {
@@ -197,15 +213,16 @@ void k_voigt_bins_wave(const ProfileJob *jobs, float *table, int m_limit)
 // and per layer the maximum single-line strength (wave max -> one 64-bit
 // atomicMax per block).  The threshold test against ethresh*kmax (:467) needs
 // the finished maximum, so it is applied where SG is consumed (k_accumulate).
-// nearest_index() continued from a previous answer: same result as the bisection
-// of pu/src/iomisc.c:1088-1108 on a strictly increasing grid with a +inf sentinel
-// at a[n] (bracket a[lo] <= v < a[lo+1], then the nearer of the two, ties to lo),
-// but the bracket is walked from `lo`, which is 0-1 steps from layer to layer.
-__device__ __forceinline__ int nearest_from(const double *a, int n, double v, int lo)
+// The nearest Doppler-width index of pu/src/iomisc.c:1088-1108 (nearest_index in
+// trx_numerics.h) is a monotone step function of the width; trx_create finds its
+// steps exactly (thr[k] = smallest double whose index is >= k, thr[0] = -inf,
+// thr[n] = +inf), so that index(v) = the k with thr[k] <= v < thr[k+1].  Walked from
+// the previous layer's answer: two compares in the common case.
+__device__ __forceinline__ int index_from(const double *thr, double v, int lo)
 {
-  while (lo + 1 < n && v >= a[lo + 1]) lo++;
-  while (lo > 0 && v < a[lo]) lo--;
-  return (fabs(a[lo + 1] - v) < fabs(a[lo] - v)) ? lo + 1 : lo;
+  while (v >= thr[lo + 1]) lo++;
+  while (v < thr[lo]) lo--;
+  return lo;
 }
 
 constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are staged in LDS
@@ -215,7 +232,7 @@ constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are
 // LDS.  G walks line ranges (contiguous per isotope block).
 __global__ __launch_bounds__(256)
 void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
-                   const double *__restrict__ adop, int ndop,
+                   const double *__restrict__ dthr, int ndop,   // steps of the Doppler index, [ndop + 1]
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                    double *__restrict__ SG, uint8_t *__restrict__ idop8,
                    unsigned long long *__restrict__ kmaxc_bits,   // [chunk slot][nmx] bits of the running maxima
@@ -223,13 +240,13 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
                    const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
 {
   if (!sweep_active(flags, ggate, eager)) return;
-  __shared__ double s_adop[kMaxDop + 1];
+  __shared__ double s_thr[kMaxDop + 1];
   __shared__ double red[4][kMaxChunk];
   __shared__ double s_ct[kMaxChunk];
   __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
   __shared__ double s_s[2][256];                         // line strengths of the layer in flight
   __shared__ double s_k[2][256];                         // per-line candidates for the layer maximum
-  for (int i = threadIdx.x; i <= ndop; i += 256) s_adop[i] = adop[i];
+  for (int i = threadIdx.x; i <= ndop; i += 256) s_thr[i] = dthr[i];
   if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
   const int nst = min(niso, kSweepIsoLds);
   for (int i = threadIdx.x; i < nc * nst; i += 256) {
@@ -256,14 +273,17 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   int in_lds = cnt;
   if (g >= 0 && (int)threadIdx.x + cnt > 256) in_lds = 256 - (int)threadIdx.x;
   (void)ln_next_block;
+  const bool all_staged = niso <= kSweepIsoLds;             // kernel-uniform: plain LDS reads below
   const bool staged = iso < kSweepIsoLds;
-  int lo = 0;                                               // Doppler-grid bracket carried across layers
+  int lo = 0;                                               // Doppler index carried across layers
   __syncthreads();
   for (int c = 0; c < nc; c++) {
     const int r = r_top - c;
     const double ct = s_ct[c];
     const int ri = r * niso + iso;
-    const double f = staged ? s_f[c][iso] : (ok ? Y.strength_f[ri] : 0.0);
+    double f;
+    if (all_staged) f = s_f[c][iso];
+    else f = staged ? s_f[c][iso] : (ok ? Y.strength_f[ri] : 0.0);
     double s = 0;
     if (ok) s = gf * exp(ct * elow) * (1 - exp(ct * wavn));
     s_s[c & 1][threadIdx.x] = s;
@@ -291,13 +311,13 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
         pk += L.gf[lm] * exp(ct * L.elow[lm]) * (1 - exp(ct * L.wavn[lm]));
       }
       pk *= f;
-      const double wc = staged ? s_wc[c][iso] : wcut[ri];
+      double wc, ad;
+      if (all_staged) { wc = s_wc[c][iso]; ad = s_ad[c][iso]; }
+      else { wc = staged ? s_wc[c][iso] : wcut[ri]; ad = staged ? s_ad[c][iso] : Y.alphad[ri]; }
       uint8_t id = 0xFF;
       if (wavn >= wc) {
-        const double v = (staged ? s_ad[c][iso] : Y.alphad[ri]) * wavn;
-        const int k = nearest_from(s_adop, ndop, v, lo);
-        lo = k;
-        id = (uint8_t)k;
+        lo = index_from(s_thr, ad * wavn, lo);
+        id = (uint8_t)lo;
       }
       SG[(long long)c * L.ngroups + g] = pk;
       idop8[(long long)c * L.ngroups + g] = id;
