@@ -43,6 +43,10 @@ struct DevBuf {
 struct trx_handle {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CIA kernels, overlapped with the first sweep step
+  // stream4: the line sweep (strengths, sticky index, accumulation) of step c+1 runs while
+  // `stream` integrates the optical depth of step c; ev_ac[c] = step c accumulated
+  hipStream_t stream4 = nullptr;
+  std::vector<hipEvent_t> ev_ac;
   hipEvent_t ev_inputs = nullptr, ev_cia = nullptr;
   std::string err;
 
@@ -539,6 +543,24 @@ void layer_dev(trx_handle *h, const LayerHost &LH, int nr, LayerDev &Y, const do
   Y.idop0 = di; Y.ilor = di + nli; Y.psmax = Y.ilor + nli; d_npre = Y.psmax + nli;
 }
 
+// ---- per-kernel timing of a profiled run: (start, end) event pairs on the stream of the kernel ----
+struct Spans {
+  enum Kind { kSweep = 0, kSticky = 1, kAccum = 2, kTau = 3 };
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> v;
+  int begin(int kind, hipStream_t st) {
+    Span sp{nullptr, nullptr, kind};
+    if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return -1;
+    v.push_back(sp);
+    return hipEventRecord(sp.a, st) == hipSuccess ? 0 : -1;
+  }
+  int end(hipStream_t st) { return hipEventRecord(v.back().b, st) == hipSuccess ? 0 : -1; }
+  void sum(double out[4]) const {
+    for (const Span &sp : v) { float t = 0; if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) out[sp.kind] += t; }
+  }
+  ~Spans() { for (Span &sp : v) { if (sp.a) (void)hipEventDestroy(sp.a); if (sp.b) (void)hipEventDestroy(sp.b); } }
+};
+
 // ---- one step of the line sweep: strengths (+ all-reduce), sticky index, accumulation ----
 struct SweepMode {
   bool eager = false, prof = false, skip_done = false, permol = false, use_comm = false;
@@ -546,15 +568,21 @@ struct SweepMode {
   int nmx = 1; const int32_t *d_iso_mx = nullptr;   // output slot per isotope (per-molecule sweeps)
   double *d_e = nullptr;                             // [layer][nmx][nsh]
   double *ar_cur = nullptr, *ar_prev = nullptr;      // maxima of this step / previous step's staging
+  double *d_SG = nullptr; uint8_t *d_idop8 = nullptr;   // strength buffers of this step
+  // strengths run on st_sweep; sticky index and accumulation on st_acc after ev_sweep
+  // (null: the handle's stream, no event needed)
+  hipStream_t st_sweep = nullptr, st_acc = nullptr; hipEvent_t ev_sweep = nullptr;
 };
 
 int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const int32_t *d_npre, const int32_t *psmax,
-                int r_top, int nc, int nc_max, const SweepMode &M, std::vector<hipEvent_t> *ev)
+                int r_top, int nc, int nc_max, const SweepMode &M, Spans *sp)
 {
-  hipStream_t st = h->stream;
+  hipStream_t st = M.st_acc ? M.st_acc : h->stream;
+  hipStream_t sts = M.st_sweep ? M.st_sweep : st;
   const int niso = h->niso; const int64_t nsh = h->nsh;
   const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
-  auto mark = [&]() -> int { if (!ev) return 0; hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev->push_back(e); return hipEventRecord(e, st) == hipSuccess ? 0 : -1; };
+  double *d_SG = M.d_SG ? M.d_SG : h->d_SG.as<double>();
+  uint8_t *d_idop8 = M.d_idop8 ? M.d_idop8 : h->d_idop8.as<uint8_t>();
   // lines whose profiles can reach this shard in any layer of the step (contiguous per
   // isotope block).  The layer maximum is global (extinction.c:399-427 runs over every
   // line): with a communicator each rank reduces its own window and the maxima are
@@ -585,28 +613,34 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   const long long seg_lines = GG.base[GG.n];
   const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
   const double *ggate = M.use_comm ? M.ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
+  if (sp && sp->begin(Spans::kSweep, sts)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
-    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, sts,
                        h->L, Y, GG, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, d_wcut,
-                       h->d_SG.as<double>(), h->d_idop8.as<uint8_t>(), (unsigned long long *)M.ar_cur,
+                       d_SG, d_idop8, (unsigned long long *)M.ar_cur,
                        M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
   }
   if (M.use_comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
-    if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
+    if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, sts) != ncclSuccess)
       return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
   }
-  if (mark()) return fail(h, TRX_E_HIP, "event");
+  if (sp && sp->end(sts)) return fail(h, TRX_E_HIP, "event");
+  if (M.ev_sweep) {
+    HIPCHK(h, hipEventRecord(M.ev_sweep, sts));
+    HIPCHK(h, hipStreamWaitEvent(st, M.ev_sweep, 0));
+  }
+  if (sp && sp->begin(Spans::kSticky, st)) return fail(h, TRX_E_HIP, "event");
   if (h->ngroups > 0) {
     hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
                        h->L, Y, niso, r_top, nc, M.ar_cur, M.nmx, M.d_iso_mx, M.ethresh, h->d_adop.as<double>(), h->ndop,
                        d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)M.eager);
   }
-  if (mark()) return fail(h, TRX_E_HIP, "event");
+  if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
   if (h->ngroups > 0) {
     AccumArgs A{};
     A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
     A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
-    A.SG = h->d_SG.as<double>(); A.idop8 = h->d_idop8.as<uint8_t>(); A.sticky_idop = h->d_sticky.as<int>();
+    A.SG = d_SG; A.idop8 = d_idop8; A.sticky_idop = h->d_sticky.as<int>();
     A.kmaxc = M.ar_cur; A.ethresh = M.ethresh; A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol;
     A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
     A.table = h->tab; A.e = M.d_e;
@@ -632,7 +666,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
       hipLaunchKernelGGL(k_accumulate_wide, dim3((wtiles + 3) / 4, (unsigned)nc), dim3(256), 0, st, W);
     }
   }
-  if (mark()) return fail(h, TRX_E_HIP, "event");
+  if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
   if (M.prof && h->ngroups > 0) {      // counters (profiling runs only; gated like the sweep itself)
     for (int k = 0; k < 3; k++)
       hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
@@ -723,8 +757,11 @@ int trx_create(const trx_static *s, trx_handle **out)
   int rc = TRX_OK;
   auto bail = [&](int code) { trx_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return bail(TRX_E_NODEVICE);
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
-  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+  {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+    if (hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+  }
   if (hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_cia, hipEventDisableTiming) != hipSuccess) return bail(TRX_E_HIP);
   h->wn_i = s->wn_i; h->wn_d = s->wn_d; h->osamp = s->osamp; h->odwn = s->wn_d / s->osamp;
@@ -785,6 +822,8 @@ void trx_destroy(trx_handle *h)
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+  if (h->stream4) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamDestroy(h->stream4); }
+  for (auto e : h->ev_ac) (void)hipEventDestroy(e);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
   if (h->ev_cia) (void)hipEventDestroy(h->ev_cia);
@@ -901,16 +940,29 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- workspaces -------------------------------------------------------------
   const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
-  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * nc_max)) ||
-      (rc = ensure(h, h->d_idop8, gr_b * nc_max)) || (rc = ensure(h, h->d_kmax, sizeof(double) * nr)) ||
+  // Two streams: the line sweep of step c+1 (saturates the machine) runs on stream4 while the
+  // optical depth of step c (a latency chain on a few waves) is integrated on the main stream.
+  // The layer maxima get one slot per step (the optical-depth kernel no longer resets them);
+  // the sharded (communicator) path stays in one stream.
+  const bool pipelined = !h->comm && !h->has_grid;
+  const size_t sg_stride = gr_b * nc_max;
+  const size_t ar_slots = pipelined ? (size_t)nr + 2 : 2;
+  if ((rc = ensure(h, h->d_SG, sizeof(double) * sg_stride)) ||
+      (rc = ensure(h, h->d_idop8, sg_stride)) || (rc = ensure(h, h->d_kmax, sizeof(double) * nr)) ||
       (rc = ensure(h, h->d_sticky, sizeof(int) * nli)) || (rc = ensure(h, h->d_counters, 24 * (size_t)nr)) ||
       (rc = ensure(h, h->d_flags, 64)) ||
       (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
       (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
       (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
       (rc = ensure(h, h->d_status, 16)) || (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)) ||
-      (rc = ensure(h, h->d_arbuf, sizeof(double) * 2 * (kMaxChunk + 1))))
+      (rc = ensure(h, h->d_arbuf, sizeof(double) * ar_slots * (kMaxChunk + 1))))
     return rc;
+  if (pipelined)
+    while ((int)h->ev_ac.size() < nr + 1) {
+      hipEvent_t e1;
+      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+      h->ev_ac.push_back(e1);
+    }
   if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4))))
     return rc;
   if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_geom, geom)) ||
@@ -923,7 +975,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
   HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
-  {   // all-reduce staging: maxima 0, "rays still open" flags 1
+  if (pipelined) {   // one slot of layer maxima per step, all zero
+    HIPCHK(h, hipMemsetAsync(h->d_arbuf.p, 0, sizeof(double) * ar_slots * (kMaxChunk + 1), st));
+  } else {           // all-reduce staging: maxima 0, "rays still open" flags 1
     static const std::vector<double> ar0 = [] { std::vector<double> v(2 * (kMaxChunk + 1), 0.0); v[kMaxChunk] = 1.0; v[2 * kMaxChunk + 1] = 1.0; return v; }();
     HIPCHK(h, hipMemcpyAsync(h->d_arbuf.p, ar0.data(), ar0.size() * sizeof(double), hipMemcpyHostToDevice, st));
   }
@@ -964,14 +1018,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(h, hipEventRecord(h->ev_inputs, st));
     HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
+    if (pipelined) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0));
     if ((rc = cia_device(h, a, o, d_tempk, h->stream2))) return rc;
     HIPCHK(h, hipEventRecord(h->ev_cia, h->stream2));
     ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
   // ---- events -----------------------------------------------------------------
-  std::vector<hipEvent_t> ev;
-  auto mark = [&]() -> int { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev.push_back(e); return hipEventRecord(e, st) == hipSuccess ? 0 : -1; };
+  Spans spans;
   hipEvent_t ev_begin, ev_end;
   HIPCHK(h, hipEventCreate(&ev_begin)); HIPCHK(h, hipEventCreate(&ev_end));
   HIPCHK(h, hipEventRecord(ev_begin, st));
@@ -988,8 +1042,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (!eager && !h->comm && h->hint_layers > swept && h->hint_layers - swept < nc) nc = std::max(h->hint_layers - swept, swept == 0 ? 3 : 1);
       nc = std::min(nc, r_top + 1);
     }
-    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    double *tau_next_ar = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
     if (h->has_grid) {
+      if (prof && spans.begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
       GridArgs Gd{};
       Gd.o = h->d_og_o.as<double>(); Gd.nt = (int)h->og_ntemp; Gd.nm = (int)h->og_nmol; Gd.nr = nr;
       Gd.nwave = h->og_nwave; Gd.lo = h->lo; Gd.nsh = nsh; Gd.r_top = r_top; Gd.nc = nc;
@@ -997,7 +1052,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       Gd.w_lo = h->d_og_layer.as<double>(); Gd.w_hi = Gd.w_lo + nr; Gd.dg = Gd.w_hi + nr; Gd.dens = Gd.dg + nr;
       Gd.e = h->d_e.as<double>(); Gd.flags = h->d_flags.as<int>(); Gd.eager = eager;
       hipLaunchKernelGGL(k_grid_extinction, dim3((unsigned)((nsh + 255) / 256), (unsigned)nc), dim3(256), 0, st, Gd);
-      if (prof) for (int k = 0; k < 3; k++) if (mark()) return fail(h, TRX_E_HIP, "event");
+      if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
     } else {
       SweepMode M{};
       M.eager = eager; M.prof = prof; M.ethresh = o->ethresh; M.chunk_index = nchunks;
@@ -1005,10 +1060,22 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       M.d_e = h->d_e.as<double>(); M.use_comm = h->comm != nullptr;
       M.ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
       M.ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
-      if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, psmax, r_top, nc, nc_max, M, prof ? &ev : nullptr))) return rc;
+      if (pipelined) {
+        // maxima of step c into slot c; the optical-depth kernel must not touch the slots
+        // (its staging pointer goes to a scratch slot, the last one)
+        M.ar_cur = h->d_arbuf.as<double>() + (size_t)nchunks * (kMaxChunk + 1);
+        M.ar_prev = nullptr;
+        tau_next_ar = h->d_arbuf.as<double>() + (ar_slots - 1) * (kMaxChunk + 1);
+        M.st_sweep = h->stream4; M.st_acc = h->stream4;
+      }
+      if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, psmax, r_top, nc, nc_max, M, prof ? &spans : nullptr))) return rc;
+      if (pipelined) {     // the optical-depth kernel of this step follows its accumulation
+        HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], h->stream4));
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_ac[nchunks], 0));
+      }
     }
-    double *ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
     if (nchunks == 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+    if (prof && spans.begin(Spans::kTau, st)) return fail(h, TRX_E_HIP, "event");
     {
       TauArgs T{};
       T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
@@ -1022,7 +1089,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
-      T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = ar_prev;
+      T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = tau_next_ar;
       if (o->solution == TRX_SOL_ECLIPSE) {
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
         const int bs = nsh <= 64 * 1024 ? 64 : 256;
@@ -1032,7 +1099,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
                            dim3(256), 0, st, T);
     }
-    if (prof && mark()) return fail(h, TRX_E_HIP, "event");
+    if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
     r_top -= nc; nchunks++;
   }
 
@@ -1082,16 +1149,12 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (prof) {
     // every launch counts (also the ~4 us gated ones after all rays stopped), so that
     // sum / launches is the average a kernel trace reports
-    for (int c = 0; c < nchunks; c++) {
-      float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-      (void)hipEventElapsedTime(&t1, ev[5*c], ev[5*c+1]); (void)hipEventElapsedTime(&t2, ev[5*c+1], ev[5*c+2]);
-      (void)hipEventElapsedTime(&t3, ev[5*c+2], ev[5*c+3]); (void)hipEventElapsedTime(&t4, ev[5*c+3], ev[5*c+4]);
-      S.ms_k_sweep += t1; S.ms_k_sticky += t2; S.ms_k_accum += t3; S.sweep_launches++;
-      S.ms_tau += t4;
-    }
+    double t[4] = {0, 0, 0, 0};
+    spans.sum(t);
+    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_sticky = t[Spans::kSticky]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
+    S.sweep_launches = nchunks;
     S.ms_sweep = S.ms_k_sweep + S.ms_k_sticky + S.ms_k_accum;
   }
-  for (auto e : ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
 
   if (dbg) {
