@@ -47,7 +47,7 @@ struct trx_handle {
   // `stream` integrates the optical depth of step c; ev_ac[c] = step c accumulated
   hipStream_t stream4 = nullptr;
   std::vector<hipEvent_t> ev_ac;
-  hipEvent_t ev_inputs = nullptr, ev_cia = nullptr;
+  hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr;
   std::string err;
 
   // grids
@@ -762,7 +762,8 @@ int trx_create(const trx_static *s, trx_handle **out)
     if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
     if (hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
   }
-  if (hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming) != hipSuccess ||
+  if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_cia, hipEventDisableTiming) != hipSuccess) return bail(TRX_E_HIP);
   h->wn_i = s->wn_i; h->wn_d = s->wn_d; h->osamp = s->osamp; h->odwn = s->wn_d / s->osamp;
   h->nwn = s->nwn; h->nown = s->nown; h->lo = s->wn_lo; h->hi = s->wn_hi; h->nsh = s->wn_hi - s->wn_lo;
@@ -826,6 +827,7 @@ void trx_destroy(trx_handle *h)
   for (auto e : h->ev_ac) (void)hipEventDestroy(e);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_cia) (void)hipEventDestroy(h->ev_cia);
   delete h;
 }
@@ -1100,6 +1102,12 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                            dim3(256), 0, st, T);
     }
     if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
+    if (pipelined && !eager && h->hint_layers == nr - 1 - r_top + nc) {
+      // this step is expected to stop the last rays: let the next step's sweep see the
+      // outcome (it then returns at its gate) instead of running ahead of it in vain
+      HIPCHK(h, hipEventRecord(h->ev_join, st));
+      HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_join, 0));
+    }
     r_top -= nc; nchunks++;
   }
 
@@ -1124,6 +1132,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
     M.ip = h->d_ip.as<double>(); M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
     hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
+  }
+  if (pipelined) {   // nothing of this run may still be in flight on the sweep stream when it returns
+    HIPCHK(h, hipEventRecord(h->ev_join, h->stream4));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(ev_end, st));
