@@ -251,9 +251,11 @@ def main():
                        "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
                        "parallelism": "wn-shard x%d" % world,
-                       "layer_chunk": args.layer_chunk or 12,
-                       "depth_hint": "chunk plan ends at the previous run's deepest layer (retrieval-loop reuse; "
-                                     "warm-up runs provide it)",
+                       "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps of <= 32 "
+                                                          "layers (12 per step on a handle's first run)",
+                       "steps_per_run": launches,
+                       "depth_hint": "step plan ends at the previous run's deepest layer (retrieval-loop reuse; "
+                                     "warm-up runs provide it); a run that needs more goes on from there",
                        "ms_create_total": 1e3 * t_create, "ms_create_voigt_table_kernels": stats["ms_create_table"],
                        "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
                        "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],

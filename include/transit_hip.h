@@ -166,7 +166,9 @@ typedef struct {
   int32_t scat_flag;      /* 0 none, 1 Lecavelier, 2 polarizability            */
   double  scat_logext;
   /* execution knobs (no effect on results)                                    */
-  int32_t layer_chunk;    /* layers swept per top-down step; 0 = default       */
+  int32_t layer_chunk;    /* layers swept per top-down step (<= 32; 16 in transit geometry);
+                             0 = automatic: 12 on a handle's first spectrum, then the depth
+                             the previous spectrum reached in equal steps               */
   int32_t eager;          /* 1 = sweep every layer (debug dumps of all layers) */
   int32_t profile;        /* 1 = bracket every kernel with HIP events (trx_stats timings) */
 } trx_opts;

@@ -879,9 +879,19 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   for (int i = 1; i < nr; i++) if (!(a->radius[i] > a->radius[i-1])) return fail(h, TRX_E_ARG, "radii must ascend");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
-  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
-  nc_max = std::max(3, std::min(nc_max, kMaxChunk));
   const bool eager = o->eager != 0, prof = o->profile != 0;
+  // Layers per step.  Large steps amortise the line reads and the launch chain, small ones
+  // waste less when the depth is unknown.  Default: 12 on a handle's first spectrum; once
+  // the previous spectrum's depth is known (hint_layers) the plan is its depth in equal
+  // steps of at most kMaxChunk layers, and the run returns right there (below).
+  const bool stop_at_hint_ok = !h->comm && !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
+  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
+  const int nc_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;   // k_optical_depth: one block row per height
+  if (o->layer_chunk <= 0 && stop_at_hint_ok) {
+    const int steps = (h->hint_layers + nc_cap - 1) / nc_cap;
+    nc_max = (h->hint_layers + steps - 1) / steps;
+  }
+  nc_max = std::max(3, std::min(nc_max, nc_cap));
   int rc;
 
   // ---- layer prologue (extinction.c:364-395) --------------------------------
@@ -1033,8 +1043,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev_begin, st));
 
   // ---- top-down sweep in chunks of layers (tau.c:235-290) ----
-  int nchunks = 0;
-  for (int r_top = nr - 1; r_top >= 0; ) {
+  int nchunks = 0, r_top = nr - 1;
+  bool stop_at_hint = stop_at_hint_ok;
+  int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
+  std::vector<unsigned long long> counters(3 * (size_t)nr);
+  double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
+  for (;;) {
+  for (; r_top >= 0; ) {
     // Chunk plan: nc_max layers per step; when the previous spectrum on this handle
     // stopped at hint_layers (retrieval loops re-run near-identical atmospheres), end a
     // step exactly there so that no layer below the expected last one is swept in vain.
@@ -1094,25 +1109,24 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = tau_next_ar;
       if (o->solution == TRX_SOL_ECLIPSE) {
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
-        const int bs = nsh <= 64 * 1024 ? 64 : 256;
-        hipLaunchKernelGGL(k_optical_depth_vertical, dim3((unsigned)std::min<int64_t>((nsh + bs - 1) / bs, kTauMaxBlocks)),
-                           dim3(bs), 0, st, T);
+        const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
+        const dim3 grid((unsigned)std::min<int64_t>((nsh + (small ? 63 : 255)) / (small ? 64 : 256), kTauMaxBlocks)), block(small ? 64 : 256);
+        if (small && extras)       hipLaunchKernelGGL((k_optical_depth_vertical<true, true>), grid, block, 0, st, T);
+        else if (small)            hipLaunchKernelGGL((k_optical_depth_vertical<true, false>), grid, block, 0, st, T);
+        else if (extras)           hipLaunchKernelGGL((k_optical_depth_vertical<false, true>), grid, block, 0, st, T);
+        else                       hipLaunchKernelGGL((k_optical_depth_vertical<false, false>), grid, block, 0, st, T);
       } else
         hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
                            dim3(256), 0, st, T);
     }
     if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
-    if (pipelined && !eager && h->hint_layers == nr - 1 - r_top + nc) {
-      // this step is expected to stop the last rays: let the next step's sweep see the
-      // outcome (it then returns at its gate) instead of running ahead of it in vain
-      HIPCHK(h, hipEventRecord(h->ev_join, st));
-      HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_join, 0));
-    }
     r_top -= nc; nchunks++;
+    // the previous spectrum stopped here: compute the spectrum now and look at the outcome
+    // on the host (which this call waits for anyway) instead of queueing gated no-op steps
+    if (stop_at_hint && nr - 1 - r_top >= h->hint_layers) break;
   }
 
   // ---- spectrum ---------------------------------------------------------------
-  double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
   if (o->solution == TRX_SOL_ECLIPSE) {
     EmisArgs E{};
     E.nr = nr; E.nang = o->nangles; E.nsh = nsh; E.lo = h->lo; E.wn_i = h->wn_i; E.wn_d = h->wn_d; E.wn_fct = o->wn_fct;
@@ -1141,13 +1155,15 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev_end, st));
 
   // ---- results back -----------------------------------------------------------
-  int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
   HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
   if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
-  std::vector<unsigned long long> counters(3 * (size_t)nr);
   HIPCHK(h, hipMemcpyAsync(counters.data(), h->d_counters.p, 24 * (size_t)nr, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  // rays still descending below the expected depth (the atmosphere changed): go on from there
+  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) { stop_at_hint = false; continue; }
+  break;
+  }
 
   trx_stats &S = h->stats;
   S.layers_swept = flags_host[2];

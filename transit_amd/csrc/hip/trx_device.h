@@ -8,7 +8,7 @@
 
 namespace trx {
 
-constexpr int kMaxChunk   = 16;    // layers swept per top-down step (upper bound)
+constexpr int kMaxChunk   = 32;    // layers swept per top-down step (upper bound)
 constexpr int kMaxIso     = 64;    // isotopes per run
 constexpr int kMaxAngles  = 16;
 constexpr int kMaxDop     = 256;   // Doppler-width samples (ndop)

@@ -927,7 +927,9 @@ struct TauArgs {
   double *next_ar;
 };
 
-__device__ __forceinline__ double scat_term(const TauArgs &T, int r, double wn)
+// (out of line: a dozen inlined pow() bodies per call site would push the optical-depth
+// loops past the instruction cache; most runs have both models switched off)
+__device__ __noinline__ double scat_term(const TauArgs &T, int r, double wn)
 {
   if (T.scat_flag == 1) return T.scat_pref * T.press[r] / T.temp[r] * pow(wn, 4);
   if (T.scat_flag == 2) return T.scat_pol[r] * pow(2. * kPi * wn * kMicron, 4);
@@ -935,7 +937,7 @@ __device__ __forceinline__ double scat_term(const TauArgs &T, int r, double wn)
 }
 
 // extinction.c:630-693: zero above the top and below the bottom of the deck
-__device__ __forceinline__ double cloud_term(const TauArgs &T, int r, double wn)
+__device__ __noinline__ double cloud_term(const TauArgs &T, int r, double wn)
 {
   if (T.cloud_flag == 0 || T.cloud_ext == 0.0) return 0.0;
   const double ctop = pow(10, T.cloud_top), cbot = pow(10, T.cloud_bot);
@@ -1117,10 +1119,15 @@ void k_optical_depth(TauArgs T)
 // which is the reference's sum re-associated (top-down instead of bottom-up) with
 // interval lengths taken as rad[k+1]-rad[k] rather than differences of their running
 // sum: ~1e-15 relative.  One lane per wavenumber walks the chunk's layers.
+// STAGED (one wave per block, small shards): the step's outputs wait in LDS and are stored
+// after the chain.  On this part stores and loads share one in-order counter, so a store in
+// the loop would make every wait for a prefetched load wait for the store's round trip too.
+template <bool STAGED, bool EXTRAS>      // EXTRAS: a scattering or cloud model is switched on
 __global__ __launch_bounds__(256)
 void k_optical_depth_vertical(TauArgs T)
 {
   if (!T.eager && T.flags[0] == 0) { tau_idle(T); return; }
+  __shared__ double s_out[STAGED ? 2 * kMaxChunk * 64 : 1];
   const int nr = T.nr;
   int nstill = 0, deep = 0;
   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
@@ -1132,18 +1139,28 @@ void k_optical_depth_vertical(TauArgs T)
     double y1 = 0, y2 = 0;
     if (T.r_top + 1 < nr) y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
     if (T.r_top + 2 < nr) y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
+    // total extinction of the layers ahead is requested six steps before it is used, so
+    // that the sequential part runs on arithmetic latency, not on memory round trips
+    auto total_ext = [&](int c) -> double {
+      if (c >= T.nc) return 0.0;
+      const int rs = T.r_top - c;
+      const long long k = (long long)rs * T.nsh + w;
+      if (EXTRAS) return T.e[k] + scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[k];   // tau.c:231-232
+      return T.e[k] + T.ecs[k];
+    };
+    double q0 = total_ext(0), q1 = total_ext(1), q2 = total_ext(2), q3 = total_ext(3), q4 = total_ext(4), q5 = total_ext(5);
+    int done = 0;
     for (int c = 0; c < T.nc; c++) {
       const int rs = T.r_top - c, ri = nr - 1 - rs, n = nr - rs;
       const long long k = (long long)rs * T.nsh + w;
-      const double yraw = T.e[k] + scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[k];   // tau.c:231-232
+      const double yraw = q0, ybelow = q1;
+      q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6);
       double tv, y0 = yraw;
       if (n == 1) {
         tv = 0.0;                                           // eclipse.c:45-46
       } else if (n == 2) {                                  // eclipse.c:65, 68-80 (value not kept)
         // needs the layer below: it belongs to this chunk (the first chunk has >= 3 layers)
-        const long long kb = (long long)(rs - 1) * T.nsh + w;
-        const double ym = T.e[kb] + scat_term(T, rs - 1, wcgs) + cloud_term(T, rs - 1, wcgs) + T.ecs[kb];
-        const double yp = parab3(T.rad[rs-1], T.rad[rs], ym, yraw, y1, T.rad[rs]);
+        const double yp = parab3(T.rad[rs-1], T.rad[rs], ybelow, yraw, y1, T.rad[rs]);
         const double *g = T.gw + (long long)rs * T.gstride;
         tv = T.rad_fct * (((yp * g[0] + ((y1 + yp) / 2.0) * g[1] + y1 * g[2]) * g[3]) / 6.0);
       } else {
@@ -1154,11 +1171,18 @@ void k_optical_depth_vertical(TauArgs T)
         tv = T.rad_fct * res;
         a2 = a1; a1 = a0;
       }
-      T.er[k] = y0;
+      if (STAGED) { s_out[(2 * c) * 64 + threadIdx.x] = y0; s_out[(2 * c + 1) * 64 + threadIdx.x] = tv; }
+      else { T.er[k] = y0; T.tau[(long long)ri * T.nsh + w] = tv; }
       y2 = y1; y1 = y0;
-      T.tau[(long long)ri * T.nsh + w] = tv;
+      done = c + 1;
       if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
     }
+    if (STAGED)
+      for (int c = 0; c < done; c++) {
+        const int rs = T.r_top - c;
+        T.er[(long long)rs * T.nsh + w] = s_out[(2 * c) * 64 + threadIdx.x];
+        T.tau[(long long)(nr - 1 - rs) * T.nsh + w] = s_out[(2 * c + 1) * 64 + threadIdx.x];
+      }
     T.acc[w] = a1; T.acc[T.nsh + w] = a2;
     nstill += still;
   }
