@@ -49,6 +49,8 @@ def parse():
                     help="N>1: weak = every GPU gets its own CH4-demo-sized slice (band and line list grow with N); "
                          "strong = the one CH4-demo run split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm-single", action="store_true",
+                    help="N=1 only: run through a 1-rank RCCL communicator (the code path every rank of an N>1 job takes)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = full workload)")
     return ap.parse_args()
 
@@ -170,7 +172,7 @@ def main():
     st = P.static
     st.device = local
     comm = None
-    if world > 1:       # in-stream all-reduce of the per-layer line-strength maxima (engine side)
+    if world > 1 or args.comm_single:       # in-stream all-reduce of the per-layer line-strength maxima (engine side)
         comm = tdist.create_comm(world, rank, local)
         st.comm, st.nranks, st.rank = comm, world, rank
     t0 = time.time()
@@ -289,8 +291,9 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if comm is not None:
         tdist.destroy_comm(comm)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

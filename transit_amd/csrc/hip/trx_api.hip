@@ -884,7 +884,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // waste less when the depth is unknown.  Default: 12 on a handle's first spectrum; once
   // the previous spectrum's depth is known (hint_layers) the plan is its depth in equal
   // steps of at most kMaxChunk layers, and the run returns right there (below).
-  const bool stop_at_hint_ok = !h->comm && !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
+  // (sharded job: the depth is the all-reduced one, so every rank plans the same steps)
+  const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
   int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
   const int nc_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;   // k_optical_depth: one block row per height
   if (o->layer_chunk <= 0 && stop_at_hint_ok) {
@@ -1056,7 +1057,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     int nc = std::min(nc_max, r_top + 1);
     {
       const int swept = nr - 1 - r_top;
-      if (!eager && !h->comm && h->hint_layers > swept && h->hint_layers - swept < nc) nc = std::max(h->hint_layers - swept, swept == 0 ? 3 : 1);
+      if (!eager && h->hint_layers > swept && h->hint_layers - swept < nc) nc = std::max(h->hint_layers - swept, swept == 0 ? 3 : 1);
       nc = std::min(nc, r_top + 1);
     }
     double *tau_next_ar = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
@@ -1155,6 +1156,12 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev_end, st));
 
   // ---- results back -----------------------------------------------------------
+  if (h->comm) {
+    // every rank must take the same decision below and plan the same steps next time:
+    // rays still open (flags[0]) and deepest stopping height (flags[4]) become job-wide maxima
+    if (rccl().AllReduce(h->d_flags.p, h->d_flags.p, 8, ncclInt32, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
+      return fail(h, TRX_E_HIP, "ncclAllReduce(flags) failed");
+  }
   HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
   if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
