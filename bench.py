@@ -230,12 +230,24 @@ def main():
         kern = {"k_group_sweep": stats["ms_k_sweep"], "k_sticky_index": stats["ms_k_sticky"],
                 "k_accumulate": stats["ms_k_accum"]}
         dom = max(kern, key=kern.get)
-        # algorithmic bytes of the reference's data flow: 26 B per
-        # line per layer per pass (k_group_sweep does both passes' line scans);
-        # 4 B per accumulated bin + 8 B per stored e for the accumulation
-        alg = {"k_group_sweep": 52.0 * L * R, "k_sticky_index": 0.0,
+        # Two byte counts per kernel:
+        #  * ref  = the REFERENCE's data flow: the line list (26 B/line) is scanned once per layer
+        #           and per pass -- 52 B per line-layer for the strength kernel, which does both
+        #           passes' scans; 4 B per accumulated bin + 8 B per stored e for the accumulation;
+        #  * kmin = what THIS data flow has to move (SURVEY's B_min idea): the strength kernel reads
+        #           a line ONCE per launch (27 B) for all the launch's layers and writes 9 B per
+        #           (group, layer); the accumulation reads those 9 B + the group's fine-grid index
+        #           (4 B) per (group, layer), the table entries and writes e.
+        # Fusing a launch's layers makes ref/launch-time exceed the HBM peak (it is not HBM traffic),
+        # so roofline.achieved uses kmin -- it cannot exceed 1 -- and ref is reported beside it.
+        G = stats["ngroups"]
+        ref = {"k_group_sweep": 52.0 * L * R, "k_sticky_index": 0.0,
                "k_accumulate": 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
+        kmin = {"k_group_sweep": 27.0 * L * launches + 9.0 * G * R, "k_sticky_index": 0.0,
+                "k_accumulate": 13.0 * G * R + 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
+        alg = kmin
         ach = alg[dom] / launches / (kern[dom] / launches * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        ref_gbs = ref[dom] / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
         # rank 0's share (its lines, bins and slice); x world for the job when N>1
         b_alg_run = world * (52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * (hi - lo) + 8.0 * (hi - lo) * (1 + nang))
         out = {
@@ -262,18 +274,27 @@ def main():
                        "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
                        "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],
                        "ms_host_cia": stats["ms_cia"], "ms_host_total_profiled_run": stats["ms_host_total"],
+                       "b_min_run_bytes": world * (27.0 * L * launches + 22.0 * G * R + 4.0 * stats["sum_bins"]
+                                                   + 24.0 * R * (hi - lo) + 8.0 * (hi - lo) * (1 + nang)),
                        "b_alg_run_bytes": b_alg_run,
                        "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9,
                        "line_layer_bins_per_s": world * stats["sum_bins"] / (ms_step * 1e-3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else None,
-                         "note": "achieved = algorithmic bytes of the reference's data flow (SURVEY 8d: 26 B per line "
-                                 "per layer per pass) / measured launch time; the kernel itself reads each line once "
-                                 "per chunk of layers, so its measured traffic is BELOW the algorithmic bytes",
+                         "note": "achieved = bytes this data flow must move per launch (lines once per launch + "
+                                 "9 B per group-layer out) / measured launch time; `traffic` = the PMC-measured HBM "
+                                 "bytes per launch.  The reference's own flow (52 B per line-layer) is in "
+                                 "ref_flow_GBs: above the HBM peak because a launch covers ~27 layers per line read. "
+                                 "This kernel is bound by the fp64 vector pipe (two exp per line-layer, ~130 VALU "
+                                 "instructions of which ~50 are the exps), see valu_issue_frac_est",
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
-                         "launches": launches},
+                         "launches": launches, "ref_flow_GBs": ref_gbs,
+                         "ref_flow_bytes_per_launch": ref[dom] / launches},
         }
+        if dom == "k_group_sweep" and kern[dom] > 0:
+            # ~130 wave instructions per line-layer (ISA count), 4 cycles each on a 16-lane SIMD
+            out["roofline"]["valu_issue_frac_est"] = (130.0 * L * R / 64.0) / (kern[dom] * 1e-3) / (1024 * 2.4e9 / 4.0)
         if dom == "k_accumulate" and ach > HBM_PEAK_GBS:
             # wide-profile regime (fine grids): neighbouring lines re-read the same profile rows, which
             # therefore come out of L1/L2 -- the 4 B per accumulated bin never reach HBM and an HBM
