@@ -983,8 +983,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     return rc;
   if ((rc = upload(h, h->d_ip, ipv))) return rc;
   HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 24 * (size_t)nr, st));
-  HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
-  HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
+  if (dbg || eager) {   // every element the path reads is written first; zeros only matter in the dumps
+    HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
+    HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
+  }
   HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
   HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
@@ -1024,18 +1026,21 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if ((rc = upload(h, h->d_og_layer, og_layer)) || (rc = upload(h, h->d_og_itemp, og_itemp))) return rc;
   }
 
-  // ---- CIA extinction (device) ----------------------------------------------------
-  {
-    // on a second stream: only the first optical-depth kernel needs e_cs, so the
-    // (latency-bound) spline kernels overlap the first sweep step
+  // ---- inputs are on the device: release the other streams -----------------------------
+  HIPCHK(h, hipEventRecord(h->ev_inputs, st));
+  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
+  if (pipelined) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0));
+  // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
+  // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
+  // after that step's kernels, which are what the GPU is waiting for.
+  auto queue_cia = [&]() -> int {
     const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(h, hipEventRecord(h->ev_inputs, st));
-    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
-    if (pipelined) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0));
-    if ((rc = cia_device(h, a, o, d_tempk, h->stream2))) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_cia, h->stream2));
+    const int rcc = cia_device(h, a, o, d_tempk, h->stream2);
+    if (rcc) return rcc;
+    if (hipEventRecord(h->ev_cia, h->stream2) != hipSuccess) return fail(h, TRX_E_HIP, "event");
     ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  }
+    return TRX_OK;
+  };
 
   // ---- events -----------------------------------------------------------------
   Spans spans;
@@ -1092,7 +1097,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_ac[nchunks], 0));
       }
     }
-    if (nchunks == 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+    if (nchunks == 0) {
+      if ((rc = queue_cia())) return rc;
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+    }
     if (prof && spans.begin(Spans::kTau, st)) return fail(h, TRX_E_HIP, "event");
     {
       TauArgs T{};
