@@ -61,7 +61,7 @@ struct trx_handle {
   int ndop = 0, nlor = 0;
   std::vector<double> adop, alor;                   // +1 sentinel
   std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
-  DevBuf d_adop, d_dopthr, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
+  DevBuf d_adop, d_dopthr, d_e2tab, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
   // both tables carry kTabPad zero floats in front and behind: k_accumulate_wide reads whole
   // 4-float lane segments around a profile row and masks what lies outside the row
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
@@ -213,6 +213,9 @@ int build_table(trx_handle *h, const trx_static *s)
         return fail(h, TRX_E_ARG, "Doppler-width grid is not strictly increasing");
     }
     if ((rc = upload(h, h->d_dopthr, thr))) return rc;
+    std::vector<double> e2(64);                       // 2^(j/64) for exp_neg (kernels)
+    for (int j = 0; j < 64; j++) e2[j] = (double)exp2l((long double)j / 64.0L);
+    if ((rc = upload(h, h->d_e2tab, e2))) return rc;
   }
   hipEvent_t e0, e1;
   HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
@@ -616,7 +619,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   if (sp && sp->begin(Spans::kSweep, sts)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
     hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, sts,
-                       h->L, Y, GG, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, d_wcut,
+                       h->L, Y, GG, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, h->d_e2tab.as<double>(), d_wcut,
                        d_SG, d_idop8, (unsigned long long *)M.ar_cur,
                        M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
   }
@@ -633,7 +636,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   if (h->ngroups > 0) {
     hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
                        h->L, Y, niso, r_top, nc, M.ar_cur, M.nmx, M.d_iso_mx, M.ethresh, h->d_adop.as<double>(), h->ndop,
-                       d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)M.eager);
+                       h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)M.eager);
   }
   if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
   if (h->ngroups > 0) {

@@ -225,6 +225,27 @@ __device__ __forceinline__ int index_from(const double *thr, double v, int lo)
   return lo;
 }
 
+// exp(x) for x <= 0, the only arguments the line strengths have (-c*Elow/T, -c*wn/T):
+//   x = (64 m + j) ln2/64 + r, |r| <= ln2/128;  exp(x) = 2^m * 2^(j/64) * e^r
+// with 2^(j/64) from a 64-entry table (LDS) and e^r by a degree-5 polynomial (truncation
+// 3e-17).  16 instructions instead of the 29 of the general-range library routine; ~1.5 ulp.
+// Underflow goes through ldexp (denormals, then 0) like the library's.
+__device__ __forceinline__ double exp_neg(double x, const double *e2tab)
+{
+  const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);           // 64/ln2
+  double r = __builtin_fma(-kd, 0x1.62e42fee00000p-7, x);               // ln2/64, high 32 bits: exact product
+  r = __builtin_fma(-kd, 0x1.a39ef35793c76p-39, r);                     // ln2/64, rest
+  const int ki = (int)kd;
+  const double t = e2tab[ki & 63];
+  double p = 0x1.1111111111111p-7;                                      // 1/120
+  p = __builtin_fma(p, r, 0x1.5555555555555p-5);                        // 1/24
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);                        // 1/6
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(t * p, ki >> 6);
+}
+
 constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are staged in LDS
 
 // One lane per LINE (uniform work: two exponentials per line and layer); the
@@ -233,6 +254,7 @@ constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are
 __global__ __launch_bounds__(256)
 void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
                    const double *__restrict__ dthr, int ndop,   // steps of the Doppler index, [ndop + 1]
+                   const double *__restrict__ e2tab,            // 2^(j/64), j = 0..63
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                    double *__restrict__ SG, uint8_t *__restrict__ idop8,
                    unsigned long long *__restrict__ kmaxc_bits,   // [chunk slot][nmx] bits of the running maxima
@@ -241,12 +263,14 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
 {
   if (!sweep_active(flags, ggate, eager)) return;
   __shared__ double s_thr[kMaxDop + 1];
+  __shared__ double s_e2[64];
   __shared__ double red[4][kMaxChunk];
   __shared__ double s_ct[kMaxChunk];
   __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
   __shared__ double s_s[2][256];                         // line strengths of the layer in flight
   __shared__ double s_k[2][256];                         // per-line candidates for the layer maximum
   for (int i = threadIdx.x; i <= ndop; i += 256) s_thr[i] = dthr[i];
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
   if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
   const int nst = min(niso, kSweepIsoLds);
   for (int i = threadIdx.x; i < nc * nst; i += 256) {
@@ -285,7 +309,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
     if (all_staged) f = s_f[c][iso];
     else f = staged ? s_f[c][iso] : (ok ? Y.strength_f[ri] : 0.0);
     double s = 0;
-    if (ok) s = gf * exp(ct * elow) * (1 - exp(ct * wavn));
+    if (ok) s = gf * exp_neg(ct * elow, s_e2) * (1 - exp_neg(ct * wavn, s_e2));
     s_s[c & 1][threadIdx.x] = s;
     double kbest = inr ? s * f : 0.0;
     if (nmx == 1) {
@@ -308,7 +332,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
       for (int m = 1; m < in_lds; m++) pk += s_s[c & 1][threadIdx.x + m];
       for (int m = in_lds; m < cnt; m++) {                  // members beyond the block: recompute
         const long long lm = ln + m;
-        pk += L.gf[lm] * exp(ct * L.elow[lm]) * (1 - exp(ct * L.wavn[lm]));
+        pk += L.gf[lm] * exp_neg(ct * L.elow[lm], s_e2) * (1 - exp_neg(ct * L.wavn[lm], s_e2));
       }
       pk *= f;
       double wc, ad;
@@ -343,11 +367,15 @@ __global__ __launch_bounds__(64)
 void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
                     const double *__restrict__ kmaxc, int nmx, const int32_t *__restrict__ iso_mx, double ethresh,
                     const double *__restrict__ adop, int ndop,
+                    const double *__restrict__ e2tab,    // 2^(j/64): the same exp as the sweep => the same decisions
                     const int *__restrict__ npre,        // [layer][iso] refreshing groups
                     int *__restrict__ sticky_idop,       // [layer][iso]
                     const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
 {
   if (!sweep_active(flags, ggate, eager)) return;
+  __shared__ double s_e2[64];
+  s_e2[threadIdx.x] = e2tab[threadIdx.x];
+  __builtin_amdgcn_wave_barrier();
   const int c = blockIdx.x / niso, b = blockIdx.x - c * niso;
   if (c >= nc) return;
   const int r = r_top - c, ri = r * niso + b, lane = threadIdx.x;
@@ -362,7 +390,7 @@ void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
       double pk = 0;
       for (int m = 0; m < cnt; m++) {
         const int ln = first + m;
-        const double s = L.gf[ln] * exp(ct * L.elow[ln]) * (1 - exp(ct * L.wavn[ln]));
+        const double s = L.gf[ln] * exp_neg(ct * L.elow[ln], s_e2) * (1 - exp_neg(ct * L.wavn[ln], s_e2));
         pk = (m == 0) ? s : pk + s;
       }
       pk *= f;
