@@ -614,7 +614,8 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
     GG.base[GG.n] = tot;
   }
   const long long seg_lines = GG.base[GG.n];
-  const unsigned tblocks = (unsigned)((ntiles + 3) / 4);
+  constexpr unsigned kSpan = kXcds * kAccumXcdGroup;
+  const unsigned tblocks = (unsigned)(((ntiles + 3) / 4 + kSpan - 1) / kSpan * kSpan);   // multiple of 8*G: xcd_grouped_x()
   const double *ggate = M.use_comm ? M.ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
   if (sp && sp->begin(Spans::kSweep, sts)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
@@ -889,13 +890,6 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // steps of at most kMaxChunk layers, and the run returns right there (below).
   // (sharded job: the depth is the all-reduced one, so every rank plans the same steps)
   const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
-  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
-  const int nc_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;   // k_optical_depth: one block row per height
-  if (o->layer_chunk <= 0 && stop_at_hint_ok) {
-    const int steps = (h->hint_layers + nc_cap - 1) / nc_cap;
-    nc_max = (h->hint_layers + steps - 1) / steps;
-  }
-  nc_max = std::max(3, std::min(nc_max, nc_cap));
   int rc;
 
   // ---- layer prologue (extinction.c:364-395) --------------------------------
@@ -904,6 +898,20 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const size_t nli = LH.nli;
   std::vector<double> &f64 = LH.f64;
   const int32_t *psmax = LH.psmax;
+  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
+  int nc_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;   // k_optical_depth: one block row per height
+  if (o->layer_chunk <= 0 && stop_at_hint_ok) {
+    // wide profiles (fine grids): the deep layers are by far the most expensive and a tile
+    // only learns between steps that its rays have stopped -- keep the steps short there
+    const int r_deep = nr - h->hint_layers;
+    long long pm = 0;
+    for (int b = 0; b < h->niso; b++)
+      if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)r_deep * h->niso + b]);
+    if ((2 * pm) / h->osamp + 1 >= 64) nc_cap = std::min(nc_cap, 12);
+    const int steps = (h->hint_layers + nc_cap - 1) / nc_cap;
+    nc_max = (h->hint_layers + steps - 1) / steps;
+  }
+  nc_max = std::max(3, std::min(nc_max, nc_cap));
   // layer-only scalars of the scattering / cloud models (tau.c:193-214, extinction.c:617-621)
   double *press = &f64[LH.extra_off], *tempk = press + nr, *mdens = tempk + nr, *nH = mdens + nr,
          *scat_pol = nH + nr, *radv = scat_pol + nr;
@@ -979,7 +987,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
       h->ev_ac.push_back(e1);
     }
-  if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * (((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4))))
+  if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
     return rc;
   if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_geom, geom)) ||
       (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))

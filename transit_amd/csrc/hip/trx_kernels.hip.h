@@ -59,6 +59,22 @@ __device__ __forceinline__ int wave_max_i(int v)
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Workgroups are dealt to the 8 XCDs round-robin (linear id mod 8) and each XCD has its own
+// L2.  Tiles next to each other read overlapping windows of the group arrays (and the same
+// profile rows), so out of every 8*G consecutive tile blocks of a layer each XCD gets G
+// CONSECUTIVE ones.  (One contiguous eighth of the layer per XCD was measured too: the
+// stopped-ray tile skipping is spectrally clustered and then unbalances the XCDs.)
+// Needs gridDim.x to be a multiple of 8*G (the host pads; surplus blocks find no tile), so
+// that blockIdx.x mod 8 is the XCD for every blockIdx.y.
+constexpr int kXcds = 8;
+constexpr int kAccumXcdGroup = 4;   // tile blocks (of 4 tiles) per XCD run in k_accumulate
+template <int G>
+__device__ __forceinline__ int xcd_grouped_x()
+{
+  const int x = (int)blockIdx.x, span = kXcds * G;
+  return (x / span) * span + (x % kXcds) * G + (x % span) / kXcds;
+}
+
 // Gate of the line-sweep kernels: rays still descending.  One GPU: the device
 // counter flags[0].  Sharded job: the all-reduced flag of the previous step
 // (ggate, a double that is > 0 while any rank still has open rays), because the
@@ -467,9 +483,9 @@ void k_accumulate(AccumArgs A)
   __shared__ long long s_po[4][kMaxDop];
   __shared__ long long s_nb[4][3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, bx = xcd_grouped_x<kAccumXcdGroup>();
   if ((A.skip_mask >> c) & 1u) return;
-  const int tile = blockIdx.x * 4 + wv;
+  const int tile = bx * 4 + wv;
   const int r = A.r_top - c;
   bool live = tile < A.ntiles;                       // wave-uniform
   const long long j0 = A.lo + (long long)tile * kTileBins;      // global coarse bin
@@ -578,7 +594,7 @@ void k_accumulate(AccumArgs A)
     if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
     __syncthreads();
     if (threadIdx.x < 3)
-      A.part[((long long)c * A.part_stride + blockIdx.x) * 3 + threadIdx.x] =
+      A.part[((long long)c * A.part_stride + bx) * 3 + threadIdx.x] =
           (unsigned long long)(s_nb[0][threadIdx.x] + s_nb[1][threadIdx.x] + s_nb[2][threadIdx.x] + s_nb[3][threadIdx.x]);
   }
 }
@@ -645,7 +661,7 @@ void k_accumulate_wide(WideArgs W)
 {
   const AccumArgs &A = W.A;
   if (!A.eager && A.flags[0] == 0) return;
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, bx = (int)blockIdx.x;
   if (!((W.layer_mask >> c) & 1u)) return;
   __shared__ int32_t   s_K[4][kMaxDop], s_psd[4][kMaxDop], s_psm[4][kMaxDop], s_r2[4][kMaxDop];
   __shared__ long long s_po[4][kMaxDop];
@@ -654,7 +670,7 @@ void k_accumulate_wide(WideArgs W)
   __shared__ int32_t   s_tt[4][64];
   __shared__ long long s_nb[4][3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wv;
+  const int tile = bx * 4 + wv;
   const int ntiles = (int)((A.nsh + kWideT - 1) / kWideT);
   const int r = A.r_top - c;
   bool live = tile < ntiles;
@@ -778,7 +794,7 @@ void k_accumulate_wide(WideArgs W)
     if (lane == 0) { s_nb[wv][0] = nb; s_nb[wv][1] = nev; s_nb[wv][2] = nsk; }
     __syncthreads();
     if (threadIdx.x < 3)
-      A.part[((long long)c * A.part_stride + blockIdx.x) * 3 + threadIdx.x] =
+      A.part[((long long)c * A.part_stride + bx) * 3 + threadIdx.x] =
           (unsigned long long)(s_nb[0][threadIdx.x] + s_nb[1][threadIdx.x] + s_nb[2][threadIdx.x] + s_nb[3][threadIdx.x]);
   }
 }
