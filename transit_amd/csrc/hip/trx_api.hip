@@ -907,7 +907,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     long long pm = 0;
     for (int b = 0; b < h->niso; b++)
       if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)r_deep * h->niso + b]);
-    if ((2 * pm) / h->osamp + 1 >= 64) nc_cap = std::min(nc_cap, 12);
+    if ((2 * pm) / h->osamp + 1 >= 64) nc_cap = std::min(nc_cap, 8);
     const int steps = (h->hint_layers + nc_cap - 1) / nc_cap;
     nc_max = (h->hint_layers + steps - 1) / steps;
   }
