@@ -256,6 +256,16 @@ void trx_comm_destroy(void *comm);
 const char *trx_strerror(int status);
 const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */
 
+/* Messages.  The reference prints through tr_output(level, ...) filtered by the global
+ * `verblevel` (transit.h:70-75, levels flags_tr.h:107-111) and exit()s on errors; the
+ * library never prints or exits by itself: it hands the text to this process-wide callback
+ * for levels <= max_level.  NULL = silent, except that the reason of a failed trx_create --
+ * whose handle does not survive to be asked -- then goes to stderr.  Called on the thread
+ * that made the API call. */
+enum { TRX_LOG_ERROR = 1, TRX_LOG_WARN = 2, TRX_LOG_INFO = 3, TRX_LOG_RESULT = 4, TRX_LOG_DEBUG = 5 };
+typedef void (*trx_log_fn)(int level, const char *message, void *user);
+void trx_set_log(trx_log_fn fn, void *user, int max_level);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,3 +260,25 @@ def test_depth_hint_is_only_a_hint(tmp_path):
     finally:
         dens[:] = base
         eng.close()
+
+
+def test_messages_go_to_the_callback():
+    """trx_set_log: the library itself never prints; errors and the create summary arrive
+    at the callback with the reference's verbosity levels (flags_tr.h:107-111)."""
+    from transit_amd import engine
+    P = golden("eclipse_small").problem
+    seen = []
+    engine.set_log(lambda lvl, msg: seen.append((lvl, msg)), 3)
+    try:
+        e = Engine(P.static)
+        opts = P.opts
+        old = opts.ethresh
+        opts.ethresh = -1.0
+        with pytest.raises(engine.EngineError):
+            e.run(P.atm, opts)
+        opts.ethresh = old
+        e.close()
+    finally:
+        engine.set_log(None)
+    assert any(lvl == 3 and "co-added groups" in msg for lvl, msg in seen)
+    assert any(lvl == 1 and "ethresh" in msg for lvl, msg in seen)

@@ -88,8 +88,17 @@ struct trx_handle {
 
 namespace {
 
+// process-wide message sink (trx_set_log): the reference's tr_output()/verblevel pair
+struct LogSink { trx_log_fn fn = nullptr; void *user = nullptr; int max_level = 0; };
+LogSink &log_sink() { static LogSink s; return s; }
+void log_msg(int level, const std::string &msg)
+{
+  const LogSink s = log_sink();
+  if (s.fn && level <= s.max_level) s.fn(level, msg.c_str(), s.user);
+}
+
 int fail(trx_handle *h, int code, const std::string &msg)
-{ if (h) h->err = msg; return code; }
+{ if (h) h->err = msg; log_msg(TRX_LOG_ERROR, msg); return code; }
 
 #define HIPCHK(h, call)                                                              \
   do { hipError_t e_ = (call);                                                       \
@@ -742,6 +751,12 @@ const char *trx_strerror(int st)
 
 const char *trx_last_error(const trx_handle *h) { return h ? h->err.c_str() : ""; }
 
+void trx_set_log(trx_log_fn fn, void *user, int max_level)
+{
+  LogSink &s = log_sink();
+  s.fn = fn; s.user = user; s.max_level = max_level;
+}
+
 int trx_create(const trx_static *s, trx_handle **out)
 {
   if (!s || !out) return TRX_E_ARG;
@@ -816,8 +831,19 @@ int trx_create(const trx_static *s, trx_handle **out)
   for (auto &c : h->cia)
     if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs)) ||
         (rc = upload(h, c.d_zt, c.zt)) || (rc = upload(h, c.d_uw, c.uw))) return bail(rc);
-  if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
-  if ((rc = prepare_lines(h, s)) != TRX_OK) { std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); return bail(rc); }
+  // the handle does not survive a failed create, so its error text cannot be asked for later:
+  // without a message callback it goes to stderr
+  auto say = [&]() { if (!log_sink().fn) std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); };
+  if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; say(); return bail(rc); }
+  if ((rc = prepare_lines(h, s)) != TRX_OK) { say(); return bail(rc); }
+  {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "trx_create: %lld lines (%lld in range, %lld co-added groups), %lld wavenumbers [%lld,%lld), "
+                  "Voigt table %dx%d = %lld floats, %zu CIA tables", (long long)s->nlines, (long long)h->stats.nlines_inrange,
+                  (long long)h->ngroups, (long long)s->nwn, (long long)h->lo, (long long)h->hi, s->ndop, s->nlor,
+                  (long long)h->tab_n, h->cia.size());
+    log_msg(TRX_LOG_INFO, buf);
+  }
   *out = h;
   return TRX_OK;
 }

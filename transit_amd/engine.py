@@ -168,5 +168,22 @@ class Engine(CEngine):
             raise EngineError(rc, "trx_run_device", self._last_error())
 
 
+LOG_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
+_log_keep = None
+
+
+def set_log(callback, max_level: int = 3):
+    """Route the library's messages (trx_set_log) to callback(level, text); None = silent."""
+    global _log_keep
+    lib = hip_library()
+    lib.trx_set_log.argtypes = [LOG_FN, C.c_void_p, C.c_int]
+    lib.trx_set_log.restype = None
+    if callback is None:
+        _log_keep = LOG_FN(0)
+    else:
+        _log_keep = LOG_FN(lambda lvl, msg, _u: callback(int(lvl), msg.decode(errors="replace")))
+    lib.trx_set_log(_log_keep, None, int(max_level))
+
+
 def device_count() -> int:
     return int(hip_library().trx_device_count())
