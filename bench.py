@@ -286,15 +286,17 @@ def main():
                                  "9 B per group-layer out) / measured launch time; `traffic` = the PMC-measured HBM "
                                  "bytes per launch.  The reference's own flow (52 B per line-layer) is in "
                                  "ref_flow_GBs: above the HBM peak because a launch covers ~27 layers per line read. "
-                                 "This kernel is bound by the fp64 vector pipe (two exp per line-layer, ~130 VALU "
-                                 "instructions of which ~50 are the exps), see valu_issue_frac_est",
+                                 "This kernel is bound by the fp64 vector pipe (two exp per line-layer; 110 VALU "
+                                 "instructions per line-layer by SQ_INSTS_VALU, ~32 of them the exps), see "
+                                 "valu_issue_frac_est",
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
                          "launches": launches, "ref_flow_GBs": ref_gbs,
                          "ref_flow_bytes_per_launch": ref[dom] / launches},
         }
         if dom == "k_group_sweep" and kern[dom] > 0:
-            # ~130 wave instructions per line-layer (ISA count), 4 cycles each on a 16-lane SIMD
-            out["roofline"]["valu_issue_frac_est"] = (130.0 * L * R / 64.0) / (kern[dom] * 1e-3) / (1024 * 2.4e9 / 4.0)
+            # 110 wave instructions per line-layer (SQ_INSTS_VALU x 64 / line-layers), 4 cycles each
+            # on a 16-lane SIMD, 1024 SIMDs at 2.4 GHz
+            out["roofline"]["valu_issue_frac_est"] = (110.0 * L * R / 64.0) / (kern[dom] * 1e-3) / (1024 * 2.4e9 / 4.0)
         if dom == "k_accumulate" and ach > HBM_PEAK_GBS:
             # wide-profile regime (fine grids): neighbouring lines re-read the same profile rows, which
             # therefore come out of L1/L2 -- the 4 B per accumulated bin never reach HBM and an HBM
