@@ -69,3 +69,27 @@ def test_gpu_follows_the_reference_through_three_reloads():
     # intended algorithm); the reference's own answer is noisy at the 1e-4 level here
     for got, ref in zip(run_sequence(Engine, CASE_T), EXPECT_T):
         assert rel_err(got, ref) < 2e-3
+
+
+@pytest.mark.gpu
+def test_swig_module_lookalike_follows_the_reference():
+    """transit_amd.transit_module = the reference's `transit_module` (transit.i:97-105): same
+    function names and signatures, driven the way BART drives it."""
+    import transit_amd.transit_module as trm
+    old = os.getcwd()
+    os.chdir(CASE)
+    try:
+        argv = ["transit", "-c", "case.cfg"]
+        trm.transit_init(len(argv), argv)
+        n = trm.get_no_samples()
+        wn = trm.get_waveno_arr(n)
+        assert n == EXPECT[0].size and wn.shape == (n,) and np.all(np.diff(wn) > 0)
+        for vec, ref in zip(INPUTS, EXPECT):
+            out = trm.run_transit(vec, n)
+            assert out.shape == (n,) and rel_err(out, ref) < 1e-9
+        trm.free_memory()
+        with pytest.raises(RuntimeError):
+            trm.get_no_samples()
+    finally:
+        os.chdir(old)
+        trm.free_memory()
