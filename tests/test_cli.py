@@ -55,3 +55,32 @@ def test_cli_writes_the_reference_spectrum_file(tmp_path, case):
     r = np.loadtxt(os.path.join(GOLDEN, case, "toomuch.dat"), comments="#", skiprows=2)
     assert np.array_equal(g[:, 3], r[:, 3])
     assert rel_err(g[:, 1], r[:, 1]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_cli_savefiles_dumps_match_the_reference_dumps(tmp_path):
+    """`savefiles yes` (tau.c:180-190, 311-335): tau.dat, CIA.dat and mol_extion.dat in the
+    reference's formats; the goldens hold the reference's own dumps of the same run."""
+    case = "eclipse_small"
+    exe = build.build_cli() or build.lib_path("transit_hip")
+    work = tmp_path / case
+    shutil.copytree(os.path.join(GOLDEN, case), work)
+    for f in ("spectrum.dat", "toomuch.dat", "tau.dat", "CIA.dat", "mol_extion.dat"):
+        if os.path.exists(work / f):
+            os.remove(work / f)
+    p = subprocess.run([exe, "-c", "case.cfg", "--savefiles", "yes"], cwd=work, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    for name, key in (("tau.dat", "wavenumber"), ("CIA.dat", "wavenumber"), ("mol_extion.dat", "radius")):
+        ref_path = os.path.join(GOLDEN, case, name)
+        got_lines = open(work / name).read().split("\n")
+        ref_lines = open(ref_path).read().split("\n")
+        assert got_lines[:4] == ref_lines[:4], name               # header block
+        assert len(got_lines) == len(ref_lines), name
+        gk, gv = ol.read_rows_dump(work / name, key)
+        rk, rv = ol.read_rows_dump(ref_path, key)
+        assert np.array_equal(gk, rk), name                       # row keys: same text
+        if name == "mol_extion.dat":                              # the reference leaves unswept layers at zero
+            sw = np.any(rv != 0, axis=1)
+            assert rel_err(gv[sw], rv[sw]) < 1e-8
+        else:
+            assert rel_err(gv, rv) < 1e-8, name

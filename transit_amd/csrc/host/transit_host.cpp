@@ -927,4 +927,55 @@ int trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *la
   return TRX_OK;
 }
 
+// `savefiles yes` (tau.c:180-190, 311-335): the reference's dumps of the intermediates, in its
+// formats and under its fixed file names in the working directory -- tau.dat (savetau,
+// tau.c:491-515), CIA.dat (saveCIA, :420-446), mol_extion.dat (savemolExtion, :386-416).
+// Inputs in the layouts of trx_debug: e, e_cs [layer][wn]; tau [wn][height].
+// (total/cloud/scatt_extion.dat are not written: the ABI does not export those arrays.)
+int trh_write_dumps(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const char *dir)
+{
+  if (!p) return TRX_E_ARG;
+  const int64_t nr = (int64_t)p->rad.size(), nw = p->nwn;
+  const std::string base = dir ? std::string(dir) : p->base_dir;
+  auto wn_at = [&](int64_t w) { return p->wn_i + (double)w * p->wn_d; };
+  auto row = [&](FILE *f, const double *v, int64_t n, int64_t stride) {          // print1dArrayDouble, tau.c:361-367
+    for (int64_t k = 0; k < n; k++) std::fprintf(f, "%-20.10g", v[k * stride]);
+    std::fprintf(f, "\n");
+  };
+  if (tau) {
+    FILE *f = std::fopen(join_path(base, "tau.dat").c_str(), "w");
+    if (!f) return TRX_E_ARG;
+    std::fprintf(f, "\n# 2D optical depth\n# tau [wn][rad]; wn[0]=min(wn); rad[0]=top (min(p))\n\n");
+    for (int64_t w = 0; w < nw; w++) {                                            // print2dArrayDouble, tau.c:371-382
+      std::fprintf(f, "wavenumber: %-20.10g\n", wn_at(w));
+      row(f, tau + w * nr, nr, 1);
+      std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+  }
+  if (e_cs) {
+    FILE *f = std::fopen(join_path(base, "CIA.dat").c_str(), "w");
+    if (!f) return TRX_E_ARG;
+    std::fprintf(f, "\n# 2D CIA extinction\n# e_cs [wn][rad]; wn[0]=min(wn); row[0]=bottom (max(p))\n\n");
+    for (int64_t w = 0; w < nw; w++) {
+      std::fprintf(f, "wavenumber: %-20.10g\n", wn_at(w));
+      row(f, e_cs + w, nr, nw);
+      std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+  }
+  if (e) {
+    FILE *f = std::fopen(join_path(base, "mol_extion.dat").c_str(), "w");
+    if (!f) return TRX_E_ARG;
+    std::fprintf(f, "\n# mol-line extinction\n# e [rad][wn]; rad[0]=bottom (max(p)); wn[0]=min(wn)\n\n");
+    for (int64_t r = 0; r < nr; r++) {
+      std::fprintf(f, "radius: %-20.10g\n", p->rad[(size_t)r]);
+      row(f, e + r * nw, nw, 1);
+      std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+  }
+  return TRX_OK;
+}
+
 }  // extern "C"

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "transit_hip.h"
+#include <string>
 #include "transit_host.h"
 
 static double now_s()
@@ -58,14 +59,17 @@ int main(int argc, char **argv)
 
   const int64_t nwn = trh_nwn(P);
   const int nr = trh_atm(P)->nlayer;
-  std::vector<double> spectrum((size_t)nwn), tau;
+  std::vector<double> spectrum((size_t)nwn), tau, e, ecs;
   std::vector<int64_t> last;
   trx_debug dbg{};
   const bool want_toomuch = trh_option(P, "outtoomuch") != nullptr;
-  if (want_toomuch) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
+  const char *sf = trh_option(P, "savefiles");
+  const bool want_dumps = sf && std::string(sf) == "yes";                       // argum.c:456-470
+  if (want_toomuch || want_dumps) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
+  if (want_dumps) { e.resize((size_t)nwn * nr); ecs.resize((size_t)nwn * nr); dbg.e = e.data(); dbg.e_cs = ecs.data(); }
 
   t0 = now_s();
-  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), want_toomuch ? &dbg : nullptr);
+  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), (want_toomuch || want_dumps) ? &dbg : nullptr);
   if (rc != TRX_OK) {
     std::fprintf(stderr, "transit_hip: trx_run failed: %s (%s)\n", trx_strerror(rc), trx_last_error(h));
     trx_destroy(h); trh_free(P); return EXIT_FAILURE;
@@ -78,6 +82,8 @@ int main(int argc, char **argv)
                 now_s() - t0, (long long)s.nlines_inrange, (long long)s.nadd, (long long)s.layers_swept, nr, s.ms_run_total);
   }
   if (want_toomuch) trh_write_toomuch(P, tau.data(), last.data(), nullptr);
+  if (want_dumps && trh_write_dumps(P, e.data(), ecs.data(), tau.data(), nullptr) != TRX_OK)
+    std::fprintf(stderr, "transit_hip: cannot write the savefiles dumps\n");
   rc = trh_write_spectrum(P, spectrum.data(), nullptr);
   if (rc != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the spectrum file\n");
   trx_destroy(h);
