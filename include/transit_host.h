@@ -57,6 +57,8 @@ int  trh_install_opacity(trh_problem *p, const double *o /* [nv][nslot][nwn] */)
 /* writers in the reference's formats */
 int  trh_write_spectrum(const trh_problem *p, const double *spectrum, const char *path /* NULL = cfg outspec */);
 int  trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *last, const char *path);
+/* per-angle intensities (eclipse geometry), printintens eclipse.c:293-350; intens = trx_debug.intens */
+int  trh_write_intens(const trh_problem *p, const double *intens, const char *path /* NULL = cfg outintens */);
 /* `savefiles yes`: tau.dat, CIA.dat, mol_extion.dat in the reference's dump formats (tau.c:386-515),
  * from the trx_debug arrays (any of them may be NULL); dir NULL = next to the cfg */
 int  trh_write_dumps(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const char *dir);

@@ -25,11 +25,12 @@ REF = os.path.join(ROOT, "oracle", "_ref", "transit")
 REF_REENTRY = os.path.join(ROOT, "oracle", "_ref", "transit_reentry")   # oracle/ref_reentry_main.c
 
 KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "cia_h2he.dat",
-        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat"]
+        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "intens.dat"]
 
 CASES = {
     # demo-shaped emission run, narrow band
-    "eclipse_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="eclipse"),
+    "eclipse_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="eclipse",
+                          extra={"outintens": "intens.dat"}),      # + the per-angle intensity file (printintens)
     # transmission geometry, two CIA tables
     "transit_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="transit", ncia=2,
                           seed=4321),

@@ -15,8 +15,9 @@ def _run_cli(tmp_path, case):
     exe = build.build_cli() or build.lib_path("transit_hip")
     work = tmp_path / case
     shutil.copytree(os.path.join(GOLDEN, case), work)
-    for f in ("spectrum.dat", "toomuch.dat"):
-        os.remove(work / f)
+    for f in ("spectrum.dat", "toomuch.dat", "intens.dat"):
+        if os.path.exists(work / f):
+            os.remove(work / f)
     p = subprocess.run([exe, "-c", "case.cfg"], cwd=work, capture_output=True, text=True, timeout=300)
     return work, p
 
@@ -84,3 +85,17 @@ def test_cli_savefiles_dumps_match_the_reference_dumps(tmp_path):
             assert rel_err(gv[sw], rv[sw]) < 1e-8
         else:
             assert rel_err(gv, rv) < 1e-8, name
+
+
+@pytest.mark.gpu
+def test_cli_outintens_matches_the_reference_file(tmp_path):
+    """--outintens (printintens, eclipse.c:293-350): wavelength + one intensity column per angle."""
+    work, p = _run_cli(tmp_path, "eclipse_small")
+    assert p.returncode == 0, p.stderr
+    ref_path = os.path.join(GOLDEN, "eclipse_small", "intens.dat")
+    got_txt = open(work / "intens.dat").read().split("\n")
+    ref_txt = open(ref_path).read().split("\n")
+    assert got_txt[:2] == ref_txt[:2] and len(got_txt) == len(ref_txt)       # two header lines, same row count
+    got, ref = np.loadtxt(work / "intens.dat", comments="#"), np.loadtxt(ref_path, comments="#")
+    assert np.array_equal(got[:, 0], ref[:, 0])
+    assert rel_err(got[:, 1:], ref[:, 1:]) < 2e-8

@@ -51,3 +51,16 @@ def test_counters(run):
     assert st["neval"] > 0 and st["sum_bins"] > 0
     if g.name == "coadd_thresh":
         assert st["nadd"] > 100 and st["nskip"] > 100        # the case must exercise both paths
+
+
+def test_per_angle_intensities_match_the_reference_file():
+    """eclipse_intens (eclipse.c:118-160) per ray angle, against the reference's --outintens file."""
+    import os
+    from cases import GOLDEN
+    g = golden("eclipse_small")
+    eng = ol.OracleEngine(g.problem.static)
+    out = eng.run(g.problem.atm, g.problem.opts, debug=True)
+    eng.close()
+    ref = np.loadtxt(os.path.join(GOLDEN, "eclipse_small", "intens.dat"), comments="#")
+    assert ref.shape == (g.problem.nwn, 1 + g.problem.opts.nangles)
+    assert rel_err(out["intens"].T, ref[:, 1:]) < 2e-8

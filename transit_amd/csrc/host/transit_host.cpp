@@ -927,6 +927,30 @@ int trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *la
   return TRX_OK;
 }
 
+// printintens (eclipse.c:293-350): wavelength + one column per ray angle
+int trh_write_intens(const trh_problem *p, const double *intens, const char *path)
+{
+  if (!p || !intens) return TRX_E_ARG;
+  std::string f = path ? std::string(path) : join_path(p->base_dir, str(*p, "outintens"));
+  if (f.empty() || f[0] == '-') return TRX_OK;               // eclipse.c:311-318: no file requested
+  FILE *out = std::fopen(f.c_str(), "w");
+  if (!out) return TRX_E_ARG;
+  const int an = p->opts.nangles;
+  std::fprintf(out, "#wvl %*s", 10, " ");
+  for (int i = 0; i < an; i++) std::fprintf(out, "I[%4.1lf deg]%*s", p->opts.angles_deg[i], 7, " ");
+  std::fprintf(out, "\n#[um]%*s", 10, " ");
+  for (int i = 0; i < an; i++) std::fprintf(out, "[erg/s/cm/sr]%*s", 5, " ");
+  std::fprintf(out, "\n");
+  for (int64_t w = 0; w < p->nwn; w++) {
+    const double wn = p->wn_i + (double)w * p->wn_d;
+    std::fprintf(out, "%-15.10g", 1e4 / (wn / 1.0));                     // wns.fct is 1 after makewnsample
+    for (int i = 0; i < an; i++) std::fprintf(out, "%-18.9g", intens[(size_t)i * p->nwn + w]);
+    std::fprintf(out, "\n");
+  }
+  std::fclose(out);
+  return TRX_OK;
+}
+
 // `savefiles yes` (tau.c:180-190, 311-335): the reference's dumps of the intermediates, in its
 // formats and under its fixed file names in the working directory -- tau.dat (savetau,
 // tau.c:491-515), CIA.dat (saveCIA, :420-446), mol_extion.dat (savemolExtion, :386-416).

@@ -67,9 +67,12 @@ int main(int argc, char **argv)
   const bool want_dumps = sf && std::string(sf) == "yes";                       // argum.c:456-470
   if (want_toomuch || want_dumps) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
   if (want_dumps) { e.resize((size_t)nwn * nr); ecs.resize((size_t)nwn * nr); dbg.e = e.data(); dbg.e_cs = ecs.data(); }
+  std::vector<double> intens;
+  const bool want_intens = trh_option(P, "outintens") != nullptr && trh_opts(P)->solution == TRX_SOL_ECLIPSE;
+  if (want_intens) { intens.resize((size_t)nwn * trh_opts(P)->nangles); dbg.intens = intens.data(); }
 
   t0 = now_s();
-  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), (want_toomuch || want_dumps) ? &dbg : nullptr);
+  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), (want_toomuch || want_dumps || want_intens) ? &dbg : nullptr);
   if (rc != TRX_OK) {
     std::fprintf(stderr, "transit_hip: trx_run failed: %s (%s)\n", trx_strerror(rc), trx_last_error(h));
     trx_destroy(h); trh_free(P); return EXIT_FAILURE;
@@ -82,6 +85,7 @@ int main(int argc, char **argv)
                 now_s() - t0, (long long)s.nlines_inrange, (long long)s.nadd, (long long)s.layers_swept, nr, s.ms_run_total);
   }
   if (want_toomuch) trh_write_toomuch(P, tau.data(), last.data(), nullptr);
+  if (want_intens) trh_write_intens(P, intens.data(), nullptr);
   if (want_dumps && trh_write_dumps(P, e.data(), ecs.data(), tau.data(), nullptr) != TRX_OK)
     std::fprintf(stderr, "transit_hip: cannot write the savefiles dumps\n");
   rc = trh_write_spectrum(P, spectrum.data(), nullptr);
