@@ -1063,6 +1063,12 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if ((rc = upload(h, h->d_og_layer, og_layer)) || (rc = upload(h, h->d_og_itemp, og_itemp))) return rc;
   }
 
+  // an error return below must not leave work of this run in flight on the side streams
+  // (the next run would overwrite its inputs underneath it)
+  struct Drain {
+    trx_handle *h; bool armed = true;
+    ~Drain() { if (armed) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->stream); } }
+  } drain{h};
   // ---- inputs are on the device: release the other streams -----------------------------
   HIPCHK(h, hipEventRecord(h->ev_inputs, st));
   HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
@@ -1217,6 +1223,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   break;
   }
 
+  drain.armed = false;                     // everything was joined into the main stream and waited for
   trx_stats &S = h->stats;
   S.layers_swept = flags_host[2];
   h->hint_layers = flags_host[4];
