@@ -41,6 +41,12 @@ CASES = {
     "cloud_scatter": dict(nlines=2000, wnlow=3000, wnhigh=3040, nlayers=40, solution="transit",
                           seed=7, line_margin=3.0,
                           extra={"cloudtop": "-2.0", "scattering": "1.5"}),
+    # polarizability scattering (scattering flag 2, extinction.c:617-621) in emission geometry.
+    # (The parametrised cloud types opa/B17/F18/P19 -- cloud flags 2-5 -- cannot be pinned: the
+    # reference accumulates their mean density into an uninitialised array, tau.c:129,203, and
+    # this build of it returns NaN for all four.)
+    "scat_polar": dict(nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution="eclipse", seed=8,
+                       extra={"scattering": "polar"}),
     # opaque-disc modulation level and a transparent planet, odd layer count
     "transit_modm1": dict(nlines=4000, wnlow=4000, wnhigh=4030, nlayers=31, solution="transit", seed=11,
                           toomuch=5.0, extra={"modlevel": "-1"}),
