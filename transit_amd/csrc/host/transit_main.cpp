@@ -24,7 +24,8 @@ int main(int argc, char **argv)
 {
   char err[512] = {0};
   trh_problem *P = nullptr;
-  double t0 = now_s();
+  const double t_start = now_s();
+  double t0 = t_start;
   int rc = trh_load(argc, argv, &P, err, sizeof(err));
   if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: %s (%s)\n", err, trx_strerror(rc)); return EXIT_FAILURE; }
   const char *verb = trh_option(P, "verb");
@@ -90,6 +91,7 @@ int main(int argc, char **argv)
     std::fprintf(stderr, "transit_hip: cannot write the savefiles dumps\n");
   rc = trh_write_spectrum(P, spectrum.data(), nullptr);
   if (rc != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the spectrum file\n");
+  if (verblevel > 3) std::printf("Check point: 00 - 15 outputs written:  wall since start = %.4f sec.\n", now_s() - t_start);
   trx_destroy(h);
   trh_free(P);
   return rc == TRX_OK ? EXIT_SUCCESS : EXIT_FAILURE;
