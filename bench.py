@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--wnosamp", type=int, default=2160)
     ap.add_argument("--wndelt", type=float, default=1.0)
     ap.add_argument("--layer-chunk", type=int, default=0)
+    ap.add_argument("--solution", choices=("eclipse", "transit"), default="eclipse")
+    ap.add_argument("--ncia", type=int, default=1)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: weak = every GPU gets its own CH4-demo-sized slice (band and line list grow with N); "
                          "strong = the one CH4-demo run split N ways")
@@ -78,8 +80,8 @@ def make_workload(args, tag, nlines, verb=2, wnhigh=None, unique=True):
         tag, nlines, args.layers, os.getpid() if unique else os.environ.get("MASTER_PORT", "0")))
     synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=wnhigh or args.wnhigh, wndelt=args.wndelt,
                     wnosamp=args.wnosamp,
-                    nlayers=args.layers, solution="eclipse", toomuch=10.0, ethresh=1e-50, nwidth=20.0,
-                    raygrid="0 20 40 60 80", ncia=1, seed=1234, extra={"verb": verb})
+                    nlayers=args.layers, solution=args.solution, toomuch=10.0, ethresh=1e-50, nwidth=20.0,
+                    raygrid="0 20 40 60 80", ncia=args.ncia, seed=1234, extra={"verb": verb})
     return d
 
 
@@ -258,9 +260,11 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]%s): %g-%g cm-1 @%g cm-1, wnosamp %d, "
-                                   "eclipse, 5 angles, H2-H2 CIA" % (
+                                   "%s, H2-H2%s CIA" % (
                                        ", band and line list x%d: one demo-sized slice per GPU" % grow if grow > 1 else "",
-                                       args.wnlow, wnhigh, args.wndelt, args.wnosamp),
+                                       args.wnlow, wnhigh, args.wndelt, args.wnosamp,
+                                       "eclipse, 5 angles" if args.solution == "eclipse" else "transit (slant paths)",
+                                       " + H2-He" if args.ncia > 1 else ""),
                        "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
                        "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
