@@ -666,7 +666,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
       long long pm = 0;
       for (int b = 0; b < niso; b++)
         if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)(r_top - c) * niso + b]);
-      if ((2 * pm) / h->osamp + 1 >= 64) wide_mask |= 1u << c;
+      if ((2 * pm) / h->osamp + 1 >= 64) wide_mask |= 1u << c;   // measured: 16 or 32 here is 4x slower at configs[2] size, 128/256 no better
     }
     A.skip_mask = wide_mask;
     if (M.prof) HIPCHK(h, hipMemsetAsync(h->d_part3.p, 0, 24 * (size_t)nc_max * tblocks, st));
