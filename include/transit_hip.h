@@ -253,6 +253,16 @@ int  trx_comm_unique_id(void *id_out /* TRX_COMM_ID_BYTES */);
 int  trx_comm_create(const void *id, int nranks, int rank, int device, void **comm_out);
 void trx_comm_destroy(void *comm);
 
+/* Sharded job without RCCL: the two exchanges of the path (the per-step maxima + rays-open
+ * flag, and the end-of-run status maxima) go through a host function instead -- the stream is
+ * drained, `n` doubles are handed to `fn`, which must return their element-wise maximum over
+ * all ranks in place (blocking, collective: every rank calls it the same number of times).
+ * For transports other than RCCL (MPI, gloo, ...) and for testing N ranks on fewer GPUs;
+ * slower than the in-stream all-reduce by two stream drains per step.  Replaces trx_static.comm
+ * (which must then be NULL); call it right after trx_create.  fn = NULL switches it off. */
+typedef int (*trx_allreduce_max_fn)(double *values, int n, void *user);
+int trx_set_host_allreduce(trx_handle *h, trx_allreduce_max_fn fn, void *user);
+
 const char *trx_strerror(int status);
 const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */
 

@@ -230,13 +230,15 @@ def test_many_isotopes_against_oracle(tmp_path):
     assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9
 
 
-def test_depth_hint_is_only_a_hint(tmp_path):
+@pytest.mark.parametrize("solution,scales", [("eclipse", (1.0, 0.02, 1.0, 30.0, 0.02)),
+                                             ("transit", (1.0, 0.3, 1.0, 3.0, 0.3))])
+def test_depth_hint_is_only_a_hint(tmp_path, solution, scales):
     """A handle plans its steps from the depth the previous spectrum reached.  When the next
     atmosphere is more transparent (rays go deeper) or more opaque (they stop earlier) the
     result must be the one a fresh handle gives."""
     d = str(tmp_path / "hint")
     synth.make_case(d, nlines=30_000, wnlow=2500, wnhigh=2700, wndelt=1.0, wnosamp=2160, nlayers=80,
-                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=5)
+                    solution=solution, toomuch=10.0, ethresh=1e-50, seed=5)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
     a = P.atm
     dens = np.ctypeslib.as_array(a.density, shape=(P.static.nmol * P.nlayer,))
@@ -251,7 +253,7 @@ def test_depth_hint_is_only_a_hint(tmp_path):
     eng = Engine(P.static)
     try:
         seen = []
-        for scale in (1.0, 0.02, 1.0, 30.0, 0.02):
+        for scale in scales:
             dens[:] = base * scale
             got = eng.run(P.atm, P.opts, debug=("last", "tau"))
             ref = fresh()

@@ -1,0 +1,22 @@
+"""A real sharded job: N processes, N shards, one (shared) GPU, exchanges over the host
+transport.  See tests/multirank_gpu_worker.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,scales", [("coadd_thresh", 2, "1,1,0.03,1,20,0.03"),
+                                               ("transit_small", 3, "1,1,0.3,1,3,0.3")])
+def test_sharded_job_matches_the_unsharded_handle(case, world, scales):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(HERE, "multirank_gpu_worker.py"), case, scales]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "MULTIRANK OK" in p.stdout, p.stdout[-3000:]

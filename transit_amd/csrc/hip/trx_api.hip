@@ -71,6 +71,8 @@ struct trx_handle {
   LinesDev L{};
   std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
   void *comm = nullptr; int nranks = 1, rank = 0;
+  trx_allreduce_max_fn ar_fn = nullptr; void *ar_user = nullptr;   // host transport instead of RCCL
+  bool sharded() const { return comm != nullptr || ar_fn != nullptr; }
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw; };
   std::vector<Cia> cia;
@@ -634,8 +636,17 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
                        M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
   }
   if (M.use_comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
-    if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, sts) != ncclSuccess)
-      return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
+    if (h->comm) {
+      if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, sts) != ncclSuccess)
+        return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
+    } else {
+      double buf[kMaxChunk + 1];
+      HIPCHK(h, hipMemcpyAsync(buf, M.ar_cur, sizeof buf, hipMemcpyDeviceToHost, sts));
+      HIPCHK(h, hipStreamSynchronize(sts));
+      if (h->ar_fn(buf, kMaxChunk + 1, h->ar_user) != 0) return fail(h, TRX_E_HIP, "host all-reduce (layer maxima) failed");
+      HIPCHK(h, hipMemcpyAsync(M.ar_cur, buf, sizeof buf, hipMemcpyHostToDevice, sts));
+      HIPCHK(h, hipStreamSynchronize(sts));          // buf leaves scope
+    }
   }
   if (sp && sp->end(sts)) return fail(h, TRX_E_HIP, "event");
   if (M.ev_sweep) {
@@ -750,6 +761,15 @@ const char *trx_strerror(int st)
 }
 
 const char *trx_last_error(const trx_handle *h) { return h ? h->err.c_str() : ""; }
+
+int trx_set_host_allreduce(trx_handle *h, trx_allreduce_max_fn fn, void *user)
+{
+  if (!h) return TRX_E_ARG;
+  if (fn && h->comm) return fail(h, TRX_E_ARG, "the handle already has an RCCL communicator");
+  h->ar_fn = fn; h->ar_user = user;
+  h->hint_layers = 0;                       // the next spectrum plans like a first one on every rank
+  return TRX_OK;
+}
 
 void trx_set_log(trx_log_fn fn, void *user, int max_level)
 {
@@ -994,7 +1014,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // optical depth of step c (a latency chain on a few waves) is integrated on the main stream.
   // The layer maxima get one slot per step (the optical-depth kernel no longer resets them);
   // the sharded (communicator) path stays in one stream.
-  const bool pipelined = !h->comm && !h->has_grid;
+  const bool pipelined = !h->sharded() && !h->has_grid;
   const size_t sg_stride = gr_b * nc_max;
   const size_t ar_slots = pipelined ? (size_t)nr + 2 : 2;
   if ((rc = ensure(h, h->d_SG, sizeof(double) * sg_stride)) ||
@@ -1123,7 +1143,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       SweepMode M{};
       M.eager = eager; M.prof = prof; M.ethresh = o->ethresh; M.chunk_index = nchunks;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
-      M.d_e = h->d_e.as<double>(); M.use_comm = h->comm != nullptr;
+      M.d_e = h->d_e.as<double>(); M.use_comm = h->sharded();
       M.ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
       M.ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
       if (pipelined) {
@@ -1179,6 +1199,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
 
   // ---- spectrum ---------------------------------------------------------------
+  HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes it a second time)
   if (o->solution == TRX_SOL_ECLIPSE) {
     EmisArgs E{};
     E.nr = nr; E.nang = o->nangles; E.nsh = nsh; E.lo = h->lo; E.wn_i = h->wn_i; E.wn_d = h->wn_d; E.wn_fct = o->wn_fct;
@@ -1212,6 +1233,15 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     // rays still open (flags[0]) and deepest stopping height (flags[4]) become job-wide maxima
     if (rccl().AllReduce(h->d_flags.p, h->d_flags.p, 8, ncclInt32, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
       return fail(h, TRX_E_HIP, "ncclAllReduce(flags) failed");
+  } else if (h->ar_fn) {
+    int fl[8]; double fd[8];
+    HIPCHK(h, hipMemcpyAsync(fl, h->d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (int k = 0; k < 8; k++) fd[k] = fl[k];
+    if (h->ar_fn(fd, 8, h->ar_user) != 0) return fail(h, TRX_E_HIP, "host all-reduce (status) failed");
+    for (int k = 0; k < 8; k++) fl[k] = (int)fd[k];
+    HIPCHK(h, hipMemcpyAsync(h->d_flags.p, fl, sizeof fl, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
   }
   HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));

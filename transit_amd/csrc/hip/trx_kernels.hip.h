@@ -1302,6 +1302,9 @@ void k_modulation(ModArgs M)
   if (w >= M.nsh) return;
   const int nr = M.nr;
   int last = M.last[w];
+  // a ray that is still descending (only possible in the provisional spectrum of a run that
+  // stopped at the previous run's depth and will go on): nothing to integrate yet
+  if (last < 0) { M.out[w] = 0.0; return; }
   const double *tw = M.tau + w;                           // tw[i*nsh] = tau[i][w]
   if (M.modlevel == -1) {
     const double tl = tw[(long long)last * M.nsh];

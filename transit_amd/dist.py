@@ -66,6 +66,17 @@ def _torch_broadcast(device: int):
     return bc
 
 
+def torch_allreduce_max():
+    """Host transport for Engine.set_host_allreduce on top of torch.distributed (any backend
+    that reduces CPU tensors, e.g. gloo): for jobs without RCCL and for tests."""
+    def fn(values: np.ndarray):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(values)          # shares memory with the engine's buffer
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return fn
+
+
 def padded_len(nwn: int, world: int) -> int:
     """Collectives want equal counts: every rank contributes ceil(nwn/world) values."""
     return -(-nwn // world)
