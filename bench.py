@@ -51,6 +51,10 @@ def parse():
                     help="N>1: weak = every GPU gets its own CH4-demo-sized slice (band and line list grow with N); "
                          "strong = the one CH4-demo run split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 on FEWER GPUs (ranks share devices): gloo instead of RCCL -- the engine's "
+                         "exchanges go over the host transport and the gather through host memory. "
+                         "Exercises the multi-rank code path; its timing means nothing")
     ap.add_argument("--comm-single", action="store_true",
                     help="N=1 only: run through a 1-rank RCCL communicator (the code path every rank of an N>1 job takes)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = full workload)")
@@ -142,11 +146,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse:
+            local = local % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if (world > 1 and args.rehearse) else dev       # where collectives run
 
     from transit_amd.host import Problem
     from transit_amd.engine import Engine
@@ -174,24 +183,26 @@ def main():
     st = P.static
     st.device = local
     comm = None
-    if world > 1 or args.comm_single:       # in-stream all-reduce of the per-layer line-strength maxima (engine side)
+    if (world > 1 and not args.rehearse) or args.comm_single:   # in-stream all-reduce of the layer maxima (engine side)
         comm = tdist.create_comm(world, rank, local)
         st.comm, st.nranks, st.rank = comm, world, rank
     t0 = time.time()
     eng = Engine(st)
     t_create = time.time() - t0
+    if world > 1 and args.rehearse:
+        eng.set_host_allreduce(tdist.torch_allreduce_max())
     opts = P.opts
     opts.layer_chunk = args.layer_chunk
     opts.profile = 0
 
     mpad = tdist.padded_len(nwn, world)
     spec_local = torch.zeros(mpad, dtype=torch.float64, device=dev)      # slice + padding to equal counts
-    gathered = torch.zeros(mpad * world, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros(mpad * world, dtype=torch.float64, device=cdev) if world > 1 else None
 
     def step():
         eng.run_device(P.atm, opts, spec_local.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, spec_local)   # the single RCCL gather of the path
+        if world > 1:       # the single gather of the path (RCCL; host memory when rehearsing)
+            dist.all_gather_into_tensor(gathered, spec_local if cdev == dev else spec_local.cpu())
 
     def fence():
         if world > 1:
@@ -207,7 +218,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = 1e3 * elapsed / args.steps
@@ -219,10 +230,11 @@ def main():
     stats = eng.stats()
     layers_needed = int(r["last"].max()) + 1
     if world > 1:
-        t = torch.tensor([layers_needed], dtype=torch.int64, device=dev)
+        t = torch.tensor([layers_needed], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         layers_needed = int(t.item())
-        full = tdist.gather_spectrum(spec_local, nwn, world, rank, out=gathered).cpu().numpy()
+        full = tdist.gather_spectrum(spec_local if cdev == dev else spec_local.cpu(), nwn, world, rank,
+                                     out=gathered).cpu().numpy()
     else:
         full = spec_local[: hi - lo].cpu().numpy()
 
