@@ -46,7 +46,7 @@ struct trx_handle {
   // stream4: the line sweep (strengths, sticky index, accumulation) of step c+1 runs while
   // `stream` integrates the optical depth of step c; ev_ac[c] = step c accumulated
   hipStream_t stream4 = nullptr;
-  std::vector<hipEvent_t> ev_ac;
+  std::vector<hipEvent_t> ev_ac, ev_tau;     // ev_tau[c] = optical depth of step c done (sharded: its flag is staged)
   hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr;
   std::string err;
 
@@ -586,6 +586,7 @@ struct SweepMode {
   // strengths run on st_sweep; sticky index and accumulation on st_acc after ev_sweep
   // (null: the handle's stream, no event needed)
   hipStream_t st_sweep = nullptr, st_acc = nullptr; hipEvent_t ev_sweep = nullptr;
+  hipEvent_t ev_before_allreduce = nullptr;          // sharded + two streams: previous step's flag is staged
 };
 
 int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const int32_t *d_npre, const int32_t *psmax,
@@ -636,6 +637,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
                        M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
   }
   if (M.use_comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
+    if (M.ev_before_allreduce) HIPCHK(h, hipStreamWaitEvent(sts, M.ev_before_allreduce, 0));
     if (h->comm) {
       if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, sts) != ncclSuccess)
         return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
@@ -875,6 +877,7 @@ void trx_destroy(trx_handle *h)
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream4) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamDestroy(h->stream4); }
   for (auto e : h->ev_ac) (void)hipEventDestroy(e);
+  for (auto e : h->ev_tau) (void)hipEventDestroy(e);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1013,8 +1016,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // Two streams: the line sweep of step c+1 (saturates the machine) runs on stream4 while the
   // optical depth of step c (a latency chain on a few waves) is integrated on the main stream.
   // The layer maxima get one slot per step (the optical-depth kernel no longer resets them);
-  // the sharded (communicator) path stays in one stream.
-  const bool pipelined = !h->sharded() && !h->has_grid;
+  // A sharded job does the same; there the optical-depth kernel of step c stages its
+  // rays-open flag in slot c+1 and the all-reduce of step c+1 waits for it (ev_tau).
+  const bool pipelined = !h->has_grid;
   const size_t sg_stride = gr_b * nc_max;
   const size_t ar_slots = pipelined ? (size_t)nr + 2 : 2;
   if ((rc = ensure(h, h->d_SG, sizeof(double) * sg_stride)) ||
@@ -1029,9 +1033,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     return rc;
   if (pipelined)
     while ((int)h->ev_ac.size() < nr + 1) {
-      hipEvent_t e1;
-      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
-      h->ev_ac.push_back(e1);
+      hipEvent_t e1, e2;
+      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+      h->ev_ac.push_back(e1); h->ev_tau.push_back(e2);
     }
   if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
     return rc;
@@ -1049,6 +1054,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
   if (pipelined) {   // one slot of layer maxima per step, all zero
     HIPCHK(h, hipMemsetAsync(h->d_arbuf.p, 0, sizeof(double) * ar_slots * (kMaxChunk + 1), st));
+    if (h->sharded()) {
+      // rays-open flags: slot 0 (all-reduced with the first step's maxima) and the last slot,
+      // which stands in as "the step before the first" for the first sweep's gate
+      static const double one = 1.0;
+      double *a = h->d_arbuf.as<double>();
+      HIPCHK(h, hipMemcpyAsync(a + kMaxChunk, &one, sizeof one, hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipMemcpyAsync(a + (ar_slots - 1) * (kMaxChunk + 1) + kMaxChunk, &one, sizeof one, hipMemcpyHostToDevice, st));
+    }
   } else {           // all-reduce staging: maxima 0, "rays still open" flags 1
     static const std::vector<double> ar0 = [] { std::vector<double> v(2 * (kMaxChunk + 1), 0.0); v[kMaxChunk] = 1.0; v[2 * kMaxChunk + 1] = 1.0; return v; }();
     HIPCHK(h, hipMemcpyAsync(h->d_arbuf.p, ar0.data(), ar0.size() * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1147,12 +1160,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       M.ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
       M.ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
       if (pipelined) {
-        // maxima of step c into slot c; the optical-depth kernel must not touch the slots
-        // (its staging pointer goes to a scratch slot, the last one)
-        M.ar_cur = h->d_arbuf.as<double>() + (size_t)nchunks * (kMaxChunk + 1);
-        M.ar_prev = nullptr;
-        tau_next_ar = h->d_arbuf.as<double>() + (ar_slots - 1) * (kMaxChunk + 1);
+        // maxima of step c into slot c.  Single GPU: the optical-depth kernel must not touch the
+        // slots (its staging pointer goes to the scratch slot, the last one).  Sharded: it stages
+        // only its rays-open flag, in slot c+1, which the all-reduce of step c+1 waits for; the
+        // sweep of step c is gated by the all-reduced flag in slot c-1.
+        double *a = h->d_arbuf.as<double>();
+        M.ar_cur = a + (size_t)nchunks * (kMaxChunk + 1);
+        M.ar_prev = h->sharded() ? a + (nchunks > 0 ? (size_t)nchunks - 1 : ar_slots - 1) * (kMaxChunk + 1) : nullptr;
+        tau_next_ar = a + (h->sharded() ? (size_t)nchunks + 1 : ar_slots - 1) * (kMaxChunk + 1);
         M.st_sweep = h->stream4; M.st_acc = h->stream4;
+        M.ev_before_allreduce = (h->sharded() && nchunks > 0) ? h->ev_tau[nchunks - 1] : nullptr;
       }
       if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, psmax, r_top, nc, nc_max, M, prof ? &spans : nullptr))) return rc;
       if (pipelined) {     // the optical-depth kernel of this step follows its accumulation
@@ -1178,7 +1195,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
-      T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = tau_next_ar;
+      T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = tau_next_ar; T.flag_only = (pipelined && h->sharded()) ? 1 : 0;
       if (o->solution == TRX_SOL_ECLIPSE) {
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
         const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
@@ -1192,6 +1209,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                            dim3(256), 0, st, T);
     }
     if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
+    if (pipelined && h->sharded()) HIPCHK(h, hipEventRecord(h->ev_tau[nchunks], st));
     r_top -= nc; nchunks++;
     // the previous spectrum stopped here: compute the spectrum now and look at the outcome
     // on the host (which this call waits for anyway) instead of queueing gated no-op steps

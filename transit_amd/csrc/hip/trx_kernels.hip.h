@@ -969,6 +969,7 @@ struct TauArgs {
   double *acc;                       // [2][nsh]
   // staging of the NEXT step's all-reduce: [kMaxChunk] maxima (zeroed here) + 1 flag
   double *next_ar;
+  int flag_only;                     // 1: write only the rays-open flag of next_ar (its maxima are being written)
 };
 
 // (out of line: a dozen inlined pow() bodies per call site would push the optical-depth
@@ -1007,7 +1008,7 @@ __device__ __noinline__ double cloud_term(const TauArgs &T, int r, double wn)
 // clean (maxima 0, "rays open" flag 0)
 __device__ __forceinline__ void tau_idle(const TauArgs &T)
 {
-  if (blockIdx.x == 0 && threadIdx.x <= kMaxChunk) T.next_ar[threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x <= kMaxChunk && (!T.flag_only || threadIdx.x == kMaxChunk)) T.next_ar[threadIdx.x] = 0.0;
 }
 
 // End of an optical-depth launch: every block adds its number of rays that are still
@@ -1036,7 +1037,7 @@ __device__ __forceinline__ void tau_publish(const TauArgs &T, int nstill, int de
       const int act = atomicAdd(&T.flags[1], 0);
       T.flags[2] += T.nc;                                // layers swept so far
       T.flags[1] = 0; T.flags[3] = 0;
-      for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
+      if (!T.flag_only) for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
       T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
       __threadfence();
       atomicExch(&T.flags[0], act);
