@@ -26,6 +26,11 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace {
 
 struct OptDef { const char *name; char shortc; bool has_arg; const char *def; };
@@ -370,8 +375,14 @@ void read_atmosphere(trh_problem &P, const std::string &path, const std::string 
   }
 }
 
-// readlineinfo.c:17-77 (datafileBS) on an in-memory ascending array
-int64_t tli_search(const double *w, int64_t n, double target, bool up)
+// readlineinfo.c:17-77 (datafileBS): bisection on the file's ascending wavelength block of one
+// isotope -- here on the memory-mapped file, so only the pages the bisection and the selected
+// range touch are ever read (the block sits at an arbitrary byte offset: unaligned loads)
+struct WlBlock {
+  const unsigned char *p;
+  double operator[](int64_t i) const { double v; std::memcpy(&v, p + 8 * (size_t)i, 8); return v; }
+};
+int64_t tli_search(WlBlock w, int64_t n, double target, bool up)
 {
   int64_t lo = 0, hi = n - 1, loc;
   do {
@@ -383,19 +394,35 @@ int64_t tli_search(const double *w, int64_t n, double target, bool up)
   return loc;
 }
 
+// read-only mapping of a whole file
+struct MappedFile {
+  const unsigned char *p = nullptr; size_t n = 0; int fd = -1;
+  explicit MappedFile(const std::string &path) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Fail(TRX_E_ARG, "cannot open TLI file '" + path + "'");
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); throw Fail(TRX_E_ARG, "cannot stat TLI file '" + path + "'"); }
+    n = (size_t)st.st_size;
+    void *m = ::mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { ::close(fd); throw Fail(TRX_E_ARG, "cannot map TLI file '" + path + "'"); }
+    p = (const unsigned char *)m;
+  }
+  ~MappedFile() { if (p) ::munmap((void *)p, n); if (fd >= 0) ::close(fd); }
+  MappedFile(const MappedFile &) = delete;
+  MappedFile &operator=(const MappedFile &) = delete;
+};
+
 // TLI v6: readlineinfo.c:88-244 (header), :416-537 (range selection)
 void read_tli(trh_problem &P, const std::string &path)
 {
-  FILE *fp = std::fopen(path.c_str(), "rb");
-  if (!fp) throw Fail(TRX_E_ARG, "cannot open TLI file '" + path + "'");
-  std::fseek(fp, 0, SEEK_END); const long fsz = std::ftell(fp); std::fseek(fp, 0, SEEK_SET);
-  std::vector<unsigned char> buf((size_t)fsz);
-  if (std::fread(buf.data(), 1, (size_t)fsz, fp) != (size_t)fsz) { std::fclose(fp); throw Fail(TRX_E_ARG, "short read on TLI file"); }
-  std::fclose(fp);
+  // the file is mapped, not read: line lists run to 10^9 transitions (tens of GB) and a run
+  // needs the header, ~60 probes per isotope and the selected wavelength window
+  MappedFile mf(path);
+  const unsigned char *buf = mf.p; const size_t bufsz = mf.n;
   size_t pos = 0;
-  auto need = [&](size_t n) { if (pos + n > buf.size()) throw Fail(TRX_E_ARG, "TLI file truncated"); };
-  auto rd = [&](void *dst, size_t n) { need(n); std::memcpy(dst, buf.data() + pos, n); pos += n; };
-  auto rstr = [&]() { uint16_t n; rd(&n, 2); need(n); std::string s((const char *)buf.data() + pos, n); pos += n; return s; };
+  auto need = [&](size_t n) { if (pos + n > bufsz) throw Fail(TRX_E_ARG, "TLI file truncated"); };
+  auto rd = [&](void *dst, size_t n) { need(n); std::memcpy(dst, buf + pos, n); pos += n; };
+  auto rstr = [&]() { uint16_t n; rd(&n, 2); need(n); std::string s((const char *)buf + pos, n); pos += n; return s; };
   unsigned char magic[4]; rd(magic, 4);
   uint16_t ver[3]; rd(ver, 6);
   if (ver[0] != 6) throw Fail(TRX_E_ARG, "TLI version is not 6");
@@ -433,23 +460,22 @@ void read_tli(trh_problem &P, const std::string &path)
   int64_t nlines; int32_t nisol; rd(&nlines, 8); rd(&nisol, 4);
   std::vector<int64_t> cnt((size_t)nisol); rd(cnt.data(), 8 * (size_t)nisol);
   const size_t wl0 = pos, iso0 = wl0 + 8 * (size_t)nlines, el0 = iso0 + 2 * (size_t)nlines, gf0 = el0 + 8 * (size_t)nlines;
-  if (gf0 + 8 * (size_t)nlines > buf.size()) throw Fail(TRX_E_ARG, "TLI line blocks truncated");
+  if (gf0 + 8 * (size_t)nlines > bufsz) throw Fail(TRX_E_ARG, "TLI line blocks truncated");
   const double iniw = 1.0 / (P.wn_f * 1.0) / trx::kTliWfct, finw = 1.0 / (P.wn_i * 1.0) / trx::kTliWfct;
   int64_t off = 0;
   for (int k = 0; k < nisol; k++) {
     if (cnt[k] > 0) {
-      std::vector<double> w((size_t)cnt[k]);
-      std::memcpy(w.data(), buf.data() + wl0 + 8 * (size_t)off, 8 * (size_t)cnt[k]);
-      const int64_t a = tli_search(w.data(), cnt[k], iniw, false);
-      const int64_t b = tli_search(w.data(), cnt[k], finw, true);
+      const WlBlock w{buf + wl0 + 8 * (size_t)off};
+      const int64_t a = tli_search(w, cnt[k], iniw, false);
+      const int64_t b = tli_search(w, cnt[k], finw, true);
       const int64_t nread = b - a + 1;
       if (nread > 0) {
         const size_t o0 = P.wl.size();
         P.wl.resize(o0 + nread); P.elow.resize(o0 + nread); P.gf.resize(o0 + nread); P.isoid.resize(o0 + nread);
-        std::memcpy(&P.wl[o0],    buf.data() + wl0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
-        std::memcpy(&P.isoid[o0], buf.data() + iso0 + 2 * (size_t)(off + a), 2 * (size_t)nread);
-        std::memcpy(&P.elow[o0],  buf.data() + el0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
-        std::memcpy(&P.gf[o0],    buf.data() + gf0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
+        std::memcpy(&P.wl[o0],    buf + wl0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
+        std::memcpy(&P.isoid[o0], buf + iso0 + 2 * (size_t)(off + a), 2 * (size_t)nread);
+        std::memcpy(&P.elow[o0],  buf + el0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
+        std::memcpy(&P.gf[o0],    buf + gf0  + 8 * (size_t)(off + a), 8 * (size_t)nread);
       }
     }
     off += cnt[k];
