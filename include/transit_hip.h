@@ -191,7 +191,8 @@ typedef struct {
   int64_t ngroups;        /* co-added groups (anchors), layer independent      */
   int64_t nadd;           /* co-added lines per layer (layer independent)      */
   int64_t layers_swept;
-  int64_t neval;          /* evaluated groups, summed over swept layers        */
+  int64_t neval;          /* evaluated groups, summed over swept layers (these three
+                             counters are collected by profiled runs only)      */
   int64_t nskip;          /* groups below ethresh*kmax, summed over layers     */
   int64_t sum_bins;       /* accumulated (group,layer,bin) triples             */
   int64_t table_floats;   /* Voigt table size                                  */
@@ -203,7 +204,7 @@ typedef struct {
   double  ms_k_accum;     /* sum over launches of k_accumulate                 */
   int64_t sweep_launches; /* launches of each sweep kernel (gated no-op ones too) */
   double  ms_tau;         /* optical-depth kernels                             */
-  double  ms_cia;         /* host wall time of the CIA interpolation            */
+  double  ms_cia;         /* host wall time of queueing the CIA kernels          */
   double  ms_host_total;  /* host wall time of the whole trx_run call           */
   double  ms_spectrum;    /* intensity/flux or modulation                      */
 } trx_stats;

@@ -79,7 +79,7 @@ struct trx_handle {
   DevBuf d_cia_ws, d_cia_dens; std::vector<double> h_cia_dens;
   // per-run workspaces (grown on demand)
   int ws_nr = 0, ws_chunk = 0;
-  DevBuf d_layer_f64, d_layer_i32, d_S, d_SG, d_idop8, d_kmax, d_sticky, d_counters, d_bins, d_flags, d_part2, d_part3;
+  DevBuf d_layer_f64, d_layer_i32, d_SG, d_idop8, d_sticky, d_counters, d_flags, d_part3;
   DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip, d_acc, d_arbuf;
   // opacity grid (optional)
   bool has_grid = false; long og_nmol = 0, og_ntemp = 0, og_nlayer = 0, og_nwave = 0;
@@ -1022,7 +1022,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const size_t sg_stride = gr_b * nc_max;
   const size_t ar_slots = pipelined ? (size_t)nr + 2 : 2;
   if ((rc = ensure(h, h->d_SG, sizeof(double) * sg_stride)) ||
-      (rc = ensure(h, h->d_idop8, sg_stride)) || (rc = ensure(h, h->d_kmax, sizeof(double) * nr)) ||
+      (rc = ensure(h, h->d_idop8, sg_stride)) ||
       (rc = ensure(h, h->d_sticky, sizeof(int) * nli)) || (rc = ensure(h, h->d_counters, 24 * (size_t)nr)) ||
       (rc = ensure(h, h->d_flags, 64)) ||
       (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
