@@ -305,3 +305,33 @@ def test_cloud_models_against_oracle(tmp_path, cloud, solution):
     assert np.array_equal(got["last"], ref["last"])
     assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9
     assert rel_err(got["tau"], ref["tau"]) < 5e-8
+
+
+def test_two_handles_on_two_threads():
+    """Handles share nothing: two of them driven from two host threads at once (ctypes drops the
+    GIL during trx_run) give what each gives alone."""
+    import threading
+    P1, P2 = golden("eclipse_small").problem, golden("coadd_thresh").problem
+    refs = []
+    for P in (P1, P2):
+        e = Engine(P.static)
+        refs.append(e.run(P.atm, P.opts)["spectrum"])
+        e.close()
+    engs = [Engine(P1.static), Engine(P2.static)]
+    outs = [[], []]
+
+    def work(k, P):
+        for _ in range(40):
+            outs[k].append(engs[k].run(P.atm, P.opts)["spectrum"])
+
+    th = [threading.Thread(target=work, args=(0, P1)), threading.Thread(target=work, args=(1, P2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in engs:
+        e.close()
+    for k in range(2):
+        assert len(outs[k]) == 40
+        for o in outs[k]:
+            assert np.array_equal(o, refs[k])
