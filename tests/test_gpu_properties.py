@@ -335,3 +335,19 @@ def test_two_handles_on_two_threads():
         assert len(outs[k]) == 40
         for o in outs[k]:
             assert np.array_equal(o, refs[k])
+
+
+@pytest.mark.parametrize("grid", [dict(ndop=256, nlor=7), dict(ndop=2, nlor=2), dict(ndop=17, nlor=120, dmin=5e-4, dmax=0.5, lmin=1e-3, lmax=2.0)])
+def test_other_voigt_grids_against_oracle(tmp_path, grid):
+    """--ndop/--nlor/--dmin/... (argum.c:220-237): the largest Doppler grid the kernels stage in
+    LDS, the smallest legal one (every line falls on its edges), and an asymmetric one."""
+    d = str(tmp_path / "vg")
+    synth.make_case(d, nlines=2500, wnlow=2500, wnhigh=2530, nlayers=25, solution="eclipse", seed=12,
+                    ethresh=1e-7, extra={k: str(v) for k, v in grid.items()})
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    assert P.static.ndop == grid["ndop"] and P.static.nlor == grid["nlor"]
+    got, ref = _both(P.static, P)
+    assert np.array_equal(got["last"], ref["last"])
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9
+    sw = got["computed"].astype(bool) & ref["computed"].astype(bool)
+    assert rel_err(got["e"][sw], ref["e"][sw]) < 1e-9
