@@ -7,8 +7,8 @@
 //   * per-run layer prologue: broadening widths, nearest table indices,
 //     strength prefactors (extinction.c:364-395, 464, 473);
 //   * Simpson weights of the ray geometry (numerical.c:390-425);
-//   * CIA interpolation (crosssec.c:272-428) -- small; device version is the
-//     next step.
+//   * the table-only halves of the CIA splines (crosssec.c:272-428), once per handle;
+//   * the plan of a run: layers per step, streams, events, the exchanges of a sharded job.
 // Everything per (line x layer), per (group x layer x bin) and per
 // (wavenumber x layer) runs in the kernels of trx_kernels.hip.h.
 #include <hip/hip_runtime.h>

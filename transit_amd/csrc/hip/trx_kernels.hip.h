@@ -8,9 +8,12 @@
 //                                     index, layer maximum      (extinction.c:399-483)
 //   k_sticky_index                    sticky Doppler index      (extinction.c:393, 480-483)
 //   k_accumulate                      pass 2b: threshold + profile accumulation into
-//                                     e[layer][wn]              (extinction.c:467-509)
+//                                     e[layer][wn], gather per 4-bin tile (extinction.c:467-509)
+//   k_accumulate_wide                 the same for profiles >= 64 coarse bins: lanes own bins,
+//                                     phase-major table (k_table_phase_major)
+//   k_grid_extinction                 opacity-grid mode          (extinction.c:535-581)
 //   k_cia_rows/_layers/_eval          CIA extinction            (crosssec.c:272-428)
-//   k_optical_depth                   total extinction + ray quadrature + toomuch cut
+//   k_optical_depth(_vertical)        total extinction + ray quadrature + toomuch cut
 //                                                               (tau.c:216-305, eclipse.c:29-105,
 //                                                                slantpath.c:19-108)
 //   k_emission / k_modulation         spectrum from tau         (eclipse.c:118-287, slantpath.c:351-473)
