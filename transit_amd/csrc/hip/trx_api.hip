@@ -67,7 +67,8 @@ struct trx_handle {
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
-  DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge;
+  DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge, d_cntsub;
+  int sub_f = 1;                        // sub-buckets per coarse cell of d_cntsub (1: it is d_cntge)
   LinesDev L{};
   std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
   void *comm = nullptr; int nranks = 1, rank = 0;
@@ -337,6 +338,29 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   for (size_t g = 1; g < giown.size(); g++)
     if (giso[g] == giso[g-1] && giown[g] > giown[g-1])
       return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
+  // the same counts at F sub-buckets per coarse cell (key iown*F/osamp): k_accumulate sizes its
+  // windows with them, so that it does not stream whole cells of groups that lie between the
+  // reach of two bins.  F = 1 (the table above) when the fine grid is no finer or the table
+  // would be large.
+  std::vector<int32_t> cntsub;
+  {
+    int F = (int)std::min<long long>(16, s->osamp);
+    while (F > 1 && (size_t)s->niso * (size_t)F * (size_t)s->nwn * 4 > ((size_t)64 << 20)) F /= 2;
+    h->sub_f = F;
+    if (F > 1) {
+      const size_t stride = (size_t)F * s->nwn + 1;
+      cntsub.assign((size_t)s->niso * stride, 0);
+      for (size_t g = 0; g < giso.size(); g++) {
+        long long k = (long long)giown[g] * F / s->osamp;
+        if (k > (long long)stride - 2) k = (long long)stride - 2;
+        cntsub[(size_t)giso[g] * stride + k]++;
+      }
+      for (int b = 0; b < s->niso; b++) {
+        int32_t *c = &cntsub[(size_t)b * stride];
+        for (long long k = (long long)stride - 2; k >= 0; k--) c[k] += c[k + 1];
+      }
+    }
+  }
 
   std::vector<int32_t> lgroup((size_t)n, -1);
   for (size_t g = 0; g < gfirst.size(); g++) lgroup[(size_t)gfirst[g]] = (int32_t)g;
@@ -348,7 +372,8 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_elow, elow)) || (rc = upload(h, h->d_gf, gf)) ||
       (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
       (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
-      (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gimod, gimod)) || (rc = upload(h, h->d_gidiv, gidiv)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)))
+      (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gimod, gimod)) || (rc = upload(h, h->d_gidiv, gidiv)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)) ||
+      (rc = upload(h, h->d_cntsub, cntsub)))
     return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
   h->h_gwavn = gwavn; h->h_gblock = gblock; h->h_cntge = cntge; h->h_gfirst = gfirst; h->h_gcount = gcount;
@@ -670,6 +695,8 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
     A.kmaxc = M.ar_cur; A.ethresh = M.ethresh; A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol;
     A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
     A.table = h->tab; A.e = M.d_e;
+    // (profiled runs count every group in the tile of its own coarse cell: whole-cell windows)
+    A.sub_f = M.prof ? 1 : h->sub_f; A.cnt_sub = A.sub_f > 1 ? h->d_cntsub.as<int32_t>() : h->d_cntge.as<int32_t>();
     A.part = M.prof ? h->d_part3.as<unsigned long long>() : nullptr; A.part_stride = (int)tblocks;
     A.flags = h->d_flags.as<int>(); A.eager = M.eager;
     A.last = M.skip_done ? h->d_last.as<int>() : nullptr;

@@ -475,6 +475,7 @@ struct AccumArgs {
   const int *last;                  // [nsh] or null: skip tiles whose rays all stopped above this chunk
   int eager;
   unsigned skip_mask;               // bit c set: layer c of the chunk belongs to k_accumulate_wide
+  int sub_f; const int32_t *cnt_sub;  // [niso][sub_f*nwn + 1]: groups with iown*sub_f/osamp >= k (sub_f == 1: cnt_ge)
 };
 
 // grid: x = groups of 4 tiles, y = layer of the chunk
@@ -532,12 +533,13 @@ void k_accumulate(AccumArgs A)
     const int idst = A.sticky_idop[ri];
     // window of groups that can reach the tile
     const long long psm = A.Y.psmax[ri];
-    // groups with iown in [osamp*j0 - psm, osamp*j1 + psm]; keys are iown/osamp
-    const long long lo_f = (long long)A.osamp * j0 - psm;
-    long long klo = lo_f > 0 ? lo_f / A.osamp : 0;
-    long long khi = ((long long)A.osamp * j1 + psm) / A.osamp;
-    if (khi > A.nwn - 1) khi = A.nwn - 1;
-    const int32_t *cg = A.L.cnt_ge + (long long)b * (A.nwn + 1);
+    // groups with iown in [osamp*j0 - psm, osamp*j1 + psm]; keys are sub-buckets iown*F/osamp
+    const long long lo_f = (long long)A.osamp * j0 - psm, hi_f = (long long)A.osamp * j1 + psm;
+    const long long nkey = (long long)A.sub_f * A.nwn;
+    long long klo = lo_f > 0 ? lo_f * A.sub_f / A.osamp : 0;
+    long long khi = hi_f * A.sub_f / A.osamp;
+    if (khi > nkey - 1) khi = nkey - 1;
+    const int32_t *cg = A.cnt_sub + (long long)b * (nkey + 1);
     const int ga = gb0 + cg[khi + 1], gz = gb0 + cg[klo];
     const double  *SGr = A.SG    + (long long)c * A.L.ngroups;
     const uint8_t *idr = A.idop8 + (long long)c * A.L.ngroups;
