@@ -21,9 +21,27 @@ typedef struct trh_problem trh_problem;
 /* Parse argv exactly like `transit [options]` (-c file | --config_file file,
  * --name value, cfg lines "name value" with the reference's prefix matching,
  * procopt.c:651-705), read every input file and build the samplings.
- * On failure returns a negative code and, if err != NULL, a message. */
+ * On failure returns a negative code and, if err != NULL, a message.
+ * Returns 1 (and no problem) when --help or --version was served: the text went to stdout and
+ * there is nothing to run (the reference exits with success there, argum.c:582-607). */
 int  trh_load(int argc, const char *const *argv, trh_problem **out, char *err, int errlen);
 void trh_free(trh_problem *p);
+
+/* Notes ("I: ...") and warnings ("W: ...") the host side recorded while loading, one per line:
+ * what the reference prints through tr_output(TOUT_WARN / TOUT_INFO, ...) for the same input
+ * (abundance sums off by more than allowq, readatm.c:545-549; options that are accepted but
+ * cannot change this path's outputs). */
+const char *trh_messages(const trh_problem *p);
+
+/* The option table (same names, order and defaults as argum.c:112-320), entry i:
+ * kind 'a' acted on, 'n' parsed like the reference and like there without effect on any output,
+ * 'w' accepted with a warning (results unaffected), 'x' rejected with TRX_E_UNSUPPORTED.
+ * Returns TRX_E_ARG past the end. */
+int  trh_option_table(int i, const char **name, int *has_arg, char *kind);
+
+/* Every file a run of this problem writes, one "kind value" line each (what the output options
+ * turned into); valid until the next call on this problem. */
+const char *trh_output_plan(trh_problem *p);
 
 const trx_static *trh_static(const trh_problem *p);
 const trx_atm    *trh_atm   (const trh_problem *p);
@@ -62,6 +80,14 @@ int  trh_write_intens(const trh_problem *p, const double *intens, const char *pa
 /* `savefiles yes`: tau.dat, CIA.dat, mol_extion.dat in the reference's dump formats (tau.c:386-515),
  * from the trx_debug arrays (any of them may be NULL); dir NULL = next to the cfg */
 int  trh_write_dumps(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const char *dir);
+/* detailtau / detailext / detailcia (detailout, tau.c:526-605): which = 0 tau [wn][height],
+ * 1 molecular extinction [layer][wn], 2 CIA extinction [layer][wn] (trx_debug layouts).  Writes
+ * the file named in the option; no-op when the option was not given. */
+int  trh_wants_detail(const trh_problem *p, int which);
+int  trh_write_detail(const trh_problem *p, int which, const double *arr);
+/* outsample (makesample.c:744-770): the samplings file; the reference writes it only together
+ * with `savefiles yes` (makesample.c:598-599).  path NULL = the outsample option. */
+int  trh_write_sample(const trh_problem *p, const char *path);
 const char *trh_option(const trh_problem *p, const char *name);  /* accepted value of an option */
 
 #ifdef __cplusplus

@@ -25,7 +25,11 @@ REF = os.path.join(ROOT, "oracle", "_ref", "transit")
 REF_REENTRY = os.path.join(ROOT, "oracle", "_ref", "transit_reentry")   # oracle/ref_reentry_main.c
 
 KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "cia_h2he.dat",
-        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "intens.dat"]
+        "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "intens.dat",
+        # cases that ask for them: samplings file, detailout files, the three per-wavenumber dumps
+        "sample.dat", "detail_ext.dat", "detail_tau.dat", "detail_cia.dat",
+        "total_extion.dat", "cloud_extion.dat", "scatt_extion.dat"]
+DUMPS3 = ("total_extion.dat", "cloud_extion.dat", "scatt_extion.dat")
 
 CASES = {
     # demo-shaped emission run, narrow band
@@ -76,6 +80,23 @@ CASES = {
     # (tau.c:238-274) -- a wavenumber-order-dependent 1e-4 effect
     "reentry_transit": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="transit", seed=55,
                             reentry=True, extra={"refpress": "0.1", "gsurf": "1000.0"}),
+    # abundance scaling while the atmosphere is read (qmol/qscale, readatm.c:394-405, 519-540:
+    # the named species are multiplied by 10^qscale, H2 and He re-balanced), emission geometry;
+    # also every optional output file: samplings, detailout at a few wavenumbers, total/cloud/
+    # scattering extinction dumps (eclipse geometry leaves its edited bottom values in them)
+    "qscale_eclipse": dict(nlines=2500, wnlow=2500, wnhigh=2540, nlayers=26, solution="eclipse", seed=61,
+                           keep_dumps3=True,
+                           extra={"qmol": "CH4 H2O", "qscale": "0.5 -0.3", "outsample": "sample.dat",
+                                  "scattering": "1.2",
+                                  "detailext": "detail_ext.dat:2503.2,2520,2539.9",
+                                  "detailtau": "detail_tau.dat:2500,2531.5",
+                                  "detailcia": "detail_cia.dat:2510,2540"}),
+    # the same outputs in transmission geometry with a cloud deck and scattering
+    "dumps_transit": dict(nlines=2000, wnlow=3000, wnhigh=3030, nlayers=25, solution="transit", seed=62,
+                          keep_dumps3=True, ncia=2,
+                          extra={"cloudtop": "-1.5", "scattering": "1.5", "outsample": "sample.dat",
+                                 "detailext": "detail_ext.dat:3001,3015.5", "detailtau": "detail_tau.dat:3029.9",
+                                 "detailcia": "detail_cia.dat:3000,3030"}),
     "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
                        solution="transit", seed=17, ncia=2),
 }
@@ -114,6 +135,7 @@ def main():
         extra = dict(kw.pop("extra", {}))
         extra.update({"savefiles": "yes"})
         reentry = kw.pop("reentry", False)
+        keep3 = kw.pop("keep_dumps3", False)
         if reentry:
             import numpy as np
             atm = synth.demo_atmosphere(kw["nlayers"])
@@ -145,6 +167,8 @@ def main():
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d)
         for f in KEEP:
+            if f in DUMPS3 and not keep3:
+                continue
             if os.path.exists(os.path.join(tmp, f)):
                 shutil.copy(os.path.join(tmp, f), os.path.join(d, f))
         for f in sorted(os.listdir(tmp)):

@@ -99,3 +99,38 @@ def test_cli_outintens_matches_the_reference_file(tmp_path):
     got, ref = np.loadtxt(work / "intens.dat", comments="#"), np.loadtxt(ref_path, comments="#")
     assert np.array_equal(got[:, 0], ref[:, 0])
     assert rel_err(got[:, 1:], ref[:, 1:]) < 2e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["qscale_eclipse", "dumps_transit"])
+def test_cli_detail_and_sampling_files_match_the_reference(tmp_path, case):
+    """detailext / detailtau / detailcia (detailout, tau.c:526-605) and outsample
+    (makesample.c:744-770), written by the command the way the reference writes them."""
+    exe = build.build_cli() or build.lib_path("transit_hip")
+    work = tmp_path / case
+    shutil.copytree(os.path.join(GOLDEN, case), work)
+    outs = ("spectrum.dat", "toomuch.dat", "sample.dat", "detail_ext.dat", "detail_tau.dat", "detail_cia.dat",
+            "tau.dat", "CIA.dat", "mol_extion.dat", "total_extion.dat", "cloud_extion.dat", "scatt_extion.dat")
+    for f in outs:
+        if os.path.exists(work / f):
+            os.remove(work / f)
+    p = subprocess.run([exe, "-c", "case.cfg"], cwd=work, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    ref = lambda f: os.path.join(GOLDEN, case, f)
+    assert open(work / "sample.dat").read() == open(ref("sample.dat")).read()
+    assert rel_err(ol.read_spectrum(work / "spectrum.dat")[:, 1], ol.read_spectrum(ref("spectrum.dat"))[:, 1]) < 2e-8
+    for f in ("detail_tau.dat", "detail_ext.dat", "detail_cia.dat"):
+        got, want = open(work / f).read().split("\n"), open(ref(f)).read().split("\n")
+        assert got[0] == want[0] and len(got) == len(want), f            # picked wavenumbers, row count
+        a, b = np.loadtxt(work / f, comments="#", ndmin=2), np.loadtxt(ref(f), comments="#", ndmin=2)
+        assert np.array_equal(a[:, 0], b[:, 0]), f                       # radius / impact-parameter column
+        if f == "detail_ext.dat":
+            sw = np.any(b[:, 1:] != 0, axis=1)                           # the reference leaves unswept layers at zero
+            assert rel_err(a[sw, 1:], b[sw, 1:]) < 2e-6, f
+        elif f == "detail_tau.dat":
+            assert np.array_equal(a[:, 1:] == 0, b[:, 1:] == 0)          # same toomuch cut
+            assert rel_err(a[:, 1:], b[:, 1:]) < 2e-6, f
+        else:
+            # the reference prints 32-bit halves of its doubles (see trh_write_detail): the rows
+            # showing the HIGH half (sign, exponent, 20 mantissa bits) are stable, compare those
+            assert rel_err(a[1::2, 1:], b[1::2, 1:]) < 1e-5, f

@@ -146,6 +146,42 @@ def test_lines_outside_the_band_contribute_nothing():
     assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-12
 
 
+def _dirty_the_device_pool(P):
+    """A run with lines and dumps leaves non-zero extinction in freed device memory."""
+    hip = Engine(P.static)
+    out = hip.run(P.atm, P.opts, debug=True)
+    hip.close()
+    assert (out["e"] != 0).any()
+
+
+@pytest.mark.parametrize("kind", ["no_lines", "lines_outside_band"])
+def test_no_inrange_line_without_debug_dumps(kind):
+    """No kernel writes the molecular extinction when no line is in range; the plain
+    run (no dumps requested, which used to be what zeroed it) must still read zeros."""
+    P = golden("eclipse_small").problem
+    _dirty_the_device_pool(P)
+    if kind == "no_lines":
+        st = _abi.TrxStatic.from_buffer_copy(P.static)
+        st.nlines = 0
+    else:
+        wl = line_array(P.static, "wl_um")
+        far = np.sort(1e4 / np.linspace(2700.0, 2800.0, wl.size))
+        iso = line_array(P.static, "isoid", np.int16)
+        for b in np.unique(iso):
+            m = iso == b
+            wl[m] = far[: m.sum()]
+        st = clone_static(P.static, wl_um=wl)
+    hip = Engine(st)
+    first = hip.run(P.atm, P.opts)["spectrum"]
+    second = hip.run(P.atm, P.opts)["spectrum"]          # hinted plan, same answer
+    hip.close()
+    ora = ol.OracleEngine(st)
+    ref = ora.run(P.atm, P.opts)["spectrum"]
+    ora.close()
+    assert rel_err(first, ref) < 1e-12
+    assert np.array_equal(first, second)
+
+
 def test_single_line_on_a_grid_point_and_at_the_band_edges():
     """Three hand-placed lines: exactly on a coarse grid point, on the first and on
     the last wavenumber of the band (clamped windows, extinction.c:493-496)."""

@@ -1072,10 +1072,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     return rc;
   if ((rc = upload(h, h->d_ip, ipv))) return rc;
   HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 24 * (size_t)nr, st));
-  if (dbg || eager) {   // every element the path reads is written first; zeros only matter in the dumps
+  // With lines, every element of e the path reads is written first (the accumulation kernels
+  // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
+  // in-range line (empty list, all lines outside the band, a CIA-only run) no kernel writes
+  // e, but the optical-depth kernels still read it: it must be zero then.
+  if (dbg || eager || (h->ngroups == 0 && !h->has_grid))
     HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
+  if (dbg || eager)
     HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
-  }
   HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
   HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));

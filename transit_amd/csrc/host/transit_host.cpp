@@ -33,42 +33,61 @@
 
 namespace {
 
-struct OptDef { const char *name; char shortc; bool has_arg; const char *def; };
+// What the host side does with an accepted option:
+//   'a' acted on (changes the problem description, an output file, or the run's verbosity)
+//   'n' parsed exactly as the reference parses it and, as in the reference, without any
+//       effect on what this path writes (a note is recorded, trh_messages)
+//   'w' accepted with a warning: results are unaffected, a resource detail differs
+//   'x' rejected with TRX_E_UNSUPPORTED and a message
+struct OptDef { const char *name; char shortc; bool has_arg; const char *def; char kind; const char *help; };
 
 // Same names, order and defaults as the reference's table (argum.c:112-320);
 // order matters because cfg tokens are matched as prefixes, first hit wins.
 const OptDef kOptions[] = {
-  {"version", 'V', false, nullptr}, {"help", 'h', false, nullptr},
-  {"quiet", 'q', false, nullptr}, {"verb", 'v', true, "2"},
-  {"config_file", 'c', true, nullptr},
-  {"atm", 0, true, nullptr}, {"linedb", 0, true, nullptr},
-  {"outtoomuch", 0, true, nullptr}, {"outsample", 0, true, nullptr},
-  {"outspec", 0, true, "outspectrum"}, {"outintens", 0, true, nullptr},
-  {"molfile", 0, true, "../inputs/molecules.dat"}, {"savefiles", 0, true, nullptr},
-  {"raddelt", 0, true, "-1"}, {"radlow", 0, true, "0"}, {"radhigh", 0, true, "0"},
-  {"radfct", 0, true, "0"},
-  {"allowq", 0, true, "0.00001"}, {"refpress", 0, true, nullptr},
-  {"refradius", 0, true, nullptr}, {"gsurf", 0, true, nullptr},
-  {"qmol", 0, true, nullptr}, {"qscale", 0, true, nullptr},
-  {"wllow", 0, true, nullptr}, {"wlhigh", 0, true, nullptr}, {"wlfct", 0, true, "1e-4"},
-  {"wnlow", 0, true, nullptr}, {"wnhigh", 0, true, nullptr}, {"wndelt", 0, true, "0"},
-  {"wnosamp", 0, true, "2160"}, {"wnfct", 0, true, "0"},
-  {"ndop", 0, true, "60"}, {"nlor", 0, true, "60"},
-  {"dmin", 0, true, "1e-3"}, {"dmax", 0, true, "0.25"},
-  {"lmin", 0, true, "1e-4"}, {"lmax", 0, true, "10.0"},
-  {"nwidth", 'a', true, "20"},
-  {"ethreshold", 0, true, "1e-8"}, {"cloud", 0, true, nullptr},
-  {"cloudtop", 0, true, nullptr}, {"scattering", 0, true, nullptr},
-  {"detailext", 0, true, nullptr}, {"detailcia", 0, true, nullptr},
-  {"csfile", 0, true, nullptr}, {"saveext", 0, true, nullptr},
-  {"opacityfile", 0, true, nullptr}, {"tlow", 0, true, "500"}, {"thigh", 0, true, "3000"},
-  {"tempdelt", 0, true, "100.0"}, {"justOpacity", 0, false, nullptr},
-  {"shareOpacity", 0, false, nullptr},
-  {"solution", 's', true, "eclipse"}, {"toomuch", 0, true, "20"},
-  {"taulevel", 0, true, "1"}, {"modlevel", 0, true, "1"}, {"detailtau", 0, true, nullptr},
-  {"starrad", 0, true, "1.125"}, {"gorbpar", 0, true, nullptr},
-  {"gorbparfct", 0, true, nullptr}, {"transparent", 0, false, nullptr},
-  {"raygrid", 0, true, "0 20 40 60 80"},
+  {"version", 'V', false, nullptr, 'a', "print the version and exit"},
+  {"help", 'h', false, nullptr, 'a', "print this list and exit"},
+  {"quiet", 'q', false, nullptr, 'a', "verbosity 1"}, {"verb", 'v', true, "2", 'a', "verbosity level"},
+  {"config_file", 'c', true, nullptr, 'a', "read options from a file"},
+  {"atm", 0, true, nullptr, 'a', "atmosphere file"}, {"linedb", 0, true, nullptr, 'a', "TLI line database"},
+  {"outtoomuch", 0, true, nullptr, 'a', "file: depth where toomuch was reached"},
+  {"outsample", 0, true, nullptr, 'a', "file: sampling information (written with savefiles)"},
+  {"outspec", 0, true, "outspectrum", 'a', "spectrum file"}, {"outintens", 0, true, nullptr, 'a', "per-angle intensity file"},
+  {"molfile", 0, true, "../inputs/molecules.dat", 'a', "molecule table"},
+  {"savefiles", 0, true, nullptr, 'a', "dump tau, extinctions and CIA under fixed names"},
+  {"raddelt", 0, true, "-1", 'a', "radius spacing (-1: keep the file's layers)"},
+  {"radlow", 0, true, "0", 'a', "lower radius"}, {"radhigh", 0, true, "0", 'a', "upper radius"},
+  {"radfct", 0, true, "0", 'a', "radius units factor of a resampled grid"},
+  {"allowq", 0, true, "0.00001", 'a', "allowed departure of the abundance sum from 1 (warning)"},
+  {"refpress", 0, true, nullptr, 'a', "reference pressure"},
+  {"refradius", 0, true, nullptr, 'a', "reference radius"}, {"gsurf", 0, true, nullptr, 'a', "surface gravity"},
+  {"qmol", 0, true, nullptr, 'a', "species whose abundance is scaled"}, {"qscale", 0, true, nullptr, 'a', "log10 scale factors"},
+  {"wllow", 0, true, nullptr, 'a', "lower wavelength"}, {"wlhigh", 0, true, nullptr, 'a', "upper wavelength"},
+  {"wlfct", 0, true, "1e-4", 'a', "wavelength units factor"},
+  {"wnlow", 0, true, nullptr, 'a', "lower wavenumber"}, {"wnhigh", 0, true, nullptr, 'a', "upper wavenumber"},
+  {"wndelt", 0, true, "0", 'a', "wavenumber spacing"},
+  {"wnosamp", 0, true, "2160", 'a', "wavenumber oversampling"}, {"wnfct", 0, true, "0", 'a', "wavenumber units factor"},
+  {"ndop", 0, true, "60", 'a', "Doppler-width samples"}, {"nlor", 0, true, "60", 'a', "Lorentz-width samples"},
+  {"dmin", 0, true, "1e-3", 'a', "smallest Doppler width"}, {"dmax", 0, true, "0.25", 'a', "largest Doppler width"},
+  {"lmin", 0, true, "1e-4", 'a', "smallest Lorentz width"}, {"lmax", 0, true, "10.0", 'a', "largest Lorentz width"},
+  {"nwidth", 'a', true, "20", 'a', "profile half-size in widths"},
+  {"ethreshold", 0, true, "1e-8", 'a', "line-strength threshold"}, {"cloud", 0, true, nullptr, 'a', "cloud model"},
+  {"cloudtop", 0, true, nullptr, 'a', "cloud-deck top (log bar)"}, {"scattering", 0, true, nullptr, 'a', "scattering model"},
+  {"detailext", 0, true, nullptr, 'a', "file:wn,... extinction at the given wavenumbers"},
+  {"detailcia", 0, true, nullptr, 'a', "file:wn,... CIA extinction at the given wavenumbers"},
+  {"csfile", 0, true, nullptr, 'a', "cross-section files"},
+  {"saveext", 0, true, nullptr, 'x', "not supported (the extinction is recomputed on the device in milliseconds)"},
+  {"opacityfile", 0, true, nullptr, 'a', "opacity-grid file"}, {"tlow", 0, true, "500", 'a', "grid: lowest temperature"},
+  {"thigh", 0, true, "3000", 'a', "grid: highest temperature"},
+  {"tempdelt", 0, true, "100.0", 'a', "grid: temperature spacing"}, {"justOpacity", 0, false, nullptr, 'a', "stop after the grid"},
+  {"shareOpacity", 0, false, nullptr, 'w', "no effect: every handle keeps its own copy of the grid in device memory"},
+  {"solution", 's', true, "eclipse", 'a', "eclipse or transit"}, {"toomuch", 0, true, "20", 'a', "optical-depth cut"},
+  {"taulevel", 0, true, "1", 'a', "1 (2 is rejected)"}, {"modlevel", 0, true, "1", 'a', "1 or -1"},
+  {"detailtau", 0, true, nullptr, 'a', "file:wn,... optical depth at the given wavenumbers"},
+  {"starrad", 0, true, "1.125", 'a', "stellar radius"},
+  {"gorbpar", 0, true, nullptr, 'n', "orbital parameters (no output of this path depends on them)"},
+  {"gorbparfct", 0, true, nullptr, 'n', "units of the orbital parameters (no output depends on them)"},
+  {"transparent", 0, false, nullptr, 'a', "transparent planet"},
+  {"raygrid", 0, true, "0 20 40 60 80", 'a', "emission angles"},
 };
 constexpr int kNumOptions = sizeof(kOptions) / sizeof(kOptions[0]);
 
@@ -120,6 +139,8 @@ struct trh_problem {
   std::vector<std::vector<double>> a_q, a_d;            // [nmol][nlayer]
   double rad_fct = 1, p_fct = 1, t_fct = 1, zerorad = 0; bool by_mass = true;
   float allowq = 1e-5f;
+  // abundance scaling while the atmosphere file is read (qmol/qscale, argum.c:881-890)
+  std::vector<std::string> qmol; std::vector<double> qscale;
   // molecules
   std::vector<int> mol_id; std::vector<double> mol_mass, mol_radius, mol_pol; std::vector<int32_t> mol_is_h2;
   // line list
@@ -148,6 +169,14 @@ struct trh_problem {
   // build request: nv = nlayer*ntemp states
   std::vector<double> rq_temp, rq_dens, rq_z; std::vector<int32_t> rq_slot; int rq_nslot = 0;
 
+  double out_rad_fct = 1;                               // rads.fct of the sampled layers (radfct when resampling)
+  // detailext / detailtau / detailcia: file + requested wavenumbers (argum.c:385-415)
+  struct Detail { std::string file; std::vector<double> wn; };
+  Detail det_ext, det_tau, det_cia;
+  // notes and warnings of the host side ("W: ..." / "I: ..."), newline separated
+  std::string messages; int nwarn_q = 0;
+  bool exit_requested = false;                          // --help / --version were served
+
   trx_static st{}; trx_atm atm{}; trx_opts opts{};
   std::string err;
 };
@@ -163,10 +192,59 @@ const OptDef *match_option(const std::string &token)
 
 void read_cfg(trh_problem &P, const std::string &path);
 
+void note(trh_problem &P, char level, const std::string &msg)
+{ P.messages += level; P.messages += ": "; P.messages += msg; P.messages += '\n'; }
+
+// "filename:wn1,wn2,..." of detailext / detailtau / detailcia (argum.c:385-415)
+void parse_detail(trh_problem::Detail &d, const std::string &value, const char *what)
+{
+  const size_t c = value.find(':');
+  d.file = value.substr(0, c); d.wn.clear();
+  if (c != std::string::npos) {
+    std::string tok; std::istringstream is(value.substr(c + 1));
+    while (std::getline(is, tok, ',')) {
+      char *e; const double v = std::strtod(tok.c_str(), &e);
+      if (e != tok.c_str()) d.wn.push_back(v);
+    }
+  }
+  if (d.wn.empty() || d.file.empty())
+    throw Fail(TRX_E_ARG, std::string("bad format for detailed ") + what + " parameter, no valid wavenumbers");
+}
+
+void print_help()
+{
+  std::printf("transit_hip: drop-in for `transit` on the spectrum path (MI355X).\n"
+              "Options (--name value on the command line, `name value` lines in a -c file):\n");
+  for (int i = 0; i < (int)(sizeof(kOptions) / sizeof(kOptions[0])); i++) {
+    const OptDef &o = kOptions[i];
+    std::printf("  --%-13s%s %-8s %s%s%s\n", o.name, o.shortc ? (std::string(" -") + o.shortc).c_str() : "   ",
+                o.has_arg ? "<value>" : "", o.help, o.def ? "  [default " : "", o.def ? (std::string(o.def) + "]").c_str() : "");
+  }
+}
+
 void accept(trh_problem &P, const OptDef *o, const std::string &value, const std::string &ctx_dir)
 {
-  if (std::strcmp(o->name, "config_file") == 0) { read_cfg(P, join_path(ctx_dir, value)); return; }
-  if (std::strcmp(o->name, "quiet") == 0) { P.opt["verb"] = "1"; return; }
+  const std::string name = o->name;
+  if (name == "config_file") { read_cfg(P, join_path(ctx_dir, value)); return; }
+  if (name == "quiet") { P.opt["verb"] = "1"; return; }
+  if (name == "help") { print_help(); P.exit_requested = true; return; }                 // argum.c:605-607
+  if (name == "version") {                                                               // argum.c:582-587
+    std::printf("This is 'transit_hip' (MI355X spectrum path behind transit's interface), ABI %d\n\n", TRX_ABI_VERSION);
+    P.exit_requested = true; return;
+  }
+  if (o->kind == 'x') throw Fail(TRX_E_UNSUPPORTED, "option '" + name + "': " + o->help);
+  if (o->kind == 'w') note(P, 'W', "option '" + name + "': " + o->help);
+  if (name == "gorbpar" || name == "gorbparfct") {          // six comma-separated numbers (argum.c:612-621)
+    int n = 0; std::string tok; std::istringstream is(value);
+    while (std::getline(is, tok, ',')) { char *e; std::strtod(tok.c_str(), &e); if (e == tok.c_str()) throw Fail(TRX_E_ARG, "bad number in " + name); n++; }
+    if (n != 6) throw Fail(TRX_E_ARG, name + " needs six comma-separated values");
+    note(P, 'I', "option '" + name + "' accepted; like in the reference, no output of the spectrum path depends on it");
+  }
+  if (name == "savefiles" && value.compare(0, 3, "yes") != 0 && value.compare(0, 2, "no") != 0)
+    throw Fail(TRX_E_ARG, "allowed arguments for savefiles are: 'yes' or 'no'");                // argum.c:461-470
+  if (name == "detailext") parse_detail(P.det_ext, value, "Extinction");
+  if (name == "detailtau") parse_detail(P.det_tau, value, "Optical depth");
+  if (name == "detailcia") parse_detail(P.det_cia, value, "CIA extinction");
   P.opt[o->name] = o->has_arg ? value : "1";
 }
 
@@ -301,6 +379,12 @@ void layer_state(trh_problem &P, size_t r)
   }
   if (P.by_mass) mm = 1.0 / mm;
   if (sumq > 1.001) throw Fail(TRX_E_ARG, "abundances add up to more than 1");
+  if (std::fabs(sumq - 1.0) > P.allowq && P.nwarn_q++ < 8) {        // readatm.c:545-549, 754-757 (a warning)
+    char b[160];
+    std::snprintf(b, sizeof b, "in layer %zu (%g), abundances don't add up to 1.0: %.9g%s", r, P.a_rad[r], sumq,
+                  P.nwarn_q == 8 ? " (further warnings of this kind are not recorded)" : "");
+    note(P, 'W', b);
+  }
   P.a_mm[r] = mm;
   const double p = P.a_p[r] * P.p_fct, t = P.a_t[r] * P.t_fct;
   for (size_t i = 0; i < nm; i++) {
@@ -356,10 +440,35 @@ void read_atmosphere(trh_problem &P, const std::string &path, const std::string 
   read_molfile(P, molpath);
   P.a_rad.resize(nr); P.a_p.resize(nr); P.a_t.resize(nr); P.a_mm.resize(nr);
   P.a_q.assign(nm, std::vector<double>(nr)); P.a_d.assign(nm, std::vector<double>(nr));
+  // qmol/qscale (readatm.c:394-405): species named in qmol get their abundance multiplied by
+  // 10^qscale while the rows are read (:519-522); names that are not atmosphere species are
+  // ignored, as in the reference.  H2 and He (molecule IDs 105 and 2, :465-466) are then
+  // re-balanced to fill what the other species leave, keeping their ratio (:535-540).
+  std::vector<int> qidx(P.qmol.size(), -1);
+  int iH2 = -1, iHe = -1;
+  if (!P.qscale.empty()) {
+    for (size_t k = 0; k < P.qmol.size(); k++)
+      for (size_t j = 0; j < nm; j++) if (P.qmol[k] == P.species[j]) { qidx[k] = (int)j; break; }
+    for (size_t j = 0; j < nm; j++) { if (iH2 < 0 && P.mol_id[j] == 105) iH2 = (int)j; if (iHe < 0 && P.mol_id[j] == 2) iHe = (int)j; }
+    if (iH2 < 0 || iHe < 0)    // the reference indexes its abundance table with -1 here
+      throw Fail(TRX_E_ARG, "qscale needs H2 and He among the atmosphere species (they absorb the re-normalisation)");
+  }
   for (size_t r = 0; r < nr; r++) {
     if (rows[r].size() < 3 + nm) throw Fail(TRX_E_ARG, "atmosphere row with too few columns");
     P.a_rad[r] = rows[r][0] + P.zerorad; P.a_p[r] = rows[r][1]; P.a_t[r] = rows[r][2];
-    for (size_t i = 0; i < nm; i++) P.a_q[i][r] = rows[r][3 + i];
+    double metals = 0.0;
+    for (size_t i = 0; i < nm; i++) {
+      double q = rows[r][3 + i];
+      for (size_t k = 0; k < qidx.size(); k++)
+        if (qidx[k] == (int)i) { q *= std::pow(10.0, P.qscale[k]); break; }
+      P.a_q[i][r] = q;
+      if ((int)i != iH2 && (int)i != iHe) metals += q;
+    }
+    if (!P.qscale.empty()) {
+      const double ratio = P.a_q[iH2][r] / P.a_q[iHe][r];
+      P.a_q[iHe][r] =         (1 - metals) / (1.0 + ratio);
+      P.a_q[iH2][r] = ratio * (1 - metals) / (1.0 + ratio);
+    }
     layer_state(P, r);
   }
   bool sorted = true, reversed = true;                     // readatm.c:583-617
@@ -487,8 +596,10 @@ void make_layer_sampling(trh_problem &P)
 {
   const size_t nm = P.species.size(), na = P.a_rad.size();
   const double raddelt = num(P, "raddelt", -1);
+  P.out_rad_fct = P.rad_fct;
   if (na == 1 || raddelt == -1) P.rad = P.a_rad;
   else {
+    if (num(P, "radfct") > 0) P.out_rad_fct = num(P, "radfct");      // makesample.c:158-161 (hint fct wins when set)
     // makesample.c:144-300 (makesample) with the atmosphere sampling as reference
     double ini = num(P, "radlow"), fin = num(P, "radhigh");
     if (ini <= 0) ini = P.a_rad.front();
@@ -732,7 +843,7 @@ void fill_pods(trh_problem &P)
 
   trx_atm &a = P.atm;
   a = trx_atm{};
-  a.nlayer = (int)P.rad.size(); a.rad_fct = P.rad_fct;
+  a.nlayer = (int)P.rad.size(); a.rad_fct = P.out_rad_fct;
   a.radius = P.rad.data(); a.temp = P.t_k.data(); a.press = P.p.data();
   a.density = P.dens.data(); a.abund = P.q.data(); a.zpart = P.zpart.data();
 
@@ -792,10 +903,19 @@ void fill_pods(trh_problem &P)
 void load(trh_problem &P, int argc, const char *const *argv)
 {
   parse_args(P, argc, argv);
+  if (P.exit_requested) return;
   make_wn_sampling(P);
   if (!has(P, "atm") || str(P, "atm") == "NULL" || str(P, "atm") == "-")
     throw Fail(TRX_E_ARG, "no atmospheric file specified");
   P.allowq = (float)num(P, "allowq");
+  if (has(P, "qscale")) {                                   // argum.c:881-890
+    for (auto &w : split_ws(str(P, "qscale"))) P.qscale.push_back(std::atof(w.c_str()));
+    if (!has(P, "qmol")) throw Fail(TRX_E_ARG, "qscale given without qmol");
+    P.qmol = split_ws(str(P, "qmol"));
+    if (P.qmol.size() != P.qscale.size())
+      throw Fail(TRX_E_ARG, "qscale (" + std::to_string(P.qscale.size()) + ") and qmol (" + std::to_string(P.qmol.size()) +
+                            ") should have the same number of elements");
+  }
   read_atmosphere(P, join_path(P.base_dir, str(P, "atm")), join_path(P.base_dir, str(P, "molfile")));
   bool have_grid = false;
   if (has(P, "opacityfile")) {
@@ -832,11 +952,22 @@ int trh_load(int argc, const char *const *argv, trh_problem **out, char *err, in
     if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what());
     delete P; return TRX_E_NOMEM;
   }
+  if (P->exit_requested) { delete P; return 1; }      // --help / --version: printed, nothing to run
   *out = P;
   return TRX_OK;
 }
 
 void trh_free(trh_problem *p) { delete p; }
+const char *trh_messages(const trh_problem *p) { return p ? p->messages.c_str() : ""; }
+
+int trh_option_table(int i, const char **name, int *has_arg, char *kind)
+{
+  if (i < 0 || i >= kNumOptions) return TRX_E_ARG;
+  if (name) *name = kOptions[i].name;
+  if (has_arg) *has_arg = kOptions[i].has_arg ? 1 : 0;
+  if (kind) *kind = kOptions[i].kind;
+  return TRX_OK;
+}
 const trx_static *trh_static(const trh_problem *p) { return p ? &p->st : nullptr; }
 const trx_atm *trh_atm(const trh_problem *p) { return p ? &p->atm : nullptr; }
 const trx_opts *trh_opts(const trh_problem *p) { return p ? &p->opts : nullptr; }
@@ -947,7 +1078,7 @@ int trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *la
   for (int64_t w = 0; w < p->nwn; w++) {                     // tau.c:634-638 (ips = reversed radii)
     const double wn = p->wn_i + (double)w * p->wn_d;
     std::fprintf(out, "%12.7f   %.5e     %12.4f     %04ld\n", 1.0 / wn * 1.0 * 1e4,
-                 tau[w * nr + last[w]], p->rad[(size_t)(nr - 1 - last[w])] * p->rad_fct / 1e5, (long)last[w]);
+                 tau[w * nr + last[w]], p->rad[(size_t)(nr - 1 - last[w])] * p->out_rad_fct / 1e5, (long)last[w]);
   }
   if (out != stdout) std::fclose(out);
   return TRX_OK;
@@ -975,6 +1106,112 @@ int trh_write_intens(const trh_problem *p, const double *intens, const char *pat
   }
   std::fclose(out);
   return TRX_OK;
+}
+
+// detailout (tau.c:526-605): the optical depth, the molecular extinction or the CIA extinction
+// at the wavenumbers requested with detailtau / detailext / detailcia, one row per radius
+// (per impact parameter for the optical depth).  which: 0 tau, 1 ext, 2 cia.  Arrays in the
+// layouts of trx_debug: tau [wn][height], e and e_cs [layer][wn].
+// The reference prints the CIA table through a float pointer laid over its array of doubles
+// (CIA_DOFLOAT with PREC_CS = double, tau.c:540,591): column m of a row shows 32 of the 64
+// bits of value m/2.  That is what its files contain, so that is what is written here.
+int trh_write_detail(const trh_problem *p, int which, const double *arr)
+{
+  if (!p || !arr || which < 0 || which > 2) return TRX_E_ARG;
+  const trh_problem::Detail &d = which == 0 ? p->det_tau : which == 1 ? p->det_ext : p->det_cia;
+  if (d.wn.empty()) return TRX_OK;
+  const int64_t nr = (int64_t)p->rad.size(), nw = p->nwn;
+  FILE *out = std::fopen(join_path(p->base_dir, d.file).c_str(), "w");
+  if (!out) return TRX_E_ARG;
+  auto wn_at = [&](int64_t w) { return p->wn_i + (double)w * p->wn_d; };
+  std::vector<int64_t> idx;
+  std::fprintf(out, "#Radius-w=>    ");
+  for (double val : d.wn) {                                  // tau.c:554-572
+    int64_t u = nw - 1, lo;
+    if (val == wn_at(u)) lo = u;
+    else { lo = 0; while (u - lo > 1) { const int64_t m = (u + lo) / 2; if (wn_at(m) > val) u = m; else lo = m; } }
+    idx.push_back(lo);
+    std::fprintf(out, "%-15.8g", wn_at(lo));
+  }
+  std::fprintf(out, "\n");
+  std::vector<double> row((size_t)nr);
+  for (int64_t m = 0; m < nr; m++) {
+    std::fprintf(out, "%-15.7g", which == 0 ? p->rad[(size_t)(nr - 1 - m)] : p->rad[(size_t)m]);
+    for (int64_t w : idx) {
+      double val;
+      if (which == 0) val = arr[w * nr + m];
+      else if (which == 1) val = arr[m * nw + w];
+      else {
+        for (int64_t k = 0; k < nr; k++) row[(size_t)k] = arr[k * nw + w];   // the reference's e_cs[wn][layer] row
+        float f; std::memcpy(&f, (const char *)row.data() + 4 * (size_t)m, 4);
+        val = f;
+      }
+      std::fprintf(out, "%-15.7g", val);
+    }
+    std::fprintf(out, "\n");
+  }
+  std::fclose(out);
+  return TRX_OK;
+}
+int trh_wants_detail(const trh_problem *p, int which)
+{
+  if (!p) return 0;
+  return !(which == 0 ? p->det_tau : which == 1 ? p->det_ext : p->det_cia).wn.empty();
+}
+
+// outsample (makesample.c:642-672, 744-770; written by makeipsample when `savefiles` is set,
+// :598-599): the four samplings as the reference holds them at that point -- the wavelength
+// sampling is never filled on this path, its block is all zeros.
+int trh_write_sample(const trh_problem *p, const char *path)
+{
+  if (!p) return TRX_E_ARG;
+  const std::string f = path ? std::string(path) : str(*p, "outsample");
+  if (f.empty()) return TRX_OK;
+  FILE *out = f == "-" ? stdout : std::fopen(join_path(p->base_dir, f).c_str(), "w");
+  if (!out) return TRX_E_ARG;
+  auto head = [&](const char *desc, double fct, double i, double fin, double d) {
+    std::fprintf(out, "############################\n   %-12s Sampling\n----------------------------\n", desc);
+    std::fprintf(out, "Factor to cgs units: %g\n", fct);
+    std::fprintf(out, "Initial value: %g\nFinal value: %g\n", i, fin);
+    std::fprintf(out, "Spacing: %g\n", d);
+  };
+  const size_t nr = p->rad.size();
+  const double raddelt = num(*p, "raddelt", -1);
+  const bool kept = (p->a_rad.size() == 1 || raddelt == -1);
+  head("Wavenumber", 1.0, p->wn_i, p->wn_f, p->wn_d);
+  std::fprintf(out, "Oversample: %i\nNumber of elements: %lli\n", 1, (long long)p->nwn);
+  head("Wavelength", 0.0, 0.0, 0.0, 0.0);
+  std::fprintf(out, "Oversample: %i\nNumber of elements: %lli\n", 0, 0LL);
+  head("Radius", p->out_rad_fct, p->rad.front(), p->rad.back(), kept ? 0.0 : raddelt);
+  std::fprintf(out, "Number of elements: %lli\nValues: ", (long long)nr);
+  for (size_t k = 0; k < nr; k++) std::fprintf(out, " %12.8g", p->rad[k]);
+  std::fprintf(out, "\n");
+  head("Impact parameter", p->out_rad_fct, p->rad.back(), p->rad.front(), kept ? 0.0 : -raddelt);
+  std::fprintf(out, "Oversample: %i\nNumber of elements: %lli\nValues: ", kept ? 0 : 1, (long long)nr);
+  for (size_t k = 0; k < nr; k++) std::fprintf(out, " %12.8g", p->rad[nr - 1 - k]);
+  std::fprintf(out, "\n");
+  if (out != stdout) std::fclose(out);
+  return TRX_OK;
+}
+
+// every file a run of this problem writes, one "kind path" per line (what each output option
+// turned into): spectrum, toomuch, intens, sample, dumps, detailtau/ext/cia
+const char *trh_output_plan(trh_problem *p)
+{
+  if (!p) return "";
+  std::string &o = p->err; o.clear();
+  auto add = [&](const char *k, const std::string &v) { o += k; o += ' '; o += v; o += '\n'; };
+  add("spectrum", str(*p, "outspec"));
+  if (has(*p, "outtoomuch")) add("toomuch", str(*p, "outtoomuch"));
+  if (has(*p, "outintens") && p->opts.solution == TRX_SOL_ECLIPSE) add("intens", str(*p, "outintens"));
+  const bool dumps = str(*p, "savefiles").compare(0, 3, "yes") == 0;
+  if (dumps) add("dumps", "tau.dat CIA.dat mol_extion.dat total_extion.dat cloud_extion.dat scatt_extion.dat");
+  if (dumps && has(*p, "outsample")) add("sample", str(*p, "outsample"));
+  if (!p->det_tau.wn.empty()) add("detailtau", p->det_tau.file + " " + std::to_string(p->det_tau.wn.size()));
+  if (!p->det_ext.wn.empty()) add("detailext", p->det_ext.file + " " + std::to_string(p->det_ext.wn.size()));
+  if (!p->det_cia.wn.empty()) add("detailcia", p->det_cia.file + " " + std::to_string(p->det_cia.wn.size()));
+  if (has(*p, "opacityfile")) add("opacity", str(*p, "opacityfile"));
+  return o.c_str();
 }
 
 // `savefiles yes` (tau.c:180-190, 311-335): the reference's dumps of the intermediates, in its

@@ -27,9 +27,16 @@ int main(int argc, char **argv)
   const double t_start = now_s();
   double t0 = t_start;
   int rc = trh_load(argc, argv, &P, err, sizeof(err));
+  if (rc == 1) return EXIT_SUCCESS;                       // --help / --version (argum.c:582-607)
   if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: %s (%s)\n", err, trx_strerror(rc)); return EXIT_FAILURE; }
   const char *verb = trh_option(P, "verb");
   const int verblevel = verb ? std::atoi(verb) : 2;
+  if (verblevel >= 2)                                     // TOUT_WARN is level 2, TOUT_INFO level 3 (flags_tr.h:181-185)
+    for (const char *m = trh_messages(P); m && *m; ) {
+      const char *e = std::strchr(m, '\n'); const size_t n = e ? (size_t)(e - m) : std::strlen(m);
+      if (m[0] == 'W' || verblevel >= 3) std::fprintf(stderr, "transit_hip: %s: %.*s\n", m[0] == 'W' ? "warning" : "note", (int)(n > 3 ? n - 3 : 0), m + 3);
+      m = e ? e + 1 : m + n;
+    }
   if (verblevel > 3) std::printf("Check point: 00 - 04 inputs read and sampled:  dt = %.4f sec.\n\n", now_s() - t0);
 
   t0 = now_s();
@@ -65,15 +72,19 @@ int main(int argc, char **argv)
   trx_debug dbg{};
   const bool want_toomuch = trh_option(P, "outtoomuch") != nullptr;
   const char *sf = trh_option(P, "savefiles");
-  const bool want_dumps = sf && std::string(sf) == "yes";                       // argum.c:456-470
-  if (want_toomuch || want_dumps) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
-  if (want_dumps) { e.resize((size_t)nwn * nr); ecs.resize((size_t)nwn * nr); dbg.e = e.data(); dbg.e_cs = ecs.data(); }
+  const bool want_dumps = sf && std::strncmp(sf, "yes", 3) == 0;                // argum.c:461-470
+  const bool det_tau = trh_wants_detail(P, 0), det_ext = trh_wants_detail(P, 1), det_cia = trh_wants_detail(P, 2);
+  if (want_dumps && trh_write_sample(P, nullptr) != TRX_OK)                     // makesample.c:598-599
+    std::fprintf(stderr, "transit_hip: cannot write the sampling file\n");
+  if (want_toomuch || want_dumps || det_tau) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
+  if (want_dumps || det_ext) { e.resize((size_t)nwn * nr); dbg.e = e.data(); }
+  if (want_dumps || det_cia) { ecs.resize((size_t)nwn * nr); dbg.e_cs = ecs.data(); }
   std::vector<double> intens;
   const bool want_intens = trh_option(P, "outintens") != nullptr && trh_opts(P)->solution == TRX_SOL_ECLIPSE;
   if (want_intens) { intens.resize((size_t)nwn * trh_opts(P)->nangles); dbg.intens = intens.data(); }
 
   t0 = now_s();
-  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), (want_toomuch || want_dumps || want_intens) ? &dbg : nullptr);
+  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), (dbg.tau || dbg.e || dbg.e_cs || dbg.intens) ? &dbg : nullptr);
   if (rc != TRX_OK) {
     std::fprintf(stderr, "transit_hip: trx_run failed: %s (%s)\n", trx_strerror(rc), trx_last_error(h));
     trx_destroy(h); trh_free(P); return EXIT_FAILURE;
@@ -89,6 +100,9 @@ int main(int argc, char **argv)
   if (want_intens) trh_write_intens(P, intens.data(), nullptr);
   if (want_dumps && trh_write_dumps(P, e.data(), ecs.data(), tau.data(), nullptr) != TRX_OK)
     std::fprintf(stderr, "transit_hip: cannot write the savefiles dumps\n");
+  if ((det_tau && trh_write_detail(P, 0, tau.data()) != TRX_OK) || (det_ext && trh_write_detail(P, 1, e.data()) != TRX_OK) ||
+      (det_cia && trh_write_detail(P, 2, ecs.data()) != TRX_OK))
+    std::fprintf(stderr, "transit_hip: cannot write a detail file\n");
   rc = trh_write_spectrum(P, spectrum.data(), nullptr);
   if (rc != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the spectrum file\n");
   if (verblevel > 3) std::printf("Check point: 00 - 15 outputs written:  wall since start = %.4f sec.\n", now_s() - t_start);

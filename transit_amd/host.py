@@ -58,6 +58,18 @@ def _load():
         lib.trh_install_opacity.restype = C.c_int
         lib.trh_option.argtypes = [C.c_void_p, C.c_char_p]
         lib.trh_option.restype = C.c_char_p
+        lib.trh_messages.argtypes = [C.c_void_p]
+        lib.trh_messages.restype = C.c_char_p
+        lib.trh_output_plan.argtypes = [C.c_void_p]
+        lib.trh_output_plan.restype = C.c_char_p
+        lib.trh_option_table.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_char)]
+        lib.trh_option_table.restype = C.c_int
+        lib.trh_wants_detail.argtypes = [C.c_void_p, C.c_int]
+        lib.trh_wants_detail.restype = C.c_int
+        lib.trh_write_detail.argtypes = [C.c_void_p, C.c_int, _abi.c_double_p]
+        lib.trh_write_detail.restype = C.c_int
+        lib.trh_write_sample.argtypes = [C.c_void_p, C.c_char_p]
+        lib.trh_write_sample.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -66,6 +78,20 @@ class HostError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__("%s (%d): %s" % (_abi.STATUS.get(code, "?"), code, msg))
         self.code = code
+
+
+def option_table():
+    """[(name, has_arg, kind)] of the host side's option table (same names and order as the
+    reference's, argum.c:112-320); kind: 'a' acted on, 'n' no effect as in the reference,
+    'w' accepted with a warning, 'x' rejected."""
+    lib = _load()
+    out, i = [], 0
+    while True:
+        name, has_arg, kind = C.c_char_p(), C.c_int(), C.c_char()
+        if lib.trh_option_table(i, C.byref(name), C.byref(has_arg), C.byref(kind)) != 0:
+            return out
+        out.append((name.value.decode(), bool(has_arg.value), kind.value.decode()))
+        i += 1
 
 
 class Problem:
@@ -84,6 +110,8 @@ class Problem:
             rc = lib.trh_load(len(args), arr, C.byref(handle), err, len(err))
         finally:
             os.chdir(old)
+        if rc == 1:
+            raise HostError(1, "--help/--version was served (text on stdout); nothing to run")
         if rc != 0:
             raise HostError(rc, err.value.decode(errors="replace"))
         self._h = handle
@@ -133,6 +161,37 @@ class Problem:
     def option(self, name: str) -> Optional[str]:
         v = _load().trh_option(self._h, name.encode())
         return v.decode() if v is not None else None
+
+    def messages(self):
+        """Notes ('I: ...') and warnings ('W: ...') recorded while loading."""
+        v = _load().trh_messages(self._h)
+        return [m for m in (v.decode(errors="replace") if v else "").split("\n") if m]
+
+    def output_plan(self):
+        """{kind: value} of every file a run of this problem writes."""
+        v = _load().trh_output_plan(self._h)
+        return dict(ln.split(" ", 1) for ln in (v.decode() if v else "").split("\n") if ln)
+
+    def write_detail(self, which: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        old = os.getcwd()
+        try:
+            os.chdir(self.cwd)
+            rc = _load().trh_write_detail(self._h, which, a.ctypes.data_as(_abi.c_double_p))
+        finally:
+            os.chdir(old)
+        if rc != 0:
+            raise HostError(rc, "write_detail failed")
+
+    def write_sample(self, path: Optional[str] = None):
+        old = os.getcwd()
+        try:
+            os.chdir(self.cwd)
+            rc = _load().trh_write_sample(self._h, path.encode() if path else None)
+        finally:
+            os.chdir(old)
+        if rc != 0:
+            raise HostError(rc, "write_sample failed")
 
     def reload_atm(self, values: np.ndarray):
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
