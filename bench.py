@@ -183,14 +183,12 @@ def main():
     st = P.static
     st.device = local
     comm = None
-    if (world > 1 and not args.rehearse) or args.comm_single:   # in-stream all-reduce of the layer maxima (engine side)
+    if (world > 1 and not args.rehearse) or args.comm_single:   # RCCL communicator of the handle: its one gather
         comm = tdist.create_comm(world, rank, local)
         st.comm, st.nranks, st.rank = comm, world, rank
     t0 = time.time()
     eng = Engine(st)
     t_create = time.time() - t0
-    if world > 1 and args.rehearse:
-        eng.set_host_allreduce(tdist.torch_allreduce_max())
     opts = P.opts
     opts.layer_chunk = args.layer_chunk
     opts.profile = 0
@@ -201,8 +199,11 @@ def main():
 
     def step():
         eng.run_device(P.atm, opts, spec_local.data_ptr())
-        if world > 1:       # the single gather of the path (RCCL; host memory when rehearsing)
-            dist.all_gather_into_tensor(gathered, spec_local if cdev == dev else spec_local.cpu())
+        if world > 1:       # the single exchange of the path
+            if comm is not None:      # trx_gather: ncclAllGather on the handle's stream (C ABI)
+                eng.gather(spec_local.data_ptr(), gathered.data_ptr(), mpad)
+            else:                     # rehearsal on a shared GPU: gloo through host memory
+                dist.all_gather_into_tensor(gathered, spec_local.cpu())
 
     def fence():
         if world > 1:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRX_ABI_VERSION 1
+#define TRX_ABI_VERSION 2
 
 typedef enum {
   TRX_OK            =  0,
@@ -116,10 +116,9 @@ typedef struct {
   int32_t ncia;
   const trx_cia *cia;
 
-  /* multi-GPU job: communicator from trx_comm_create (NULL for one GPU).  With
-   * a communicator each handle sweeps only the lines whose profiles can reach
-   * its shard and the per-layer maximum line strength (extinction.c:399-427,
-   * a global quantity) is agreed by one small in-stream all-reduce per step. */
+  /* multi-GPU job: communicator from trx_comm_create (NULL for one GPU); used by
+   * trx_gather only.  A handle whose shard [wn_lo, wn_hi) is a part of the grid
+   * sweeps only the lines whose profiles can reach it. */
   void   *comm;
   int32_t nranks, rank;
 
@@ -166,9 +165,10 @@ typedef struct {
   int32_t scat_flag;      /* 0 none, 1 Lecavelier, 2 polarizability            */
   double  scat_logext;
   /* execution knobs (no effect on results)                                    */
-  int32_t layer_chunk;    /* layers swept per top-down step (<= 32; 16 in transit geometry);
-                             0 = automatic: 12 on a handle's first spectrum, then the depth
-                             the previous spectrum reached in equal steps               */
+  int32_t layer_chunk;    /* layers swept per top-down step; 0 = automatic: up to 64 where the
+                             profiles are narrow (one kernel walks the line list with one lane
+                             per layer), up to 32 otherwise; the depth the previous spectrum
+                             reached is split into equal steps                          */
   int32_t eager;          /* 1 = sweep every layer (debug dumps of all layers) */
   int32_t profile;        /* 1 = bracket every kernel with HIP events (trx_stats timings) */
 } trx_opts;
@@ -199,9 +199,9 @@ typedef struct {
   double  ms_create_table;/* device time of the Voigt-table build              */
   double  ms_run_total;   /* device time of the last run, first to last kernel */
   double  ms_sweep;       /* line-sweep kernels (pass 1 + pass 2 + accumulate) */
-  double  ms_k_sweep;      /* sum over launches of k_group_sweep (+ all-reduce)   */
-  double  ms_k_sticky;     /* sum over launches of k_sticky_index                */
-  double  ms_k_accum;     /* sum over launches of k_accumulate                 */
+  double  ms_k_sweep;      /* sum over launches of the line kernel (k_line_walk, or k_group_sweep where profiles are wide) */
+  double  ms_k_sticky;     /* unused (the sticky Doppler index is computed once per run)  */
+  double  ms_k_accum;     /* sum over launches of k_walk_combine / k_accumulate  */
   int64_t sweep_launches; /* launches of each sweep kernel (gated no-op ones too) */
   double  ms_tau;         /* optical-depth kernels                             */
   double  ms_cia;         /* host wall time of queueing the CIA kernels          */
@@ -254,15 +254,15 @@ int  trx_comm_unique_id(void *id_out /* TRX_COMM_ID_BYTES */);
 int  trx_comm_create(const void *id, int nranks, int rank, int device, void **comm_out);
 void trx_comm_destroy(void *comm);
 
-/* Sharded job without RCCL: the two exchanges of the path (the per-step maxima + rays-open
- * flag, and the end-of-run status maxima) go through a host function instead -- the stream is
- * drained, `n` doubles are handed to `fn`, which must return their element-wise maximum over
- * all ranks in place (blocking, collective: every rank calls it the same number of times).
- * For transports other than RCCL (MPI, gloo, ...) and for testing N ranks on fewer GPUs;
- * slower than the in-stream all-reduce by two stream drains per step.  Replaces trx_static.comm
- * (which must then be NULL); call it right after trx_create.  fn = NULL switches it off. */
-typedef int (*trx_allreduce_max_fn)(double *values, int n, void *user);
-int trx_set_host_allreduce(trx_handle *h, trx_allreduce_max_fn fn, void *user);
+/* The one exchange of a wavenumber-sharded job ("one ncclAllGather of the
+ * spectrum slices at the end"): every rank hands in `count` doubles in device memory (its slice,
+ * padded to the same count on every rank) and receives all ranks' slices in rank order in d_all
+ * (nranks * count doubles, device memory).  ncclAllGather on the handle's stream over the
+ * communicator given in trx_static.comm; synchronised on return.  A handle without a
+ * communicator (single rank) copies its slice.  Nothing else is exchanged between ranks: the
+ * per-layer maximum line strength, the only global quantity of the path (extinction.c:399-427),
+ * is computed by every rank from the same small set of candidate lines. */
+int  trx_gather(trx_handle *h, const void *d_slice, void *d_all, int64_t count);
 
 const char *trx_strerror(int status);
 const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */

@@ -39,3 +39,11 @@ def rel_err(a, b, floor=1e-300):
     if not m.any():
         return 0.0
     return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m])))
+
+
+def free_port():
+    """A TCP port that is free right now (rendezvous of multi-process tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -1,9 +1,9 @@
 """One rank of a sharded job on a SHARED GPU (launched by tests/test_multirank_gpu.py through
-torch.distributed.run, backend gloo).  RCCL refuses two ranks on one device, so the two
-exchanges of the path travel through the host transport (trx_set_host_allreduce): same
-engine logic as the RCCL job -- per-rank line windows, all-reduced layer maxima with the
-lagged rays-open flag, job-wide depth hint and stop/resume decision -- on real shards.
-Rank 0 checks the stitched spectra against an unsharded handle."""
+torch.distributed.run, backend gloo).  RCCL refuses two ranks on one device, so the one
+exchange of the path -- the gather of the slices -- goes over gloo here; everything else is
+the engine as every rank of an N-GPU job runs it: its own line window, its own depth hint and
+stop/resume decisions, layer maxima from the shared candidate set.  Rank 0 checks the
+stitched spectra against an unsharded handle."""
 import os
 import sys
 
@@ -45,7 +45,6 @@ def main():
     lo, hi = shard_bounds(nwn, world, rank)
     P.set_shard(lo, hi)
     eng = Engine(P.static)
-    eng.set_host_allreduce(tdist.torch_allreduce_max())
     mpad = tdist.padded_len(nwn, world)
     ok = True
     for k, sc in enumerate(scales):

@@ -35,7 +35,7 @@ def test_hip_library_exports():
     for n in names:
         assert hasattr(lib, n), n
     lib.trx_abi_version.restype = ctypes.c_int
-    assert lib.trx_abi_version() == 1
+    assert lib.trx_abi_version() == 2
     lib.trx_strerror.restype = ctypes.c_char_p
     lib.trx_strerror.argtypes = [ctypes.c_int]
     assert b"sorted" in lib.trx_strerror(-7)
@@ -47,8 +47,8 @@ def test_hip_code_object_is_gfx950():
         build.build_hip()
     blob = open(path, "rb").read()
     assert b"gfx950" in blob
-    for k in (b"k_group_sweep", b"k_sticky_index", b"k_accumulate", b"k_optical_depth",
-              b"k_emission", b"k_modulation", b"k_voigt_bins"):
+    for k in (b"k_line_walk", b"k_walk_combine", b"k_layer_max", b"k_group_sweep", b"k_sticky_index", b"k_accumulate",
+              b"k_optical_depth", b"k_emission", b"k_modulation", b"k_voigt_bins"):
         assert k in blob, k
 
 

@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+from cases import free_port
+
 from transit_amd.shard import all_bounds, shard_bounds, stitch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,7 +56,7 @@ def test_two_rank_gloo_gather(tmp_path, case):
     script.write_text(WORKER % {"root": ROOT, "case": case, "out": out})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     from cases import golden

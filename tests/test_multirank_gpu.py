@@ -6,6 +6,8 @@ import sys
 
 import pytest
 
+from cases import free_port
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -15,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_sharded_job_matches_the_unsharded_handle(case, world, scales):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", "29631",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(HERE, "multirank_gpu_worker.py"), case, scales]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -30,7 +32,7 @@ def test_bench_multirank_code_path_rehearsal():
     root = os.path.dirname(HERE)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "2", "--rehearse", "--lines", "30000", "--layers", "40",
            "--wnhigh", "2700"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_double_p = C.POINTER(C.c_double)
 c_int16_p = C.POINTER(C.c_int16)

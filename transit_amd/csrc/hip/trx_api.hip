@@ -26,6 +26,7 @@
 
 #include "transit_hip.h"
 #include "trx_kernels.hip.h"
+#include "trx_walk.hip.h"
 
 using namespace trx;
 
@@ -43,10 +44,10 @@ struct DevBuf {
 struct trx_handle {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CIA kernels, overlapped with the first sweep step
-  // stream4: the line sweep (strengths, sticky index, accumulation) of step c+1 runs while
-  // `stream` integrates the optical depth of step c; ev_ac[c] = step c accumulated
+  // stream4: the line sweep of step c+1 runs while `stream` integrates the optical depth of
+  // step c; ev_ac[c] = extinction of step c complete
   hipStream_t stream4 = nullptr;
-  std::vector<hipEvent_t> ev_ac, ev_tau;     // ev_tau[c] = optical depth of step c done (sharded: its flag is staged)
+  std::vector<hipEvent_t> ev_ac;
   hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr;
   std::string err;
 
@@ -71,9 +72,16 @@ struct trx_handle {
   int sub_f = 1;                        // sub-buckets per coarse cell of d_cntsub (1: it is d_cntge)
   LinesDev L{};
   std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
-  void *comm = nullptr; int nranks = 1, rank = 0;
-  trx_allreduce_max_fn ar_fn = nullptr; void *ar_user = nullptr;   // host transport instead of RCCL
-  bool sharded() const { return comm != nullptr || ar_fn != nullptr; }
+  void *comm = nullptr; int nranks = 1, rank = 0;          // RCCL communicator: only trx_gather uses it
+  bool windowed() const { return lo > 0 || hi < nwn; }    // a shard sweeps only the lines that can reach it
+  // candidates for the layer maximum (k_cand_*): indices into the line arrays; -1 = use every line
+  DevBuf d_cand; int64_t ncand = -1;
+  DevBuf d_kmax;                                            // [layer][nmx] strongest single line of the run
+  // the walk (k_line_walk): one record per line, line ranges of ngw groups, plans per profile reach
+  DevBuf d_walk, d_wbase, d_part;
+  std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
+  struct Plan { bool built = false; DevBuf blo, bhi, off; int64_t records = 0; };
+  Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw; };
   std::vector<Cia> cia;
@@ -81,7 +89,7 @@ struct trx_handle {
   // per-run workspaces (grown on demand)
   int ws_nr = 0, ws_chunk = 0;
   DevBuf d_layer_f64, d_layer_i32, d_SG, d_idop8, d_sticky, d_counters, d_flags, d_part3;
-  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip, d_acc, d_arbuf;
+  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip, d_acc;
   // opacity grid (optional)
   bool has_grid = false; long og_nmol = 0, og_ntemp = 0, og_nlayer = 0, og_nwave = 0;
   std::vector<double> og_temp; std::vector<int32_t> og_molidx; DevBuf d_og_o, d_og_layer, d_og_itemp, d_iso_mx, d_pm, d_kmaxpm;
@@ -369,6 +377,27 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   std::vector<double> elow(s->elow, s->elow + n), gf(s->gf, s->gf + n);
   std::vector<int16_t> iso(s->isoid, s->isoid + n);
   int rc;
+  // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
+  // ranges of ngw consecutive groups per isotope block
+  h->walk_ok = s->osamp < (1 << 28) && h->tab_n < ((int64_t)1 << 31) && !gfirst.empty();
+  if (h->walk_ok) {
+    std::vector<WalkLine> walk((size_t)n);
+    for (int64_t i = 0; i < n; i++) { walk[i].wavn = wavn[i]; walk[i].elow = elow[i]; walk[i].gf = gf[i]; walk[i].meta = 0; walk[i].cell = 0; }
+    for (size_t g = 0; g < gfirst.size(); g++) {
+      WalkLine &a = walk[(size_t)gfirst[g]];
+      a.meta |= 1 | (gimod[g] << 2); a.cell = gidiv[g];
+      walk[(size_t)gfirst[g] + gcount[g] - 1].meta |= 2;
+    }
+    int ngw = 32;
+    if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
+    else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 8192) ngw *= 2;
+    h->ngw = ngw;
+    h->h_wbase.assign(s->niso + 1, 0);
+    for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
+    h->nwaves = h->h_wbase[s->niso];
+    if ((rc = upload(h, h->d_walk, walk)) || (rc = upload(h, h->d_wbase, h->h_wbase))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));    // `walk` dies here
+  }
   if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_elow, elow)) || (rc = upload(h, h->d_gf, gf)) ||
       (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
       (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
@@ -384,6 +413,32 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   L.giown = h->d_giown.as<int32_t>(); L.giso = h->d_giso.as<int16_t>(); L.gwavn = h->d_gwavn.as<double>();
   L.gblock = h->d_gblock.as<int32_t>(); L.cnt_ge = h->d_cntge.as<int32_t>();
   h->stats.nlines_inrange = h->ninrange; h->stats.ngroups = h->ngroups; h->stats.nadd = h->nadd;
+  // ---- candidates for the layer maximum: lines no other line of their isotope dominates
+  // (trx_walk.hip.h).  Falls back to "every line" when the filter would not pay.
+  h->ncand = -1;
+  if (h->ninrange > 4096 && s->niso > 0) {
+    double emin = HUGE_VAL, emax = -HUGE_VAL;
+    for (int64_t i = 0; i < n; i++) if (inr[i]) { emin = std::min(emin, elow[i]); emax = std::max(emax, elow[i]); }
+    CandGeom Gm{};
+    Gm.e_min = emin; Gm.e_scale = emax > emin ? kCandGrid / (emax - emin) : 0.0;
+    Gm.w_min = wn0;  Gm.w_scale = own_last > wn0 ? kCandGrid / (own_last - wn0) : 0.0;
+    const int cap = (int)std::max<int64_t>(4096, n / 8);
+    DevBuf d_M, d_n;
+    const size_t mbytes = sizeof(unsigned long long) * (size_t)s->niso * kCandGrid * kCandGrid;
+    if ((rc = ensure(h, d_M, mbytes)) || (rc = ensure(h, d_n, sizeof(int))) || (rc = ensure(h, h->d_cand, sizeof(int32_t) * (size_t)cap))) return rc;
+    HIPCHK(h, hipMemsetAsync(d_M.p, 0, mbytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_n.p, 0, sizeof(int), h->stream));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_cand_cellmax, dim3(nb), dim3(256), 0, h->stream, (long long)n, L.wavn, L.elow, L.gf, L.iso, L.inrange, Gm, d_M.as<unsigned long long>());
+    hipLaunchKernelGGL(k_cand_prefix, dim3((unsigned)s->niso), dim3(kCandGrid), 0, h->stream, d_M.as<unsigned long long>());
+    hipLaunchKernelGGL(k_cand_select, dim3(nb), dim3(256), 0, h->stream, (long long)n, L.wavn, L.elow, L.gf, L.iso, L.inrange, Gm,
+                       d_M.as<unsigned long long>(), h->d_cand.as<int32_t>(), d_n.as<int>(), cap);
+    int nc = 0;
+    HIPCHK(h, hipMemcpyAsync(&nc, d_n.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (nc > 0 && nc <= cap) h->ncand = nc;
+  }
   return TRX_OK;
 }
 
@@ -493,9 +548,9 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllReduce; }
+  bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 Rccl &rccl()
 {
@@ -508,7 +563,7 @@ Rccl &rccl()
   R.GetUniqueId  = (decltype(R.GetUniqueId))dlsym(R.lib, "ncclGetUniqueId");
   R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.lib, "ncclCommInitRank");
   R.CommDestroy  = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
-  R.AllReduce    = (decltype(R.AllReduce))dlsym(R.lib, "ncclAllReduce");
+  R.AllGather    = (decltype(R.AllGather))dlsym(R.lib, "ncclAllGather");
   R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
   return R;
 }
@@ -600,33 +655,120 @@ struct Spans {
   ~Spans() { for (Span &sp : v) { if (sp.a) (void)hipEventDestroy(sp.a); if (sp.b) (void)hipEventDestroy(sp.b); } }
 };
 
-// ---- one step of the line sweep: strengths (+ all-reduce), sticky index, accumulation ----
+// ---- one step of the line sweep ------------------------------------------------------------
 struct SweepMode {
-  bool eager = false, prof = false, skip_done = false, permol = false, use_comm = false;
-  double ethresh = 0; int chunk_index = 0;
+  bool eager = false, prof = false, skip_done = false, permol = false;
+  double ethresh = 0;
   int nmx = 1; const int32_t *d_iso_mx = nullptr;   // output slot per isotope (per-molecule sweeps)
   double *d_e = nullptr;                             // [layer][nmx][nsh]
-  double *ar_cur = nullptr, *ar_prev = nullptr;      // maxima of this step / previous step's staging
-  double *d_SG = nullptr; uint8_t *d_idop8 = nullptr;   // strength buffers of this step
-  // strengths run on st_sweep; sticky index and accumulation on st_acc after ev_sweep
-  // (null: the handle's stream, no event needed)
-  hipStream_t st_sweep = nullptr, st_acc = nullptr; hipEvent_t ev_sweep = nullptr;
-  hipEvent_t ev_before_allreduce = nullptr;          // sharded + two streams: previous step's flag is staged
+  const double *d_kmax = nullptr;                    // [layer][nmx] (k_layer_max)
+  const int *d_sticky = nullptr;                     // [layer][iso] (k_sticky_index)
+  hipStream_t st = nullptr;                          // null: the handle's stream
 };
 
-int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const int32_t *d_npre, const int32_t *psmax,
+// widest profile (in fine-grid points) any isotope with lines can use in layer r
+long long layer_psmax(const trx_handle *h, const int32_t *psmax, int r)
+{
+  long long pm = 0;
+  for (int b = 0; b < h->niso; b++)
+    if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)r * h->niso + b]);
+  return pm;
+}
+
+// Frame size of the walk for layer r (bins a line can reach = 2*Rc + 2 with Rc whole cells of
+// profile half-width), or 0 when its profiles are wider than the largest frame: the layer then
+// takes the two-kernel path.  A per-LAYER property, so that the path a layer takes -- and with
+// it the order of its sums -- does not depend on how the layers are grouped into steps.
+int walk_frame_bins(const trx_handle *h, const int32_t *psmax, int r)
+{
+  if (!h->walk_ok) return 0;
+  const long long rc = layer_psmax(h, psmax, r) / h->osamp;
+  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : rc <= 7 ? 16 : 0;
+}
+
+// plan of the line ranges for a frame of nb bins (built once per handle and frame size)
+int walk_plan(trx_handle *h, int nb, hipStream_t st, WalkPlan &P, trx_handle::Plan *&pl)
+{
+  const int v = nb == 2 ? 0 : nb == 4 ? 1 : nb == 8 ? 2 : 3;
+  pl = &h->plan[v];
+  int rc;
+  if (!pl->built) {
+    const size_t nw = (size_t)std::max(h->nwaves, 1);
+    if ((rc = ensure(h, pl->blo, 4 * nw)) || (rc = ensure(h, pl->bhi, 4 * nw)) || (rc = ensure(h, pl->off, 8 * (nw + 1)))) return rc;
+  }
+  P.nwaves = h->nwaves; P.ngw = h->ngw; P.wbase = h->d_wbase.as<int32_t>();
+  P.blo = pl->blo.as<int32_t>(); P.bhi = pl->bhi.as<int32_t>(); P.off = pl->off.as<int64_t>();
+  if (!pl->built) {
+    hipLaunchKernelGGL(k_wave_plan, dim3(1), dim3(256), 0, st, P, h->niso, h->d_gblock.as<int32_t>(), h->d_gidiv.as<int32_t>(),
+                       nb / 2 - 1, (long long)h->lo, (long long)h->hi);
+    int64_t total = 0;
+    HIPCHK(h, hipMemcpyAsync(&total, P.off + h->nwaves, sizeof total, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));                 // once per handle and frame size
+    pl->records = total; pl->built = true;
+  }
+  return TRX_OK;
+}
+
+template <int NB>
+void launch_walk(const WalkArgs &A, bool prof, unsigned nwaves, hipStream_t st)
+{
+  if (prof) hipLaunchKernelGGL((k_line_walk<NB, true>), dim3(nwaves), dim3(64), 0, st, A);
+  else      hipLaunchKernelGGL((k_line_walk<NB, false>), dim3(nwaves), dim3(64), 0, st, A);
+}
+
+// The walk: layers r_top .. r_top-nc+1 (nc <= 64) in one kernel + the combine of its partial sums.
+int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, int r_top, int nc, const SweepMode &M, Spans *sp)
+{
+  hipStream_t st = M.st ? M.st : h->stream;
+  if (const char *e = std::getenv("TRX_WALK_NB")) nb = std::max(nb, std::atoi(e));      // (experiments)
+  WalkPlan P{}; trx_handle::Plan *pl = nullptr;
+  int rc = walk_plan(h, nb, st, P, pl);
+  if (rc) return rc;
+  const size_t pbytes = sizeof(double) * kWalkLayers * (size_t)std::max<int64_t>(pl->records, 1);
+  if (h->d_part.bytes < pbytes) {
+    HIPCHK(h, hipStreamSynchronize(st));                 // an earlier step may still be reading the old buffer
+    if ((rc = ensure(h, h->d_part, pbytes))) return rc;
+  }
+  if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
+  // bins a range's frame never visits (a jump over empty cells) must read as zero
+  HIPCHK(h, hipMemsetAsync(h->d_part.p, 0, pbytes, st));
+  WalkArgs A{};
+  A.lines = h->d_walk.as<WalkLine>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
+  A.gblock = h->d_gblock.as<int32_t>(); A.P = P;
+  A.niso = h->niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp; A.lo = h->lo; A.hi = h->hi;
+  A.r_top = r_top; A.nc = nc; A.Y = Y; A.wcut = d_wcut; A.kmax = M.d_kmax; A.ethresh = M.ethresh;
+  A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol; A.sticky_idop = M.d_sticky;
+  A.dthr = h->d_dopthr.as<double>(); A.e2tab = h->d_e2tab.as<double>();
+  A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>(); A.table = h->tab;
+  A.part = h->d_part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
+  A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
+  const unsigned nw = (unsigned)h->nwaves;
+  if (nw > 0) {
+    if (nb == 2) launch_walk<2>(A, M.prof, nw, st);
+    else if (nb == 4) launch_walk<4>(A, M.prof, nw, st);
+    else if (nb == 8) launch_walk<8>(A, M.prof, nw, st);
+    else launch_walk<16>(A, M.prof, nw, st);
+  }
+  if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
+  CombineArgs C{};
+  C.P = P; C.niso = h->niso; C.gblock = h->d_gblock.as<int32_t>(); C.lo = h->lo; C.nsh = h->nsh; C.r_top = r_top; C.nc = nc;
+  C.nmx = M.nmx; C.iso_mx = M.d_iso_mx; C.part = h->d_part.as<double>(); C.e = M.d_e;
+  C.flags = h->d_flags.as<int>(); C.last = A.last; C.eager = M.eager;
+  hipLaunchKernelGGL(k_walk_combine, dim3((unsigned)((h->nsh + kCombineBins - 1) / kCombineBins)), dim3(64), 0, st, C);
+  if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
+  return TRX_OK;
+}
+
+// The two-kernel form (profiles wider than the walk's largest frame): strengths, accumulation.
+int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const int32_t *psmax,
                 int r_top, int nc, int nc_max, const SweepMode &M, Spans *sp)
 {
-  hipStream_t st = M.st_acc ? M.st_acc : h->stream;
-  hipStream_t sts = M.st_sweep ? M.st_sweep : st;
+  hipStream_t st = M.st ? M.st : h->stream;
   const int niso = h->niso; const int64_t nsh = h->nsh;
   const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
-  double *d_SG = M.d_SG ? M.d_SG : h->d_SG.as<double>();
-  uint8_t *d_idop8 = M.d_idop8 ? M.d_idop8 : h->d_idop8.as<uint8_t>();
-  // lines whose profiles can reach this shard in any layer of the step (contiguous per
-  // isotope block).  The layer maximum is global (extinction.c:399-427 runs over every
-  // line): with a communicator each rank reduces its own window and the maxima are
-  // all-reduced in-stream; a shard running on its own scans every line itself.
+  double *d_SG = h->d_SG.as<double>();
+  uint8_t *d_idop8 = h->d_idop8.as<uint8_t>();
+  // lines whose profiles can reach this shard in any layer of the step (contiguous per isotope block)
   Segments GG{};
   {
     long long tot = 0;
@@ -634,7 +776,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
       const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
       if (gb0 == gb1) continue;
       int ga = gb0, gz = gb1;
-      if (M.use_comm) {
+      if (h->windowed()) {
         long long psm = 0;
         for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
         const long long lo_f = (long long)h->osamp * h->lo - psm;
@@ -653,46 +795,19 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   const long long seg_lines = GG.base[GG.n];
   constexpr unsigned kSpan = kXcds * kAccumXcdGroup;
   const unsigned tblocks = (unsigned)(((ntiles + 3) / 4 + kSpan - 1) / kSpan * kSpan);   // multiple of 8*G: xcd_grouped_x()
-  const double *ggate = M.use_comm ? M.ar_prev + kMaxChunk : nullptr;     // lagged global "rays open" flag
-  if (sp && sp->begin(Spans::kSweep, sts)) return fail(h, TRX_E_HIP, "event");
+  if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
-    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, sts,
+    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
                        h->L, Y, GG, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, h->d_e2tab.as<double>(), d_wcut,
-                       d_SG, d_idop8, (unsigned long long *)M.ar_cur,
-                       M.nmx, M.d_iso_mx, h->d_flags.as<int>(), ggate, (int)M.eager);
-  }
-  if (M.use_comm) {   // maxima of this step's layers + "any ray still open" flag of the previous step
-    if (M.ev_before_allreduce) HIPCHK(h, hipStreamWaitEvent(sts, M.ev_before_allreduce, 0));
-    if (h->comm) {
-      if (rccl().AllReduce(M.ar_cur, M.ar_cur, (size_t)(kMaxChunk + 1), ncclDouble, ncclMax, (ncclComm_t)h->comm, sts) != ncclSuccess)
-        return fail(h, TRX_E_HIP, "ncclAllReduce(kmax) failed");
-    } else {
-      double buf[kMaxChunk + 1];
-      HIPCHK(h, hipMemcpyAsync(buf, M.ar_cur, sizeof buf, hipMemcpyDeviceToHost, sts));
-      HIPCHK(h, hipStreamSynchronize(sts));
-      if (h->ar_fn(buf, kMaxChunk + 1, h->ar_user) != 0) return fail(h, TRX_E_HIP, "host all-reduce (layer maxima) failed");
-      HIPCHK(h, hipMemcpyAsync(M.ar_cur, buf, sizeof buf, hipMemcpyHostToDevice, sts));
-      HIPCHK(h, hipStreamSynchronize(sts));          // buf leaves scope
-    }
-  }
-  if (sp && sp->end(sts)) return fail(h, TRX_E_HIP, "event");
-  if (M.ev_sweep) {
-    HIPCHK(h, hipEventRecord(M.ev_sweep, sts));
-    HIPCHK(h, hipStreamWaitEvent(st, M.ev_sweep, 0));
-  }
-  if (sp && sp->begin(Spans::kSticky, st)) return fail(h, TRX_E_HIP, "event");
-  if (h->ngroups > 0) {
-    hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nc * niso)), dim3(64), 0, st,
-                       h->L, Y, niso, r_top, nc, M.ar_cur, M.nmx, M.d_iso_mx, M.ethresh, h->d_adop.as<double>(), h->ndop,
-                       h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), ggate, (int)M.eager);
+                       d_SG, d_idop8, h->d_flags.as<int>(), (int)M.eager);
   }
   if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
   if (h->ngroups > 0) {
     AccumArgs A{};
     A.L = h->L; A.Y = Y; A.niso = niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp;
     A.nwn = h->nwn; A.lo = h->lo; A.nsh = nsh; A.r_top = r_top; A.nc = nc; A.ntiles = ntiles;
-    A.SG = d_SG; A.idop8 = d_idop8; A.sticky_idop = h->d_sticky.as<int>();
-    A.kmaxc = M.ar_cur; A.ethresh = M.ethresh; A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol;
+    A.SG = d_SG; A.idop8 = d_idop8; A.sticky_idop = M.d_sticky;
+    A.kmaxc = M.d_kmax; A.ethresh = M.ethresh; A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol;
     A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
     A.table = h->tab; A.e = M.d_e;
     // (profiled runs count every group in the tile of its own coarse cell: whole-cell windows)
@@ -702,12 +817,8 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
     A.last = M.skip_done ? h->d_last.as<int>() : nullptr;
     // layers whose profiles span >= 64 coarse bins go to the lanes-own-bins kernel
     unsigned wide_mask = 0;
-    for (int c = 0; c < nc; c++) {
-      long long pm = 0;
-      for (int b = 0; b < niso; b++)
-        if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)(r_top - c) * niso + b]);
-      if ((2 * pm) / h->osamp + 1 >= 64) wide_mask |= 1u << c;   // measured: 16 or 32 here is 4x slower at configs[2] size, 128/256 no better
-    }
+    for (int c = 0; c < nc; c++)
+      if ((2 * layer_psmax(h, psmax, r_top - c)) / h->osamp + 1 >= 64) wide_mask |= 1u << c;   // measured: 16 or 32 here is 4x slower at configs[2] size, 128/256 no better
     A.skip_mask = wide_mask;
     if (M.prof) HIPCHK(h, hipMemsetAsync(h->d_part3.p, 0, 24 * (size_t)nc_max * tblocks, st));
     if (wide_mask != (nc >= 32 ? 0xffffffffu : ((1u << nc) - 1u)))
@@ -725,6 +836,37 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
       hipLaunchKernelGGL(k_sum_parts_gated, dim3((unsigned)nc), dim3(256), 0, st, h->d_part3.as<unsigned long long>(),
                          (int)tblocks, 3, k, h->d_counters.as<unsigned long long>(), 3, r_top, h->d_flags.as<int>(), (int)M.eager);
   }
+  return TRX_OK;
+}
+
+// Strongest single line and sticky Doppler index of ALL nv layers (states) at once: both depend
+// on the inputs only, not on how far the rays get, so they leave the per-step chain.
+int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_npre, int nv, const double *temp_k,
+                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st)
+{
+  int rc;
+  if ((rc = ensure(h, h->d_kmax, sizeof(double) * (size_t)nv * nmx)) || (rc = ensure(h, h->d_sticky, sizeof(int) * (size_t)nv * std::max(h->niso, 1))))
+    return rc;
+  HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * (size_t)nv * nmx, st));
+  if (h->ngroups == 0) return TRX_OK;
+  // the pruning argument needs c*nu/T well above the rounding of 1 - exp(-c*nu/T) (trx_walk.hip.h)
+  bool pruned = h->ncand > 0;
+  for (int r = 0; r < nv && pruned; r++) if (kExpCte * kTliEfct * h->wn_i / temp_k[r] < 1e-5) pruned = false;
+  const long long n = pruned ? h->ncand : h->nlines;
+  for (int r0 = 0; r0 < nv; r0 += 32768) {
+    const int nr = std::min(32768, nv - r0);
+    LayerDev Yr = Y; Yr.negc_over_t += r0; Yr.strength_f += (size_t)r0 * h->niso;
+    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, st, h->L, Yr, h->niso,
+                       pruned ? h->d_cand.as<int32_t>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
+                       (unsigned long long *)(h->d_kmax.as<double>() + (size_t)r0 * nmx));
+  }
+  for (int r0 = 0; r0 < nv; r0 += 4096) {               // one wave per (layer, isotope)
+    const int nr = std::min(4096, nv - r0);
+    hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nr * h->niso)), dim3(64), 0, st,
+                       h->L, Y, h->niso, r0 + nr - 1, nr, h->d_kmax.as<double>(), nmx, d_iso_mx, ethresh, h->d_adop.as<double>(), h->ndop,
+                       h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), 1);
+  }
+  HIPCHK(h, hipGetLastError());
   return TRX_OK;
 }
 
@@ -791,12 +933,21 @@ const char *trx_strerror(int st)
 
 const char *trx_last_error(const trx_handle *h) { return h ? h->err.c_str() : ""; }
 
-int trx_set_host_allreduce(trx_handle *h, trx_allreduce_max_fn fn, void *user)
+// The single exchange of a wavenumber-sharded job: every rank contributes `count` doubles (its
+// spectrum slice, padded to the same length on every rank) and receives all of them, rank
+// order, in d_all -- ncclAllGather on the handle's stream, synchronised on return.  Without a
+// communicator (one rank) it is a device copy.
+int trx_gather(trx_handle *h, const void *d_slice, void *d_all, int64_t count)
 {
-  if (!h) return TRX_E_ARG;
-  if (fn && h->comm) return fail(h, TRX_E_ARG, "the handle already has an RCCL communicator");
-  h->ar_fn = fn; h->ar_user = user;
-  h->hint_layers = 0;                       // the next spectrum plans like a first one on every rank
+  if (!h || !d_slice || !d_all || count < 0) return TRX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->comm) {
+    if (rccl().AllGather(d_slice, d_all, (size_t)count, ncclDouble, (ncclComm_t)h->comm, h->stream) != ncclSuccess)
+      return fail(h, TRX_E_HIP, "ncclAllGather failed");
+  } else if (d_all != d_slice) {
+    HIPCHK(h, hipMemcpyAsync(d_all, d_slice, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return TRX_OK;
 }
 
@@ -904,7 +1055,6 @@ void trx_destroy(trx_handle *h)
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream4) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamDestroy(h->stream4); }
   for (auto e : h->ev_ac) (void)hipEventDestroy(e);
-  for (auto e : h->ev_tau) (void)hipEventDestroy(e);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -942,6 +1092,13 @@ int trx_width_grids(const trx_handle *h, double *adop, double *alor)
   return TRX_OK;
 }
 
+namespace {
+struct EventPair {        // released on every return path
+  hipEvent_t a = nullptr, b = nullptr;
+  ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+}  // namespace
+
 static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum,
                     trx_debug *dbg)
 {
@@ -960,11 +1117,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const bool eager = o->eager != 0, prof = o->profile != 0;
-  // Layers per step.  Large steps amortise the line reads and the launch chain, small ones
-  // waste less when the depth is unknown.  Default: 12 on a handle's first spectrum; once
-  // the previous spectrum's depth is known (hint_layers) the plan is its depth in equal
-  // steps of at most kMaxChunk layers, and the run returns right there (below).
-  // (sharded job: the depth is the all-reduced one, so every rank plans the same steps)
+  // A handle remembers how deep the previous spectrum went (hint_layers) and plans its steps to
+  // end exactly there; the run returns at that depth and goes on only if rays are still open.
   const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
   int rc;
 
@@ -974,20 +1128,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const size_t nli = LH.nli;
   std::vector<double> &f64 = LH.f64;
   const int32_t *psmax = LH.psmax;
-  int nc_max = o->layer_chunk > 0 ? o->layer_chunk : 12;
-  int nc_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;   // k_optical_depth: one block row per height
-  if (o->layer_chunk <= 0 && stop_at_hint_ok) {
-    // wide profiles (fine grids): the deep layers are by far the most expensive and a tile
-    // only learns between steps that its rays have stopped -- keep the steps short there
-    const int r_deep = nr - h->hint_layers;
-    long long pm = 0;
-    for (int b = 0; b < h->niso; b++)
-      if (h->h_gblock[b] != h->h_gblock[b + 1]) pm = std::max<long long>(pm, psmax[(size_t)r_deep * h->niso + b]);
-    if ((2 * pm) / h->osamp + 1 >= 64) nc_cap = std::min(nc_cap, 8);
-    const int steps = (h->hint_layers + nc_cap - 1) / nc_cap;
-    nc_max = (h->hint_layers + steps - 1) / steps;
-  }
-  nc_max = std::max(3, std::min(nc_max, nc_cap));
+  // Layers per step.  The walk (narrow profiles) takes up to 64 layers, one per lane; its cost
+  // hardly depends on how many lanes are busy, so its steps are as large as the plan allows.
+  // The two-kernel form keeps a strength buffer per layer in flight: at most kMaxChunk, and
+  // 8 where the profiles are wide (a tile only learns between steps that its rays stopped).
+  // Optical depths are integrated in sub-steps of at most tau_cap layers.
+  const int tau_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;
+  const int user_chunk = o->layer_chunk > 0 ? std::max(3, o->layer_chunk) : 0;
   // layer-only scalars of the scattering / cloud models (tau.c:193-214, extinction.c:617-621)
   double *press = &f64[LH.extra_off], *tempk = press + nr, *mdens = tempk + nr, *nH = mdens + nr,
          *scat_pol = nH + nr, *radv = scat_pol + nr;
@@ -1035,37 +1182,31 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   std::vector<double> ipv(nr);
   for (int i = 0; i < nr; i++) ipv[i] = a->radius[nr - 1 - i];
 
-  // ---- CIA -----------------------------------------------------------------
   double ms_cia = 0;
 
   // ---- workspaces -------------------------------------------------------------
-  const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
   // Two streams: the line sweep of step c+1 (saturates the machine) runs on stream4 while the
   // optical depth of step c (a latency chain on a few waves) is integrated on the main stream.
-  // The layer maxima get one slot per step (the optical-depth kernel no longer resets them);
-  // A sharded job does the same; there the optical-depth kernel of step c stages its
-  // rays-open flag in slot c+1 and the all-reduce of step c+1 waits for it (ev_tau).
   const bool pipelined = !h->has_grid;
-  const size_t sg_stride = gr_b * nc_max;
-  const size_t ar_slots = pipelined ? (size_t)nr + 2 : 2;
-  if ((rc = ensure(h, h->d_SG, sizeof(double) * sg_stride)) ||
-      (rc = ensure(h, h->d_idop8, sg_stride)) ||
-      (rc = ensure(h, h->d_sticky, sizeof(int) * nli)) || (rc = ensure(h, h->d_counters, 24 * (size_t)nr)) ||
+  bool any_wide = false;                      // some layer needs the two-kernel form
+  for (int r = 0; r < nr && !any_wide; r++) any_wide = walk_frame_bins(h, psmax, r) == 0;
+  const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
+  const int sg_layers = any_wide ? (user_chunk ? std::min(user_chunk, kMaxChunk) : kMaxChunk) : 1;
+  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * sg_layers)) || (rc = ensure(h, h->d_idop8, gr_b * sg_layers)) ||
+      (rc = ensure(h, h->d_counters, 24 * (size_t)nr)) ||
       (rc = ensure(h, h->d_flags, 64)) ||
       (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
       (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
       (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
-      (rc = ensure(h, h->d_status, 16)) || (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)) ||
-      (rc = ensure(h, h->d_arbuf, sizeof(double) * ar_slots * (kMaxChunk + 1))))
+      (rc = ensure(h, h->d_status, 16)) || (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)))
     return rc;
   if (pipelined)
     while ((int)h->ev_ac.size() < nr + 1) {
-      hipEvent_t e1, e2;
-      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
-      h->ev_ac.push_back(e1); h->ev_tau.push_back(e2);
+      hipEvent_t e1;
+      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+      h->ev_ac.push_back(e1);
     }
-  if (prof && (rc = ensure(h, h->d_part3, 24 * (size_t)nc_max * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
+  if (prof && any_wide && (rc = ensure(h, h->d_part3, 24 * (size_t)kMaxChunk * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
     return rc;
   if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_geom, geom)) ||
       (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))
@@ -1083,20 +1224,6 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
   HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
   HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
-  if (pipelined) {   // one slot of layer maxima per step, all zero
-    HIPCHK(h, hipMemsetAsync(h->d_arbuf.p, 0, sizeof(double) * ar_slots * (kMaxChunk + 1), st));
-    if (h->sharded()) {
-      // rays-open flags: slot 0 (all-reduced with the first step's maxima) and the last slot,
-      // which stands in as "the step before the first" for the first sweep's gate
-      static const double one = 1.0;
-      double *a = h->d_arbuf.as<double>();
-      HIPCHK(h, hipMemcpyAsync(a + kMaxChunk, &one, sizeof one, hipMemcpyHostToDevice, st));
-      HIPCHK(h, hipMemcpyAsync(a + (ar_slots - 1) * (kMaxChunk + 1) + kMaxChunk, &one, sizeof one, hipMemcpyHostToDevice, st));
-    }
-  } else {           // all-reduce staging: maxima 0, "rays still open" flags 1
-    static const std::vector<double> ar0 = [] { std::vector<double> v(2 * (kMaxChunk + 1), 0.0); v[kMaxChunk] = 1.0; v[2 * kMaxChunk + 1] = 1.0; return v; }();
-    HIPCHK(h, hipMemcpyAsync(h->d_arbuf.p, ar0.data(), ar0.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  }
   { const int f0[8] = {(int)std::min<int64_t>(nsh, 0x7fffffff), 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(h->d_flags.p, f0, sizeof(f0), hipMemcpyHostToDevice, st)); }
 
@@ -1107,6 +1234,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
   const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride, *d_pw = d_mh0 + (nr + 1);
+  (void)nli;
 
   // ---- opacity grid: temperature bracket and weights per layer (extinction.c:549-574) ----
   std::vector<double> og_layer; std::vector<int> og_itemp;
@@ -1137,6 +1265,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(h->ev_inputs, st));
   HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
   if (pipelined) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0));
+  hipStream_t st_sweep = pipelined ? h->stream4 : st;
+  // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
+  if (!h->has_grid &&
+      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep))) return rc;
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
   // after that step's kernels, which are what the GPU is waiting for.
@@ -1151,11 +1283,11 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- events -----------------------------------------------------------------
   Spans spans;
-  hipEvent_t ev_begin, ev_end;
-  HIPCHK(h, hipEventCreate(&ev_begin)); HIPCHK(h, hipEventCreate(&ev_end));
-  HIPCHK(h, hipEventRecord(ev_begin, st));
+  EventPair ev;
+  HIPCHK(h, hipEventCreate(&ev.a)); HIPCHK(h, hipEventCreate(&ev.b));
+  HIPCHK(h, hipEventRecord(ev.a, st));
 
-  // ---- top-down sweep in chunks of layers (tau.c:235-290) ----
+  // ---- top-down sweep in steps of layers (tau.c:235-290) ----
   int nchunks = 0, r_top = nr - 1;
   bool stop_at_hint = stop_at_hint_ok;
   int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
@@ -1163,16 +1295,35 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
   for (;;) {
   for (; r_top >= 0; ) {
-    // Chunk plan: nc_max layers per step; when the previous spectrum on this handle
-    // stopped at hint_layers (retrieval loops re-run near-identical atmospheres), end a
-    // step exactly there so that no layer below the expected last one is swept in vain.
-    int nc = std::min(nc_max, r_top + 1);
-    {
-      const int swept = nr - 1 - r_top;
-      if (!eager && h->hint_layers > swept && h->hint_layers - swept < nc) nc = std::max(h->hint_layers - swept, swept == 0 ? 3 : 1);
-      nc = std::min(nc, r_top + 1);
+    // Step plan.  Layers still to go: down to the previous spectrum's depth when it is known
+    // (retrieval loops re-run near-identical atmospheres), else to the bottom.  The step takes
+    // the layers of ONE kind from r_top down -- walk or two-kernel form -- up to that kind's cap,
+    // in equal parts when more than one step is needed.
+    const int swept = nr - 1 - r_top;
+    int togo = r_top + 1;
+    if (!eager && h->hint_layers > swept) togo = std::min(togo, h->hint_layers - swept);
+    int nb = 0, nc;
+    if (h->has_grid) nc = std::min(togo, user_chunk ? user_chunk : kMaxChunk);
+    else {
+      nb = walk_frame_bins(h, psmax, r_top);
+      int run = 1;                                 // consecutive layers of the same kind below r_top
+      while (run < togo && (walk_frame_bins(h, psmax, r_top - run) == 0) == (nb == 0)) run++;
+      int cap = nb ? kWalkLayers : kMaxChunk;
+      if (!nb && (2 * layer_psmax(h, psmax, std::max(0, r_top - run + 1))) / h->osamp + 1 >= 64) cap = 8;
+      if (user_chunk) cap = std::min(cap, user_chunk);
+      else if (!nb && !stop_at_hint_ok) cap = std::min(cap, 12);      // depth unknown, expensive layers: small steps
+      const int steps = (run + cap - 1) / cap;
+      nc = (run + steps - 1) / steps;
+      if (nb) for (int c = 1; c < nc; c++) nb = std::max(nb, walk_frame_bins(h, psmax, r_top - c));
     }
-    double *tau_next_ar = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
+    if (swept == 0) nc = std::max(nc, 3);          // the first step holds the 2- and 3-point rays (eclipse.c:65-80)
+    nc = std::min(nc, r_top + 1);
+    if (nb && swept == 0) for (int c = 1; c < nc; c++) {          // (a widened first step stays one kind)
+      const int v = walk_frame_bins(h, psmax, r_top - c);
+      if (v == 0) { nb = 0; break; }
+      nb = std::max(nb, v);
+    }
+    if (!nb && !h->has_grid && nc > sg_layers) nc = sg_layers;
     if (h->has_grid) {
       if (prof && spans.begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
       GridArgs Gd{};
@@ -1185,25 +1336,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
     } else {
       SweepMode M{};
-      M.eager = eager; M.prof = prof; M.ethresh = o->ethresh; M.chunk_index = nchunks;
+      M.eager = eager; M.prof = prof; M.ethresh = o->ethresh;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
-      M.d_e = h->d_e.as<double>(); M.use_comm = h->sharded();
-      M.ar_cur = h->d_arbuf.as<double>() + (size_t)(nchunks & 1) * (kMaxChunk + 1);
-      M.ar_prev = h->d_arbuf.as<double>() + (size_t)((nchunks + 1) & 1) * (kMaxChunk + 1);
-      if (pipelined) {
-        // maxima of step c into slot c.  Single GPU: the optical-depth kernel must not touch the
-        // slots (its staging pointer goes to the scratch slot, the last one).  Sharded: it stages
-        // only its rays-open flag, in slot c+1, which the all-reduce of step c+1 waits for; the
-        // sweep of step c is gated by the all-reduced flag in slot c-1.
-        double *a = h->d_arbuf.as<double>();
-        M.ar_cur = a + (size_t)nchunks * (kMaxChunk + 1);
-        M.ar_prev = h->sharded() ? a + (nchunks > 0 ? (size_t)nchunks - 1 : ar_slots - 1) * (kMaxChunk + 1) : nullptr;
-        tau_next_ar = a + (h->sharded() ? (size_t)nchunks + 1 : ar_slots - 1) * (kMaxChunk + 1);
-        M.st_sweep = h->stream4; M.st_acc = h->stream4;
-        M.ev_before_allreduce = (h->sharded() && nchunks > 0) ? h->ev_tau[nchunks - 1] : nullptr;
+      M.d_e = h->d_e.as<double>(); M.d_kmax = h->d_kmax.as<double>(); M.d_sticky = h->d_sticky.as<int>();
+      M.st = st_sweep;
+      if (h->ngroups > 0) {
+        if (nb) rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr);
+        else    rc = sweep_chunk(h, Y, d_wcut, psmax, r_top, nc, sg_layers, M, prof ? &spans : nullptr);
+        if (rc) return rc;
       }
-      if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, psmax, r_top, nc, nc_max, M, prof ? &spans : nullptr))) return rc;
-      if (pipelined) {     // the optical-depth kernel of this step follows its accumulation
+      if (pipelined) {     // the optical depth of this step follows its extinction
         HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], h->stream4));
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_ac[nchunks], 0));
       }
@@ -1213,11 +1355,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
     }
     if (prof && spans.begin(Spans::kTau, st)) return fail(h, TRX_E_HIP, "event");
-    {
+    for (int done = 0; done < nc; ) {          // optical depth in sub-steps of at most tau_cap layers
+      int nt = std::min(tau_cap, nc - done);
+      if (swept == 0 && done == 0) nt = std::min(nc, std::max(nt, 3));
       TauArgs T{};
       T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
       T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
-      T.r_top = r_top; T.nc = nc; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
+      T.r_top = r_top - done; T.nc = nt; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
       T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
       T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
       T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
@@ -1226,7 +1370,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
-      T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.next_ar = tau_next_ar; T.flag_only = (pipelined && h->sharded()) ? 1 : 0;
+      T.pw = d_pw; T.acc = h->d_acc.as<double>();
       if (o->solution == TRX_SOL_ECLIPSE) {
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
         const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
@@ -1238,9 +1382,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       } else
         hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
                            dim3(256), 0, st, T);
+      done += nt;
     }
     if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
-    if (pipelined && h->sharded()) HIPCHK(h, hipEventRecord(h->ev_tau[nchunks], st));
     r_top -= nc; nchunks++;
     // the previous spectrum stopped here: compute the spectrum now and look at the outcome
     // on the host (which this call waits for anyway) instead of queueing gated no-op steps
@@ -1274,31 +1418,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
   }
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipEventRecord(ev_end, st));
+  HIPCHK(h, hipEventRecord(ev.b, st));
 
   // ---- results back -----------------------------------------------------------
-  if (h->comm) {
-    // every rank must take the same decision below and plan the same steps next time:
-    // rays still open (flags[0]) and deepest stopping height (flags[4]) become job-wide maxima
-    if (rccl().AllReduce(h->d_flags.p, h->d_flags.p, 8, ncclInt32, ncclMax, (ncclComm_t)h->comm, st) != ncclSuccess)
-      return fail(h, TRX_E_HIP, "ncclAllReduce(flags) failed");
-  } else if (h->ar_fn) {
-    int fl[8]; double fd[8];
-    HIPCHK(h, hipMemcpyAsync(fl, h->d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    for (int k = 0; k < 8; k++) fd[k] = fl[k];
-    if (h->ar_fn(fd, 8, h->ar_user) != 0) return fail(h, TRX_E_HIP, "host all-reduce (status) failed");
-    for (int k = 0; k < 8; k++) fl[k] = (int)fd[k];
-    HIPCHK(h, hipMemcpyAsync(h->d_flags.p, fl, sizeof fl, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-  }
   HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
   if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(counters.data(), h->d_counters.p, 24 * (size_t)nr, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   // rays still descending below the expected depth (the atmosphere changed): go on from there
-  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) { stop_at_hint = false; continue; }
+  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) { stop_at_hint = false; h->hint_layers = 0; continue; }
   break;
   }
 
@@ -1308,7 +1437,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   h->hint_layers = flags_host[4];
   S.neval = S.nskip = S.sum_bins = 0;
   for (int r = 0; r < nr; r++) { S.sum_bins += (int64_t)counters[3*r]; S.neval += (int64_t)counters[3*r+1]; S.nskip += (int64_t)counters[3*r+2]; }
-  float ms = 0; (void)hipEventElapsedTime(&ms, ev_begin, ev_end); S.ms_run_total = ms;
+  float ms = 0; (void)hipEventElapsedTime(&ms, ev.a, ev.b); S.ms_run_total = ms;
   S.ms_cia = ms_cia;
   S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   S.ms_k_sweep = S.ms_k_sticky = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
@@ -1321,7 +1450,6 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     S.sweep_launches = nchunks;
     S.ms_sweep = S.ms_k_sweep + S.ms_k_sticky + S.ms_k_accum;
   }
-  (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
 
   if (dbg) {
     if (dbg->e)    HIPCHK(h, hipMemcpy(dbg->e, h->d_e.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
@@ -1360,27 +1488,33 @@ int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double
   int rc;
   LayerHost LH;
   if ((rc = prep_layers(h, nv, temp, density, zpart, 0, LH))) return rc;
-  const int nc_max = 12;
   const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
   std::vector<int32_t> slots(iso_slot, iso_slot + std::max(niso, 1));
-  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * nc_max)) || (rc = ensure(h, h->d_idop8, gr_b * nc_max)) ||
-      (rc = ensure(h, h->d_sticky, sizeof(int) * LH.nli)) || (rc = ensure(h, h->d_flags, 64)) ||
+  bool any_wide = false;
+  for (int r = 0; r < nv && !any_wide; r++) any_wide = walk_frame_bins(h, LH.psmax, r) == 0;
+  const int sg_layers = any_wide ? 12 : 1;
+  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * sg_layers)) || (rc = ensure(h, h->d_idop8, gr_b * sg_layers)) ||
+      (rc = ensure(h, h->d_flags, 64)) || (rc = ensure(h, h->d_counters, 24 * (size_t)nv)) ||
       (rc = ensure(h, h->d_pm, sizeof(double) * (size_t)nv * nslot * nsh)) ||
-      (rc = ensure(h, h->d_kmaxpm, sizeof(double) * (size_t)kMaxChunk * nslot)) ||
       (rc = upload(h, h->d_layer_f64, LH.f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_iso_mx, slots)))
     return rc;
   HIPCHK(h, hipMemsetAsync(h->d_pm.p, 0, sizeof(double) * (size_t)nv * nslot * nsh, st));
   LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
   layer_dev(h, LH, nv, Y, d_wcut, d_npre);
-  int nchunks = 0;
-  for (int r_top = nv - 1; r_top >= 0; ) {
-    const int nc = std::min(nc_max, r_top + 1);
-    HIPCHK(h, hipMemsetAsync(h->d_kmaxpm.p, 0, sizeof(double) * (size_t)kMaxChunk * nslot, st));
+  if ((rc = layer_maxima_and_sticky(h, Y, d_npre, nv, temp, nslot, h->d_iso_mx.as<int32_t>(), ethresh, st))) return rc;
+  for (int r_top = nv - 1; r_top >= 0 && h->ngroups > 0; ) {
+    int nb = walk_frame_bins(h, LH.psmax, r_top);
+    int nc = 1;
+    const int cap = nb ? kWalkLayers : sg_layers;
+    while (nc < cap && nc <= r_top && (walk_frame_bins(h, LH.psmax, r_top - nc) == 0) == (nb == 0)) nc++;
+    if (nb) for (int c = 1; c < nc; c++) nb = std::max(nb, walk_frame_bins(h, LH.psmax, r_top - c));
     SweepMode M{};
-    M.eager = true; M.ethresh = ethresh; M.chunk_index = nchunks; M.nmx = nslot; M.d_iso_mx = h->d_iso_mx.as<int32_t>();
-    M.permol = true; M.d_e = h->d_pm.as<double>(); M.ar_cur = h->d_kmaxpm.as<double>(); M.ar_prev = nullptr;
-    if ((rc = sweep_chunk(h, Y, d_wcut, d_npre, LH.psmax, r_top, nc, nc_max, M, nullptr))) return rc;
-    r_top -= nc; nchunks++;
+    M.eager = true; M.ethresh = ethresh; M.nmx = nslot; M.d_iso_mx = h->d_iso_mx.as<int32_t>();
+    M.permol = true; M.d_e = h->d_pm.as<double>(); M.d_kmax = h->d_kmax.as<double>(); M.d_sticky = h->d_sticky.as<int>();
+    if (nb) rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr);
+    else    rc = sweep_chunk(h, Y, d_wcut, LH.psmax, r_top, nc, sg_layers, M, nullptr);
+    if (rc) return rc;
+    r_top -= nc;
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(out, h->d_pm.p, sizeof(double) * (size_t)nv * nslot * nsh, hipMemcpyDeviceToHost, st));

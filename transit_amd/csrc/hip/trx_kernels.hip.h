@@ -78,15 +78,11 @@ __device__ __forceinline__ int xcd_grouped_x()
   return (x / span) * span + (x % kXcds) * G + (x % span) / kXcds;
 }
 
-// Gate of the line-sweep kernels: rays still descending.  One GPU: the device
-// counter flags[0].  Sharded job: the all-reduced flag of the previous step
-// (ggate, a double that is > 0 while any rank still has open rays), because the
-// per-layer maximum line strength needs every rank's lines as long as ANY rank
-// goes on.
-__device__ __forceinline__ bool sweep_active(const int *flags, const double *ggate, int eager)
+// Gate of the line-sweep kernels: rays still descending (the device counter flags[0],
+// maintained by the optical-depth kernel of the step before).
+__device__ __forceinline__ bool sweep_active(const int *flags, int eager)
 {
-  if (eager) return true;
-  return ggate ? (*ggate > 0.0) : (flags[0] != 0);
+  return eager || flags[0] != 0;
 }
 
 __device__ __forceinline__ long long seg_index(const Segments &G, long long t)
@@ -219,19 +215,16 @@ void k_voigt_bins_wave(const ProfileJob *jobs, float *table, int m_limit)
 }
 
 // ---------------------------------------------------------------------------
-// line sweep, strength part: passes 1 and 2a of computemolext in one scan
+// line sweep, strength part (two-kernel form, profiles wider than the walk's window)
 // ---------------------------------------------------------------------------
-// extinction.c:399-427 (strongest line of the layer) and :429-483 (co-added
-// group strength, Doppler-width index).  One lane per co-added group (anchor
-// line + the following lines of the same isotope inside one fine bin, built on
-// the host); the lane reads its lines once for the whole chunk of layers and
-// evaluates the two exponentials once per line-layer.  Per (layer, group) it
-// emits
+// extinction.c:429-483 (co-added group strength, Doppler-width index).  One lane per LINE
+// (uniform work: two exponentials per line and layer); the lanes that anchor a co-added group
+// (anchor line + the following lines of the same isotope inside one fine bin, built on the
+// host) then add their members' strengths out of LDS.  Per (layer, group) it emits
 //     SG    = sum_members gf*exp(-c*Elow/T)*(1-exp(-c*wn/T)) * SIGCTE*ratio/(m*Z)
 //     idop8 = nearest Doppler-width index, or 0xFF = "use the isotope's sticky one"
-// and per layer the maximum single-line strength (wave max -> one 64-bit
-// atomicMax per block).  The threshold test against ethresh*kmax (:467) needs
-// the finished maximum, so it is applied where SG is consumed (k_accumulate).
+// The threshold test against ethresh*kmax (:467) is applied where SG is consumed
+// (k_accumulate); kmax itself comes from k_layer_max (trx_walk.hip.h).
 // The nearest Doppler-width index of pu/src/iomisc.c:1088-1108 (nearest_index in
 // trx_numerics.h) is a monotone step function of the width; trx_create finds its
 // steps exactly (thr[k] = smallest double whose index is >= k, thr[0] = -inf,
@@ -267,27 +260,21 @@ __device__ __forceinline__ double exp_neg(double x, const double *e2tab)
 
 constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are staged in LDS
 
-// One lane per LINE (uniform work: two exponentials per line and layer); the
-// lanes that anchor a co-added group then add their members' strengths out of
-// LDS.  G walks line ranges (contiguous per isotope block).
+// G walks line ranges (contiguous per isotope block).
 __global__ __launch_bounds__(256)
 void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
                    const double *__restrict__ dthr, int ndop,   // steps of the Doppler index, [ndop + 1]
                    const double *__restrict__ e2tab,            // 2^(j/64), j = 0..63
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                    double *__restrict__ SG, uint8_t *__restrict__ idop8,
-                   unsigned long long *__restrict__ kmaxc_bits,   // [chunk slot][nmx] bits of the running maxima
-                   int nmx, const int32_t *__restrict__ iso_mx,   // output slots (per-molecule sweeps), else 1/null
-                   const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
+                   const int *__restrict__ flags, int eager)
 {
-  if (!sweep_active(flags, ggate, eager)) return;
+  if (!sweep_active(flags, eager)) return;
   __shared__ double s_thr[kMaxDop + 1];
   __shared__ double s_e2[64];
-  __shared__ double red[4][kMaxChunk];
   __shared__ double s_ct[kMaxChunk];
   __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
   __shared__ double s_s[2][256];                         // line strengths of the layer in flight
-  __shared__ double s_k[2][256];                         // per-line candidates for the layer maximum
   for (int i = threadIdx.x; i <= ndop; i += 256) s_thr[i] = dthr[i];
   if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
   if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
@@ -298,15 +285,11 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   }
   const long long t0 = (long long)blockIdx.x * 256;
   const long long ln = seg_index(G, t0 + threadIdx.x);
-  // lanes of one block that belong to the same segment are consecutive lines: lane
-  // tid+m holds line ln+m iff it maps to the same segment (checked below)
-  const long long ln_next_block = seg_index(G, t0 + 256);     // first line after this block (or -1)
   const bool ok = ln >= 0;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int g = -1, cnt = 0, iso = 0;
-  double wavn = 0, elow = 0, gf = 0; bool inr = false;
+  double wavn = 0, elow = 0, gf = 0;
   if (ok) {
-    wavn = L.wavn[ln]; elow = L.elow[ln]; gf = L.gf[ln]; inr = L.inrange[ln] != 0;
+    wavn = L.wavn[ln]; elow = L.elow[ln]; gf = L.gf[ln];
     iso = L.iso[ln]; g = L.lgroup[ln];
     if (g >= 0) cnt = L.gcount[g];
   }
@@ -315,7 +298,6 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   // and its members always share a segment (segments are cut at group boundaries)
   int in_lds = cnt;
   if (g >= 0 && (int)threadIdx.x + cnt > 256) in_lds = 256 - (int)threadIdx.x;
-  (void)ln_next_block;
   const bool all_staged = niso <= kSweepIsoLds;             // kernel-uniform: plain LDS reads below
   const bool staged = iso < kSweepIsoLds;
   int lo = 0;                                               // Doppler index carried across layers
@@ -324,29 +306,14 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
     const int r = r_top - c;
     const double ct = s_ct[c];
     const int ri = r * niso + iso;
-    double f;
-    if (all_staged) f = s_f[c][iso];
-    else f = staged ? s_f[c][iso] : (ok ? Y.strength_f[ri] : 0.0);
     double s = 0;
     if (ok) s = gf * exp_neg(ct * elow, s_e2) * (1 - exp_neg(ct * wavn, s_e2));
     s_s[c & 1][threadIdx.x] = s;
-    double kbest = inr ? s * f : 0.0;
-    if (nmx == 1) {
-      s_k[c & 1][threadIdx.x] = kbest;                   // reduced by wave 0 after the barrier
-    } else if (kbest > 0) {
-      // per-molecule maxima (extinction.c:406-407, permol): a wave can straddle two
-      // molecules, so each qualifying lane updates its own slot (offline build path)
-      const unsigned long long kb = (unsigned long long)__double_as_longlong(kbest);
-      unsigned long long *slot = &kmaxc_bits[c * nmx + iso_mx[iso]];
-      if (kb > *slot) atomicMax(slot, kb);
-    }
-    __syncthreads();
-    if (nmx == 1 && wv == 0) {
-      const double *k = s_k[c & 1];
-      const double m = wave_max(fmax(fmax(k[lane], k[lane + 64]), fmax(k[lane + 128], k[lane + 192])));
-      if (lane == 0) red[0][c] = m;
-    }
+    __syncthreads();                                        // (two buffers: one barrier per layer)
     if (g >= 0) {
+      double f;
+      if (all_staged) f = s_f[c][iso];
+      else f = staged ? s_f[c][iso] : Y.strength_f[ri];
       double pk = s;
       for (int m = 1; m < in_lds; m++) pk += s_s[c & 1][threadIdx.x + m];
       for (int m = in_lds; m < cnt; m++) {                  // members beyond the block: recompute
@@ -366,12 +333,6 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
       idop8[(long long)c * L.ngroups + g] = id;
     }
   }
-  __syncthreads();
-  if (nmx == 1 && threadIdx.x < nc) {
-    const int c = threadIdx.x;
-    const double m = red[0][c];
-    if (m > 0) atomicMax(&kmaxc_bits[c], (unsigned long long)__double_as_longlong(m));
-  }
 }
 
 // Sticky Doppler index of every (layer, isotope): extinction.c:393 and :480-483.
@@ -384,14 +345,14 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
 // their strengths exactly as pass 1/2a do.
 __global__ __launch_bounds__(64)
 void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
-                    const double *__restrict__ kmaxc, int nmx, const int32_t *__restrict__ iso_mx, double ethresh,
+                    const double *__restrict__ kmax /* [layer][nmx] */, int nmx, const int32_t *__restrict__ iso_mx, double ethresh,
                     const double *__restrict__ adop, int ndop,
                     const double *__restrict__ e2tab,    // 2^(j/64): the same exp as the sweep => the same decisions
                     const int *__restrict__ npre,        // [layer][iso] refreshing groups
                     int *__restrict__ sticky_idop,       // [layer][iso]
-                    const int *__restrict__ flags, const double *__restrict__ ggate, int eager)
+                    const int *__restrict__ flags, int eager)
 {
-  if (!sweep_active(flags, ggate, eager)) return;
+  if (!sweep_active(flags, eager)) return;
   __shared__ double s_e2[64];
   s_e2[threadIdx.x] = e2tab[threadIdx.x];
   __builtin_amdgcn_wave_barrier();
@@ -399,7 +360,7 @@ void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
   if (c >= nc) return;
   const int r = r_top - c, ri = r * niso + b, lane = threadIdx.x;
   const int gb0 = L.gblock[b];
-  const double ct = Y.negc_over_t[r], lim = ethresh * kmaxc[nmx == 1 ? c : c * nmx + iso_mx[b]], f = Y.strength_f[ri];
+  const double ct = Y.negc_over_t[r], lim = ethresh * kmax[(long long)r * nmx + (nmx == 1 ? 0 : iso_mx[b])], f = Y.strength_f[ri];
   int found = -1;
   for (int base = npre[ri] - 1; base >= 0 && found < 0; base -= 64) {
     const int k = base - lane;
@@ -460,7 +421,7 @@ struct AccumArgs {
   int r_top, nc, ntiles;
   const double  *SG;                // [chunk][ngroups] group strength before threshold and density
   const uint8_t *idop8;             // [chunk][ngroups]
-  const double  *kmaxc;             // [chunk slot][nmx] strongest single line (after the all-reduce, if any)
+  const double  *kmaxc;             // [layer][nmx] strongest single line (k_layer_max)
   double ethresh;
   int nmx; const int32_t *iso_mx;   // per-molecule sweeps: output slot of every isotope (else 1 / null)
   int permol;                       // 1: no density factor, one output row per slot (extinction.c:472, 507)
@@ -522,7 +483,7 @@ void k_accumulate(AccumArgs A)
     if (gb0 == gb1) continue;
     const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
     if (mx != cur_mx) { if (cur_mx >= 0) flush(cur_mx); cur_mx = mx; }
-    const double lim = A.ethresh * A.kmaxc[c * A.nmx + mx];
+    const double lim = A.ethresh * A.kmaxc[(long long)r * A.nmx + mx];
     const int ri = r * A.niso + b;
     const int il = A.Y.ilor[ri];
     // profile column of this (layer, isotope): size and offset per Doppler index
@@ -710,7 +671,7 @@ void k_accumulate_wide(WideArgs W)
     if (gb0 == gb1) continue;
     const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
     if (mx != cur_mx) { if (cur_mx >= 0) flush(cur_mx); cur_mx = mx; }
-    const double lim = A.ethresh * A.kmaxc[c * A.nmx + mx];
+    const double lim = A.ethresh * A.kmaxc[(long long)r * A.nmx + mx];
     const int ri = r * A.niso + b;
     const int il = A.Y.ilor[ri];
     __builtin_amdgcn_wave_barrier();
@@ -972,9 +933,6 @@ struct TauArgs {
   // Simpson sums of both parities carried from chunk to chunk
   const double *pw;                  // [nr][4]
   double *acc;                       // [2][nsh]
-  // staging of the NEXT step's all-reduce: [kMaxChunk] maxima (zeroed here) + 1 flag
-  double *next_ar;
-  int flag_only;                     // 1: write only the rays-open flag of next_ar (its maxima are being written)
 };
 
 // (out of line: a dozen inlined pow() bodies per call site would push the optical-depth
@@ -1009,13 +967,6 @@ __device__ __noinline__ double cloud_term(const TauArgs &T, int r, double wn)
   return 0.0;
 }
 
-// every ray of this shard has stopped: keep the next step's all-reduce staging
-// clean (maxima 0, "rays open" flag 0)
-__device__ __forceinline__ void tau_idle(const TauArgs &T)
-{
-  if (blockIdx.x == 0 && threadIdx.x <= kMaxChunk && (!T.flag_only || threadIdx.x == kMaxChunk)) T.next_ar[threadIdx.x] = 0.0;
-}
-
 // End of an optical-depth launch: every block adds its number of rays that are still
 // descending and its deepest stopping height ONCE (blocks loop over tiles, so the
 // same-address atomics stay in the low thousands at any grid size); the last block to
@@ -1042,8 +993,6 @@ __device__ __forceinline__ void tau_publish(const TauArgs &T, int nstill, int de
       const int act = atomicAdd(&T.flags[1], 0);
       T.flags[2] += T.nc;                                // layers swept so far
       T.flags[1] = 0; T.flags[3] = 0;
-      if (!T.flag_only) for (int k = 0; k < kMaxChunk; k++) T.next_ar[k] = 0.0;
-      T.next_ar[kMaxChunk] = act > 0 ? 1.0 : 0.0;
       __threadfence();
       atomicExch(&T.flags[0], act);
     }
@@ -1066,7 +1015,7 @@ constexpr int kTauW = 256 / kTauH;        // wavenumbers per block
 __global__ __launch_bounds__(256)
 void k_optical_depth(TauArgs T)
 {
-  if (!T.eager && T.flags[0] == 0) { tau_idle(T); return; }
+  if (!T.eager && T.flags[0] == 0) return;
   __shared__ double s_y0[kTauH][kTauW];
   __shared__ double s_tv[kTauH][kTauW];
   __shared__ int s_alive[kTauW];
@@ -1176,7 +1125,7 @@ template <bool STAGED, bool EXTRAS>      // EXTRAS: a scattering or cloud model 
 __global__ __launch_bounds__(256)
 void k_optical_depth_vertical(TauArgs T)
 {
-  if (!T.eager && T.flags[0] == 0) { tau_idle(T); return; }
+  if (!T.eager && T.flags[0] == 0) return;
   __shared__ double s_out[STAGED ? 2 * kMaxChunk * 64 : 1];
   const int nr = T.nr;
   int nstill = 0, deep = 0;

@@ -1,0 +1,462 @@
+// trx_walk.hip.h -- the line sweep of the narrow-profile regime as ONE kernel, and the exact
+// per-layer maximum line strength from a pruned candidate set.
+//
+//   k_cand_cellmax / _prefix / _select   create time: lines that can never be a layer's
+//                                        strongest line are pruned (dominance on a grid)
+//   k_layer_max                          strongest single line of every layer (extinction.c:399-427)
+//   k_wave_plan                          bin interval and partial-sum slot of every line range
+//   k_line_walk<NB>                      passes 2a + 2b of computemolext (extinction.c:429-511)
+//                                        for up to 64 layers at once: LANES ARE LAYERS
+//   k_walk_combine                       adds the line ranges' partial sums into e[layer][wn]
+//
+// Why lanes = layers.  At 1 cm-1 output resolution a line reaches 0-2 coarse bins per layer, so
+// the sweep is per-(line, layer) arithmetic: two exponentials, a threshold, a table look-up.
+// With one lane per LAYER a wavefront walks a contiguous range of the (wavenumber-sorted) line
+// list sequentially; the line's data is wave-uniform (scalar loads, one 32-byte record per
+// line), everything that depends on the layer (-c/T, partition function, widths, profile
+// column, threshold) is loaded once per wave and stays in registers, every lane owns its
+// layer's accumulators for the few bins around the walk's current cell, and:
+//   * no cross-lane reduction anywhere (the line sum of a bin is a per-lane running sum, in
+//     line order like the reference's);
+//   * no intermediate strength array (the two-kernel form writes and re-reads 9 + 13 bytes per
+//     group and layer, 82 % of a demo-sized run's traffic);
+//   * exp(-c nu/T) costs a 5-term polynomial: consecutive lines are < 1e-3 apart in c nu/T, so
+//     it is rebased on a value computed once per ~100 lines.
+// The price: the layer maximum (needed by the threshold test BEFORE a line is accumulated) must
+// be known up front -- k_layer_max, exact, from the few thousand lines that survive the
+// dominance filter -- and bins near the ends of a line range get contributions from two
+// neighbouring ranges: every wave writes its bins as partial records and k_walk_combine adds
+// them in a fixed order (isotope, then range, i.e. line order), so results are bitwise
+// reproducible and independent of the step size and of the wavenumber shard.
+#pragma once
+#include "trx_kernels.hip.h"
+
+namespace trx {
+
+// ---------------------------------------------------------------------------
+// candidate lines for the layer maximum
+// ---------------------------------------------------------------------------
+// Strength of a line in a layer (pass 1): K = gf * exp(-c Elow/T) * (1 - exp(-c nu/T)) * F_iso(T).
+// For lines A, B of the SAME isotope with gf_A >= gf_B (1 + eps), Elow_A <= Elow_B and
+// nu_A >= nu_B the exact K_A exceeds K_B by the factor (1 + eps) at EVERY temperature, and so
+// does the computed one as long as eps (1e-9) is far above the relative error of the evaluation
+// (~1e-15, and ~4e-16/(c nu/T) for the 1-exp factor: the host checks c nu_min/T_max >= 1e-5
+// per run and falls back to all lines otherwise).  B can then never be a layer's strongest
+// line.  Dominators are looked for on a G x G grid over (Elow, nu): M = largest gf per cell,
+// D[a][b] = max of M over cells with strictly smaller Elow index and strictly larger nu index.
+// Survivors: gf (1 + eps) > D[cell].  For random lists about 2/G of the lines survive.
+constexpr int    kCandGrid = 128;
+constexpr double kCandEps  = 1e-9;
+
+struct CandGeom { double e_min, e_scale, w_min, w_scale; };   // cell = clamp((x - min) * scale)
+
+__device__ __forceinline__ int cand_cell(double x, double x0, double scale)
+{
+  const double c = (x - x0) * scale;
+  int k = (c > 0) ? (int)fmin(c, (double)(kCandGrid - 1)) : 0;
+  return k;
+}
+
+__global__ __launch_bounds__(256)
+void k_cand_cellmax(long long n, const double *__restrict__ wavn, const double *__restrict__ elow,
+                    const double *__restrict__ gf, const int16_t *__restrict__ iso, const uint8_t *__restrict__ inr,
+                    CandGeom Gm, unsigned long long *__restrict__ M /* [niso][G][G] */)
+{
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !inr[i]) return;
+  const double g = gf[i];
+  if (!(g > 0)) return;
+  const int a = cand_cell(elow[i], Gm.e_min, Gm.e_scale), b = cand_cell(wavn[i], Gm.w_min, Gm.w_scale);
+  unsigned long long *slot = &M[((long long)iso[i] * kCandGrid + a) * kCandGrid + b];
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(g);
+  if (bits > *slot) atomicMax(slot, bits);
+}
+
+// one block per isotope: D[a][b] = max M[a' < a][b' > b]  (in place: M becomes D)
+__global__ __launch_bounds__(kCandGrid)
+void k_cand_prefix(unsigned long long *__restrict__ M)
+{
+  __shared__ unsigned long long s[kCandGrid][kCandGrid + 1];
+  unsigned long long *Mi = M + (long long)blockIdx.x * kCandGrid * kCandGrid;
+  const int t = threadIdx.x;
+  for (int a = 0; a < kCandGrid; a++) s[a][t] = Mi[a * kCandGrid + t];
+  __syncthreads();
+  // inclusive running maximum along a (thread = column b)
+  for (int a = 1; a < kCandGrid; a++) s[a][t] = max(s[a][t], s[a - 1][t]);
+  __syncthreads();
+  // inclusive running maximum along descending b (thread = row a)
+  for (int b = kCandGrid - 2; b >= 0; b--) s[t][b] = max(s[t][b], s[t][b + 1]);
+  __syncthreads();
+  for (int a = 0; a < kCandGrid; a++)
+    Mi[a * kCandGrid + t] = (a > 0 && t < kCandGrid - 1) ? s[a - 1][t + 1] : 0ull;
+}
+
+__global__ __launch_bounds__(256)
+void k_cand_select(long long n, const double *__restrict__ wavn, const double *__restrict__ elow,
+                   const double *__restrict__ gf, const int16_t *__restrict__ iso, const uint8_t *__restrict__ inr,
+                   CandGeom Gm, const unsigned long long *__restrict__ D,
+                   int32_t *__restrict__ cand, int *__restrict__ ncand, int cap)
+{
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !inr[i]) return;
+  const double g = gf[i];
+  if (!(g > 0)) return;                    // a line without strength is nobody's maximum (K = 0)
+  const int a = cand_cell(elow[i], Gm.e_min, Gm.e_scale), b = cand_cell(wavn[i], Gm.w_min, Gm.w_scale);
+  const double d = __longlong_as_double((long long)D[((long long)iso[i] * kCandGrid + a) * kCandGrid + b]);
+  if (g * (1.0 + kCandEps) > d) {
+    const int k = atomicAdd(ncand, 1);
+    if (k < cap) cand[k] = (int32_t)i;
+  }
+}
+
+// Strongest single line of every layer: grid (candidate blocks, layers).  cand == null: all lines.
+// kmax is [layer][nmx] bit patterns, zeroed by the host.
+__global__ __launch_bounds__(256)
+void k_layer_max(LinesDev L, LayerDev Y, int niso, const int32_t *__restrict__ cand, long long ncand,
+                 const double *__restrict__ e2tab, int nmx, const int32_t *__restrict__ iso_mx,
+                 unsigned long long *__restrict__ kmax_bits)
+{
+  __shared__ double s_e2[64];
+  __shared__ double s_red[4];
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
+  __syncthreads();
+  const int r = blockIdx.y;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  double k = 0.0; int iso = 0;
+  if (t < ncand) {
+    const long long ln = cand ? cand[t] : t;
+    if (L.inrange[ln]) {
+      iso = L.iso[ln];
+      const double ct = Y.negc_over_t[r];
+      const double s = L.gf[ln] * exp_neg(ct * L.elow[ln], s_e2) * (1 - exp_neg(ct * L.wavn[ln], s_e2));
+      k = s * Y.strength_f[r * niso + iso];
+    }
+  }
+  if (nmx == 1) {
+    const double m = wave_max(k);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double mm = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+      if (mm > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(mm));
+    }
+  } else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
+    unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso]];
+    const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
+    if (kb > *slot) atomicMax(slot, kb);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// line ranges ("waves") of the walk
+// ---------------------------------------------------------------------------
+// Range w of isotope block b covers the groups [g0, g1) = kWalkGroups consecutive co-added
+// groups (fewer at the end of the block).  Groups are sorted by descending wavenumber, so a
+// range's groups sit in the cells gidiv[g1-1] .. gidiv[g0] and can reach the bins
+//     blo = gidiv[g1-1] - Rc  ..  bhi = gidiv[g0] + Rc + 1          (clipped to the shard)
+// when every profile of the step is at most Rc whole cells wide on either side.  The range
+// writes one partial record (64 lanes = layers) per bin of that interval, at record index
+// off[w] + (j - blo); off is the running sum of the interval lengths.
+struct WalkPlan {
+  int nwaves, ngw;                  // ranges, groups per range
+  const int32_t *wbase;             // [niso + 1] first range of every isotope block
+  int32_t *blo, *bhi;               // [nwaves] (bhi < blo: the range cannot reach the shard)
+  int64_t *off;                     // [nwaves + 1]
+};
+
+__device__ __forceinline__ int walk_block_of(const int32_t *wbase, int niso, int w)
+{
+  int b = 0;
+  while (b + 1 < niso && w >= wbase[b + 1]) b++;
+  return b;
+}
+
+__global__ __launch_bounds__(256)
+void k_wave_plan(WalkPlan P, int niso, const int32_t *__restrict__ gblock, const int32_t *__restrict__ gidiv,
+                 int Rc, long long lo, long long hi)
+{
+  __shared__ long long s_scan[256];
+  __shared__ long long s_carry;
+  if (threadIdx.x == 0) { s_carry = 0; P.off[0] = 0; }
+  __syncthreads();
+  for (int w0 = 0; w0 < P.nwaves; w0 += 256) {
+    const int w = w0 + threadIdx.x;
+    long long len = 0;
+    if (w < P.nwaves) {
+      const int b = walk_block_of(P.wbase, niso, w);
+      const int g0 = gblock[b] + (w - P.wbase[b]) * P.ngw, g1 = min(g0 + P.ngw, gblock[b + 1]);
+      long long bl = (long long)gidiv[g1 - 1] - Rc, bh = (long long)gidiv[g0] + Rc + 1;
+      if (bl < lo) bl = lo;
+      if (bh > hi - 1) bh = hi - 1;
+      P.blo[w] = (int32_t)bl; P.bhi[w] = (int32_t)bh;
+      len = bh >= bl ? bh - bl + 1 : 0;
+    }
+    s_scan[threadIdx.x] = len;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const long long v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (w < P.nwaves) P.off[w + 1] = s_carry + s_scan[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry += s_scan[255];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the walk
+// ---------------------------------------------------------------------------
+// One 32-byte record per line, read with ONE scalar load per line.
+//   meta bit 0: the line anchors a co-added group (extinction.c:449-462), bit 1: it is the
+//   group's last member; bits 2..: iown % osamp of the group's anchor; cell = iown / osamp.
+struct alignas(32) WalkLine { double wavn, elow, gf; int32_t meta, cell; };
+
+constexpr int kWalkLayers = 64;      // layers per step = lanes
+constexpr double kRebaseMax = 0.00390625;   // 2^-8: polynomial range of the rebased exponential
+
+struct WalkArgs {
+  const WalkLine *lines;
+  const int32_t *gfirst, *gcount, *gblock;
+  WalkPlan P;
+  int niso, nlor, ndop, osamp;
+  long long lo, hi;                 // shard [lo, hi)
+  int r_top, nc;
+  LayerDev Y; const double *wcut;   // [layer][iso]
+  const double *kmax;               // [layer][nmx] strongest single line
+  double ethresh;
+  int nmx; const int32_t *iso_mx; int permol;
+  const int *sticky_idop;           // [layer][iso]
+  const double *dthr;               // [ndop + 1] steps of the nearest-Doppler-index function
+  const double *e2tab;              // [64]
+  const int32_t *psize; const long long *poff; const float *table;
+  double *part;                     // [records][64]
+  unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
+  const int *flags; const int *last; int eager;
+};
+
+// exp(ct*wavn) for consecutive lines of a wavenumber-sorted list: with the base point
+// t0 = fl(ct*w0) kept as c0 = -t0 and E0 = exp(t0), the argument x = fma(ct, wavn, c0) is the
+// EXACT difference ct*wavn - t0 (one rounding), 0 <= x <= 2^-8, and exp(ct*wavn) = E0 * P5(x).
+__device__ __forceinline__ double exp_small(double x)
+{
+  double p = 0x1.1111111111111p-7;                 // 1/120
+  p = __builtin_fma(p, x, 0x1.5555555555555p-5);   // 1/24
+  p = __builtin_fma(p, x, 0x1.5555555555555p-3);   // 1/6
+  p = __builtin_fma(p, x, 0.5);
+  p = __builtin_fma(p, x, 1.0);
+  p = __builtin_fma(p, x, 1.0);
+  return p;
+}
+
+template <int NB, bool PROF>
+__global__ __launch_bounds__(64)
+void k_line_walk(WalkArgs A)
+{
+  constexpr int Rc = NB / 2 - 1;
+  if (!A.eager && A.flags[0] == 0) return;
+  const int w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int blo = A.P.blo[w], bhi = A.P.bhi[w];
+  if (bhi < blo) return;                                  // nothing of this range reaches the shard
+  if (A.last) {   // every ray of the range's bins has stopped (tau.c:277-287): nobody reads them
+    bool open = false;
+    for (int j = blo + lane; j <= bhi; j += 64) open |= A.last[j - A.lo] < 0;
+    if (__ballot(open) == 0ull) return;
+  }
+  __shared__ double s_thr[kMaxDop + 1];
+  __shared__ double s_e2[64];
+  for (int i = lane; i <= A.ndop; i += 64) s_thr[i] = A.dthr[i];
+  s_e2[lane] = A.e2tab[lane];
+  __builtin_amdgcn_wave_barrier();
+
+  const int b = walk_block_of(A.P.wbase, A.niso, w);
+  const int g0 = A.gblock[b] + (w - A.P.wbase[b]) * A.P.ngw, g1 = min(g0 + A.P.ngw, A.gblock[b + 1]);
+  const int l0 = A.gfirst[g0], l1 = A.gfirst[g1 - 1] + A.gcount[g1 - 1];
+  const long long rec0 = A.P.off[w];
+
+  // ---- this lane's layer
+  const bool valid = lane < A.nc;
+  const int r = A.r_top - (valid ? lane : 0), ri = r * A.niso + b;
+  const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
+  const double ct = valid ? A.Y.negc_over_t[r] : 0.0;      // idle lanes: strength 0
+  const double f = A.Y.strength_f[ri], dens = A.permol ? 1.0 : A.Y.density[ri];
+  const double lim = A.ethresh * A.kmax[(long long)r * A.nmx + mx];
+  const double wc = A.wcut[ri], ad = A.Y.alphad[ri];
+  const int il = A.Y.ilor[ri];
+  const int idst = A.sticky_idop[ri];
+  const int ps_st = A.psize[idst * A.nlor + il];
+  const unsigned vo_st = (unsigned)(A.poff[idst * A.nlor + il] + ps_st);     // table index of the profile centre
+  // widest profile any lane of this step can use for this isotope: wave-uniform bound for the bin loop
+  const int psm_s = wave_max_i(valid ? A.Y.psmax[ri] : 0);
+
+  // Doppler index of the first anchor, then followed downwards (wavenumbers descend => it never rises)
+  int lo_i = index_from(s_thr, ad * A.lines[l0].wavn, A.Y.idop0[ri]);
+  double thr_lo = s_thr[lo_i];
+  int ps_cur = A.psize[lo_i * A.nlor + il];
+  unsigned vo_cur = (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);
+
+  double acc[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) acc[k] = 0.0;
+  int jc = A.lines[l0].cell;                               // frame: acc[k] <-> bin jc - Rc + k
+  unsigned long long nb = 0, nev = 0, nsk = 0;
+
+  auto flush = [&](int k, double v) {                      // bin of slot k leaves the frame
+    const int j = jc - Rc + k;
+    if (j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = v;
+  };
+
+  double c0 = 0.0, E0 = 1.0;
+  bool based = false;
+  double pk = 0.0, wav_a = 0.0;
+  int cell = jc, imod = 0;
+
+  for (int ln = l0; ln < l1; ln++) {
+    const WalkLine Ln = A.lines[ln];                       // wave-uniform: one scalar load
+    // ---- strength of the line in every layer
+    const double e1 = exp_neg(ct * Ln.elow, s_e2);
+    double x = __builtin_fma(ct, Ln.wavn, c0);
+    // (a lane rebases on ITS OWN argument only, so that its sums do not depend on which other
+    // layers share the step)
+    const bool reb = !based || x > kRebaseMax;
+    if (__any(reb)) {
+      if (reb) {
+        const double t0 = ct * Ln.wavn;
+        E0 = exp_neg(t0, s_e2); c0 = -t0; x = 0.0;
+      }
+      based = true;
+    }
+    const double q = __builtin_fma(-E0, exp_small(x), 1.0);
+    const double s = Ln.gf * e1 * q;
+    if (Ln.meta & 1) { pk = s; wav_a = Ln.wavn; cell = Ln.cell; imod = Ln.meta >> 2; }
+    else pk += s;
+    if (!(Ln.meta & 2)) continue;
+    // ---- the group is complete: threshold, density, profile, bins (extinction.c:464-509)
+    const double pkf = pk * f;
+    const bool below = pkf < lim;                          // :467
+    if (PROF && cell >= A.lo && cell < A.hi && valid) { if (below) nsk++; else nev++; }
+    const double kk = pkf * dens;                          // :472-473
+    // nearest Doppler-width index: own one while alphad*wn/alphal >= 0.1, else the sticky one (:480-483)
+    const double v = ad * wav_a;
+    while (__any(v < thr_lo)) {
+      if (v < thr_lo) {
+        lo_i--; thr_lo = s_thr[lo_i];
+        ps_cur = A.psize[lo_i * A.nlor + il];
+        vo_cur = (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);
+      }
+    }
+    const bool own = wav_a >= wc;
+    const int ps = own ? ps_cur : ps_st;
+    const unsigned vo = own ? vo_cur : vo_st;
+    const bool act = valid && !below;
+    // ---- move the frame down to the group's cell
+    if (cell != jc) {
+      int sh = jc - cell;
+      if (sh >= NB) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) { flush(k, acc[k]); acc[k] = 0.0; }
+        jc = cell;
+      } else {
+        for (; sh > 0; sh--) {
+          flush(NB - 1, acc[NB - 1]);
+#pragma unroll
+          for (int k = NB - 1; k > 0; k--) acc[k] = acc[k - 1];
+          acc[0] = 0.0;
+          jc--;
+        }
+      }
+    }
+    // ---- bins: slot k is bin jc - Rc + k at fine distance d = (k - Rc)*osamp - imod from the line
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      const int d = (k - Rc) * A.osamp - imod;              // wave-uniform
+      const int ad_ = d < 0 ? -d : d;
+      const int j = jc - Rc + k;
+      if (ad_ <= psm_s && j >= A.lo && j < A.hi) {          // wave-uniform: some layer may reach this bin
+        if (act && ad_ <= ps) {
+          const float pv = A.table[(long long)vo + d];
+          acc[k] += kk * (double)pv;                       // :507 (two roundings, as compiled there)
+          if (PROF) nb++;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++) flush(k, acc[k]);
+  if (PROF && valid && A.counters) {
+    if (nb)  atomicAdd(&A.counters[(long long)r * 3 + 0], nb);
+    if (nev) atomicAdd(&A.counters[(long long)r * 3 + 1], nev);
+    if (nsk) atomicAdd(&A.counters[(long long)r * 3 + 2], nsk);
+  }
+}
+
+// e[layer][j] = sum of the partial records of bin j, isotope blocks in order, ranges in order.
+// One wavefront (lanes = layers) per 8 consecutive bins; lanes then hold 8 consecutive doubles
+// of their layer's row and store them as one 64-byte segment.
+struct CombineArgs {
+  WalkPlan P; int niso; const int32_t *gblock;
+  long long lo, nsh; int r_top, nc;
+  int nmx; const int32_t *iso_mx;
+  const double *part; double *e;
+  const int *flags; const int *last; int eager;
+};
+
+constexpr int kCombineBins = 8;
+
+__global__ __launch_bounds__(64)
+void k_walk_combine(CombineArgs C)
+{
+  if (!C.eager && C.flags[0] == 0) return;
+  const int lane = threadIdx.x;
+  const long long j0 = C.lo + (long long)blockIdx.x * kCombineBins;
+  const int nbins = (int)min((long long)kCombineBins, C.lo + C.nsh - j0);
+  if (C.last) {
+    const bool open = lane < nbins && C.last[j0 - C.lo + lane] < 0;
+    if (__ballot(open) == 0ull) return;
+  }
+  const bool valid = lane < C.nc;
+  const int r = C.r_top - (valid ? lane : 0);
+  double sum[kCombineBins];
+  int cur_mx = -1;
+  auto store = [&](int mx) {
+    if (!valid) return;
+    double *dst = C.e + ((long long)r * C.nmx + mx) * C.nsh + (j0 - C.lo);
+#pragma unroll
+    for (int t = 0; t < kCombineBins; t++) if (t < nbins) dst[t] = sum[t];
+  };
+  for (int b = 0; b < C.niso; b++) {
+    if (C.gblock[b] == C.gblock[b + 1]) continue;
+    const int mx = C.nmx == 1 ? 0 : C.iso_mx[b];
+    if (mx != cur_mx) {
+      if (cur_mx >= 0) store(cur_mx);
+      cur_mx = mx;
+#pragma unroll
+      for (int t = 0; t < kCombineBins; t++) sum[t] = 0.0;
+    }
+    const int w0 = C.P.wbase[b], w1 = C.P.wbase[b + 1];
+    const long long jl = j0, jh = j0 + nbins - 1;
+    // ranges of the block that touch [jl, jh]: bhi and blo descend with w
+    int a = w0, z = w1;                      // first w with blo[w] <= jh
+    while (a < z) { const int m = (a + z) >> 1; if (C.P.blo[m] <= jh) z = m; else a = m + 1; }
+    const int wa = a;
+    a = wa; z = w1;                          // first w >= wa with bhi[w] < jl
+    while (a < z) { const int m = (a + z) >> 1; if (C.P.bhi[m] < jl) z = m; else a = m + 1; }
+    const int wz = a;
+    for (int w = wa; w < wz; w++) {
+      const int bl = C.P.blo[w], bh = C.P.bhi[w];
+      if (bh < bl) continue;
+      const long long rec = C.P.off[w];
+#pragma unroll
+      for (int t = 0; t < kCombineBins; t++) {
+        const long long j = j0 + t;
+        if (t < nbins && j >= bl && j <= bh) sum[t] += C.part[(rec + (j - bl)) * kWalkLayers + lane];
+      }
+    }
+  }
+  if (cur_mx >= 0) store(cur_mx);
+}
+
+}  // namespace trx

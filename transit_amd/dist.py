@@ -1,13 +1,13 @@
 """Multi-GPU jobs: one process per GPU, the wavenumber axis split across ranks
-(SURVEY.md section 8e).  The data path has exactly two exchanges:
+(SURVEY.md section 8e).  The data path has exactly ONE exchange: the gather of the
+per-rank spectrum slices at the end -- `Engine.gather` (trx_gather: ncclAllGather on
+the handle's stream, communicator from `create_comm`) or, for CPU tests and ranks that
+share a device, `gather_spectrum` over torch.distributed.  The per-layer maximum line
+strength, the only global quantity of the path (reference extinction.c:399-427), needs
+no exchange: every rank computes it from the same small set of candidate lines.
 
-  * inside the engine, one tiny in-stream RCCL all-reduce(max) per sweep step
-    for the per-layer maximum line strength (a global quantity, reference
-    extinction.c:399-427) -- communicator from `create_comm`;
-  * at the end, one gather of the per-rank spectrum slices (`gather_spectrum`).
-
-torch.distributed is plumbing here: rendezvous, the 128-byte id broadcast and
-the final gather (backend "nccl" is RCCL on ROCm; "gloo" works for CPU tests).
+torch.distributed is plumbing here: rendezvous and the 128-byte id broadcast (backend
+"nccl" is RCCL on ROCm; "gloo" works for CPU tests).
 """
 from __future__ import annotations
 
@@ -64,17 +64,6 @@ def _torch_broadcast(device: int):
         dist.broadcast(t, src=0)
         return bytes(t.cpu().tolist())
     return bc
-
-
-def torch_allreduce_max():
-    """Host transport for Engine.set_host_allreduce on top of torch.distributed (any backend
-    that reduces CPU tensors, e.g. gloo): for jobs without RCCL and for tests."""
-    def fn(values: np.ndarray):
-        import torch
-        import torch.distributed as dist
-        t = torch.from_numpy(values)          # shares memory with the engine's buffer
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return fn
 
 
 def padded_len(nwn: int, world: int) -> int:

@@ -162,34 +162,23 @@ class Engine(CEngine):
     def __init__(self, static: _abi.TrxStatic):
         super().__init__(hip_library(), "trx_", static)
 
-    def set_host_allreduce(self, fn):
-        """Sharded job over a host transport (trx_set_host_allreduce): fn(values: np.ndarray) must
-        overwrite `values` with their element-wise maximum over all ranks (collective, blocking).
-        None switches it off."""
-        self._lib.trx_set_host_allreduce.argtypes = [C.c_void_p, AR_FN, C.c_void_p]
-        self._lib.trx_set_host_allreduce.restype = C.c_int
-        if fn is None:
-            self._ar_keep = AR_FN(0)
-        else:
-            def cb(ptr, n, _user):
-                try:
-                    fn(np.ctypeslib.as_array(ptr, shape=(n,)))
-                    return 0
-                except Exception:            # never let an exception cross the C boundary
-                    return 1
-            self._ar_keep = AR_FN(cb)
-        rc = self._lib.trx_set_host_allreduce(self._h, self._ar_keep, None)
-        if rc != 0:
-            raise EngineError(rc, "trx_set_host_allreduce", self._last_error())
-
     def run_device(self, atm, opts, d_spectrum_ptr: int):
         rc = self._lib.trx_run_device(self._h, C.byref(atm), C.byref(opts), C.c_void_p(d_spectrum_ptr), None)
         if rc != 0:
             raise EngineError(rc, "trx_run_device", self._last_error())
 
+    def gather(self, d_slice_ptr: int, d_all_ptr: int, count: int):
+        """trx_gather: the one exchange of a sharded job -- every rank's `count` doubles (device
+        memory) into d_all in rank order, ncclAllGather over the handle's communicator (a device
+        copy without one)."""
+        self._lib.trx_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        self._lib.trx_gather.restype = C.c_int
+        rc = self._lib.trx_gather(self._h, C.c_void_p(d_slice_ptr), C.c_void_p(d_all_ptr), int(count))
+        if rc != 0:
+            raise EngineError(rc, "trx_gather", self._last_error())
+
 
 LOG_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
-AR_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 _log_keep = None
 
 
