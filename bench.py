@@ -279,7 +279,7 @@ def main():
                                        "eclipse, 5 angles" if args.solution == "eclipse" else "transit (slant paths)",
                                        " + H2-He" if args.ncia > 1 else ""),
                        "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
-                       "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "sum_bins": stats["sum_bins"],
+                       "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "n_kmax_candidates": stats["ncandidates"], "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
                        "parallelism": "wn-shard x%d" % world,
                        "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps of <= 32 "

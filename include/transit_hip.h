@@ -207,6 +207,8 @@ typedef struct {
   double  ms_cia;         /* host wall time of queueing the CIA kernels          */
   double  ms_host_total;  /* host wall time of the whole trx_run call           */
   double  ms_spectrum;    /* intensity/flux or modulation                      */
+  int64_t ncandidates;    /* lines that can be a layer's strongest line (the others are
+                             dominated, trx_walk.hip.h); -1: every line is looked at */
 } trx_stats;
 
 typedef struct trx_handle trx_handle;

@@ -39,6 +39,12 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
+// view into another allocation (same accessors as DevBuf, owns nothing)
+struct DevView {
+  void *p = nullptr;
+  template <class T> T *as() const { return (T *)p; }
+};
+
 }  // namespace
 
 struct trx_handle {
@@ -47,7 +53,7 @@ struct trx_handle {
   // stream4: the line sweep of step c+1 runs while `stream` integrates the optical depth of
   // step c; ev_ac[c] = extinction of step c complete
   hipStream_t stream4 = nullptr;
-  std::vector<hipEvent_t> ev_ac;
+  std::vector<hipEvent_t> ev_ac, ev_cb;      // ev_cb[c] = partial records of step c consumed
   hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr;
   std::string err;
 
@@ -78,18 +84,26 @@ struct trx_handle {
   DevBuf d_cand; int64_t ncand = -1;
   DevBuf d_kmax;                                            // [layer][nmx] strongest single line of the run
   // the walk (k_line_walk): one record per line, line ranges of ngw groups, plans per profile reach
-  DevBuf d_walk, d_wbase, d_part;
+  DevBuf d_walk, d_wbase, d_part[2];   // partial records: consecutive steps alternate
   std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
+  bool walk_temp_ok = true;         // this run's layers are all warmer than kWalkMinTemp
   struct Plan { bool built = false; DevBuf blo, bhi, off; int64_t records = 0; };
   Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw; };
   std::vector<Cia> cia;
-  DevBuf d_cia_ws, d_cia_dens; std::vector<double> h_cia_dens;
+  DevBuf d_cia_ws;
   // per-run workspaces (grown on demand)
   int ws_nr = 0, ws_chunk = 0;
-  DevBuf d_layer_f64, d_layer_i32, d_SG, d_idop8, d_sticky, d_counters, d_flags, d_part3;
-  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_geom, d_intens, d_spec, d_status, d_ip, d_acc;
+  DevBuf d_SG, d_idop8, d_sticky, d_part3;
+  // per-run inputs: packed into ONE pinned host block and copied with ONE transfer
+  // (layer scalars, ray geometry, impact parameters, CIA density products)
+  DevBuf d_in; void *h_in = nullptr; size_t h_in_bytes = 0;
+  DevBuf d_pm_f64, d_pm_i32;         // the same scalars of a per-molecule sweep (trx_sweep_permol)
+  // what the host reads back after a run, in ONE device block and one pinned host block:
+  // flags (8 ints, byte 0), status (4 ints, byte 64), counters (3 per layer, byte 128)
+  DevBuf d_small; DevView d_flags, d_status, d_counters; void *h_small = nullptr; size_t h_small_bytes = 0;
+  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_intens, d_spec, d_acc;
   // opacity grid (optional)
   bool has_grid = false; long og_nmol = 0, og_ntemp = 0, og_nlayer = 0, og_nwave = 0;
   std::vector<double> og_temp; std::vector<int32_t> og_molidx; DevBuf d_og_o, d_og_layer, d_og_itemp, d_iso_mx, d_pm, d_kmaxpm;
@@ -124,6 +138,23 @@ int ensure(trx_handle *h, DevBuf &b, size_t bytes)
   b.release();
   HIPCHK(h, hipMalloc(&b.p, bytes));
   b.bytes = bytes;
+  return TRX_OK;
+}
+
+// the small read-back block for nlay layers (device + pinned host mirror)
+int ensure_small(trx_handle *h, int nlay)
+{
+  const size_t bytes = 128 + 24 * (size_t)nlay;
+  int rc = ensure(h, h->d_small, bytes);
+  if (rc) return rc;
+  char *base = (char *)h->d_small.p;
+  h->d_flags.p = base; h->d_status.p = base + 64; h->d_counters.p = base + 128;
+  if (h->h_small_bytes < bytes) {
+    if (h->h_small) (void)hipHostFree(h->h_small);
+    h->h_small = nullptr; h->h_small_bytes = 0;
+    HIPCHK(h, hipHostMalloc(&h->h_small, bytes, hipHostMallocDefault));
+    h->h_small_bytes = bytes;
+  }
   return TRX_OK;
 }
 
@@ -379,13 +410,15 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   int rc;
   // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
   // ranges of ngw consecutive groups per isotope block
-  h->walk_ok = s->osamp < (1 << 28) && h->tab_n < ((int64_t)1 << 31) && !gfirst.empty();
+  h->walk_ok = s->osamp < (1 << 27) && h->tab_n < ((int64_t)1 << 30) && !gfirst.empty();
+  std::vector<WalkLine> walk;
   if (h->walk_ok) {
-    std::vector<WalkLine> walk((size_t)n);
+    walk.resize((size_t)n + 1);                    // + one record of padding (the walk reads one line ahead)
     for (int64_t i = 0; i < n; i++) { walk[i].wavn = wavn[i]; walk[i].elow = elow[i]; walk[i].gf = gf[i]; walk[i].meta = 0; walk[i].cell = 0; }
+    walk[(size_t)n] = WalkLine{0.0, 0.0, 0.0, 0, 0};
     for (size_t g = 0; g < gfirst.size(); g++) {
       WalkLine &a = walk[(size_t)gfirst[g]];
-      a.meta |= 1 | (gimod[g] << 2); a.cell = gidiv[g];
+      a.meta |= 1 | (gimod[g] << 3); a.cell = gidiv[g];
       walk[(size_t)gfirst[g] + gcount[g] - 1].meta |= 2;
     }
     int ngw = 32;
@@ -395,6 +428,16 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     h->h_wbase.assign(s->niso + 1, 0);
     for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
     h->nwaves = h->h_wbase[s->niso];
+    // base points of the rebased exponential (meta bit 2): a range's first line, then every
+    // line more than kRebaseSpan below the last base point
+    for (int b = 0; b < s->niso; b++)
+      for (int g0 = gblock[b]; g0 < gblock[b + 1]; g0 += ngw) {
+        const int g1 = std::min(g0 + ngw, gblock[b + 1]);
+        const int64_t l0 = gfirst[g0], l1 = (int64_t)gfirst[g1 - 1] + gcount[g1 - 1];
+        double w0 = HUGE_VAL;
+        for (int64_t l = l0; l < l1; l++)
+          if (l == l0 || w0 - walk[l].wavn > kRebaseSpan) { walk[l].meta |= 4; w0 = walk[l].wavn; }
+      }
     if ((rc = upload(h, h->d_walk, walk)) || (rc = upload(h, h->d_wbase, h->h_wbase))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));    // `walk` dies here
   }
@@ -439,13 +482,29 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     HIPCHK(h, hipGetLastError());
     if (nc > 0 && nc <= cap) h->ncand = nc;
   }
+  h->stats.ncandidates = h->ncand;
   return TRX_OK;
 }
 
 // ---- CIA: crosssec.c:272-344 + 354-428, device kernels ----------------------
 // Host part: range checks and the no-extrapolation index windows only.
+// density product of every CIA table and layer (crosssec.c:318-330), host side
+void cia_densities(const trx_handle *h, const trx_atm *a, double *dens /* [ncia][nr] */)
+{
+  const int nr = a->nlayer;
+  for (size_t n = 0; n < h->cia.size(); n++)
+    for (int j = 0; j < nr; j++) {
+      double d = 1.0;
+      for (int k = 0; k < h->cia[n].nspec; k++) {
+        const int m = h->cia[n].mol[k];
+        d *= a->density[(size_t)m * nr + j] / (kAmu * h->mol_mass[m] * kAmagat);
+      }
+      dens[n * nr + j] = d;
+    }
+}
+
 int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double *d_tlay /* [nr] on device */,
-               hipStream_t cst)
+               const double *d_dens /* [ncia][nr] on device */, hipStream_t cst)
 {
   const int nr = a->nlayer; const long long nsh = h->nsh;
   HIPCHK(h, hipMemsetAsync(h->d_ecs.p, 0, sizeof(double) * (size_t)nr * nsh, cst));
@@ -457,19 +516,6 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     if (a->temp[i] < tmin || a->temp[i] > tmax) return fail(h, TRX_E_RANGE, "layer temperature outside the CIA tables");
   int rc;
   if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 3 * nwmax * (size_t)nr))) return rc;
-  if ((rc = ensure(h, h->d_cia_dens, sizeof(double) * (size_t)nr * h->cia.size()))) return rc;
-  std::vector<double> &dens = h->h_cia_dens;     // member: must outlive the async copy
-  dens.resize((size_t)nr * h->cia.size());
-  for (size_t n = 0; n < h->cia.size(); n++)
-    for (int j = 0; j < nr; j++) {
-      double d = 1.0;
-      for (int k = 0; k < h->cia[n].nspec; k++) {
-        const int m = h->cia[n].mol[k];
-        d *= a->density[(size_t)m * nr + j] / (kAmu * h->mol_mass[m] * kAmagat);
-      }
-      dens[n * nr + j] = d;
-    }
-  HIPCHK(h, hipMemcpyAsync(h->d_cia_dens.p, dens.data(), dens.size() * sizeof(double), hipMemcpyHostToDevice, cst));
   auto wn_at = [&](long long i) { return o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d); };
   for (size_t n = 0; n < h->cia.size(); n++) {
     auto &c = h->cia[n];
@@ -494,7 +540,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, cst, C, nr, fj, lj, mid, z2, v);
     hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li - fi + 255) / 256), (unsigned)(lj - fj)), dim3(256), 0, cst,
                        C, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi, li, fj, mid, z2,
-                       h->d_cia_dens.as<double>() + n * nr, h->d_ecs.as<double>());
+                       d_dens + n * nr, h->d_ecs.as<double>());
   }
   HIPCHK(h, hipGetLastError());
   return TRX_OK;
@@ -628,9 +674,8 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
   return TRX_OK;
 }
 
-void layer_dev(trx_handle *h, const LayerHost &LH, int nr, LayerDev &Y, const double *&d_wcut, const int32_t *&d_npre)
+void layer_dev(const double *df, const int32_t *di, const LayerHost &LH, int nr, LayerDev &Y, const double *&d_wcut, const int32_t *&d_npre)
 {
-  const double *df = h->d_layer_f64.as<double>(); const int32_t *di = h->d_layer_i32.as<int32_t>();
   const size_t nli = LH.nli;
   Y.negc_over_t = df; Y.strength_f = df + nr; Y.density = Y.strength_f + nli; Y.alphad = Y.density + nli;
   Y.alphal = Y.alphad + nli; d_wcut = Y.alphal + nli;
@@ -681,7 +726,7 @@ long long layer_psmax(const trx_handle *h, const int32_t *psmax, int r)
 // it the order of its sums -- does not depend on how the layers are grouped into steps.
 int walk_frame_bins(const trx_handle *h, const int32_t *psmax, int r)
 {
-  if (!h->walk_ok) return 0;
+  if (!h->walk_ok || !h->walk_temp_ok) return 0;
   const long long rc = layer_psmax(h, psmax, r) / h->osamp;
   return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : rc <= 7 ? 16 : 0;
 }
@@ -712,26 +757,33 @@ int walk_plan(trx_handle *h, int nb, hipStream_t st, WalkPlan &P, trx_handle::Pl
 template <int NB>
 void launch_walk(const WalkArgs &A, bool prof, unsigned nwaves, hipStream_t st)
 {
-  if (prof) hipLaunchKernelGGL((k_line_walk<NB, true>), dim3(nwaves), dim3(64), 0, st, A);
-  else      hipLaunchKernelGGL((k_line_walk<NB, false>), dim3(nwaves), dim3(64), 0, st, A);
+  const dim3 grid((nwaves + kWalkWaves - 1) / kWalkWaves), block(64 * kWalkWaves);
+  if (prof) hipLaunchKernelGGL((k_line_walk<NB, true>), grid, block, 0, st, A);
+  else      hipLaunchKernelGGL((k_line_walk<NB, false>), grid, block, 0, st, A);
 }
 
-// The walk: layers r_top .. r_top-nc+1 (nc <= 64) in one kernel + the combine of its partial sums.
-int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, int r_top, int nc, const SweepMode &M, Spans *sp)
+// The walk: layers r_top .. r_top-nc+1 (nc <= 64) in one kernel on M.st, then the combine of its
+// partial sums on st_comb (the stream the optical depth runs on; null: M.st).  Consecutive steps
+// alternate between two record buffers, so that the next step's walk does not wait for this
+// step's combine.
+int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, int r_top, int nc, const SweepMode &M, Spans *sp,
+               int parity, hipStream_t st_comb, hipEvent_t ev_walk, hipEvent_t ev_reuse = nullptr, hipEvent_t ev_done = nullptr)
 {
   hipStream_t st = M.st ? M.st : h->stream;
   if (const char *e = std::getenv("TRX_WALK_NB")) nb = std::max(nb, std::atoi(e));      // (experiments)
   WalkPlan P{}; trx_handle::Plan *pl = nullptr;
   int rc = walk_plan(h, nb, st, P, pl);
   if (rc) return rc;
+  DevBuf &part = h->d_part[parity & 1];
   const size_t pbytes = sizeof(double) * kWalkLayers * (size_t)std::max<int64_t>(pl->records, 1);
-  if (h->d_part.bytes < pbytes) {
-    HIPCHK(h, hipStreamSynchronize(st));                 // an earlier step may still be reading the old buffer
-    if ((rc = ensure(h, h->d_part, pbytes))) return rc;
+  if (part.bytes < pbytes) {
+    HIPCHK(h, hipStreamSynchronize(st));                 // an earlier step may still be using the old buffer
+    if (st_comb) HIPCHK(h, hipStreamSynchronize(st_comb));
+    if ((rc = ensure(h, part, pbytes))) return rc;
   }
+  // this buffer's previous records (two steps ago) must have been combined
+  if (st_comb && ev_reuse) HIPCHK(h, hipStreamWaitEvent(st, ev_reuse, 0));
   if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
-  // bins a range's frame never visits (a jump over empty cells) must read as zero
-  HIPCHK(h, hipMemsetAsync(h->d_part.p, 0, pbytes, st));
   WalkArgs A{};
   A.lines = h->d_walk.as<WalkLine>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
   A.gblock = h->d_gblock.as<int32_t>(); A.P = P;
@@ -740,7 +792,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol; A.sticky_idop = M.d_sticky;
   A.dthr = h->d_dopthr.as<double>(); A.e2tab = h->d_e2tab.as<double>();
   A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>(); A.table = h->tab;
-  A.part = h->d_part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
+  A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
   const unsigned nw = (unsigned)h->nwaves;
   if (nw > 0) {
@@ -749,13 +801,20 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     else if (nb == 8) launch_walk<8>(A, M.prof, nw, st);
     else launch_walk<16>(A, M.prof, nw, st);
   }
-  if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
+  if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
+  hipStream_t sc = st_comb ? st_comb : st;
+  if (st_comb && ev_walk) {
+    HIPCHK(h, hipEventRecord(ev_walk, st));
+    HIPCHK(h, hipStreamWaitEvent(st_comb, ev_walk, 0));
+  }
+  if (sp && sp->begin(Spans::kAccum, sc)) return fail(h, TRX_E_HIP, "event");
   CombineArgs C{};
   C.P = P; C.niso = h->niso; C.gblock = h->d_gblock.as<int32_t>(); C.lo = h->lo; C.nsh = h->nsh; C.r_top = r_top; C.nc = nc;
-  C.nmx = M.nmx; C.iso_mx = M.d_iso_mx; C.part = h->d_part.as<double>(); C.e = M.d_e;
+  C.nmx = M.nmx; C.iso_mx = M.d_iso_mx; C.part = part.as<double>(); C.e = M.d_e;
   C.flags = h->d_flags.as<int>(); C.last = A.last; C.eager = M.eager;
-  hipLaunchKernelGGL(k_walk_combine, dim3((unsigned)((h->nsh + kCombineBins - 1) / kCombineBins)), dim3(64), 0, st, C);
-  if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
+  hipLaunchKernelGGL(k_walk_combine, dim3((unsigned)((h->nsh + kCombineBins - 1) / kCombineBins)), dim3(64 * kCombineBins), 0, sc, C);
+  if (sp && sp->end(sc)) return fail(h, TRX_E_HIP, "event");
+  if (st_comb && ev_done) HIPCHK(h, hipEventRecord(ev_done, sc));
   return TRX_OK;
 }
 
@@ -842,12 +901,12 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
 // Strongest single line and sticky Doppler index of ALL nv layers (states) at once: both depend
 // on the inputs only, not on how far the rays get, so they leave the per-step chain.
 int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_npre, int nv, const double *temp_k,
-                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st)
+                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st, bool zeroed)
 {
   int rc;
   if ((rc = ensure(h, h->d_kmax, sizeof(double) * (size_t)nv * nmx)) || (rc = ensure(h, h->d_sticky, sizeof(int) * (size_t)nv * std::max(h->niso, 1))))
     return rc;
-  HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * (size_t)nv * nmx, st));
+  if (!zeroed) HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * (size_t)nv * nmx, st));
   if (h->ngroups == 0) return TRX_OK;
   // the pruning argument needs c*nu/T well above the rounding of 1 - exp(-c*nu/T) (trx_walk.hip.h)
   bool pruned = h->ncand > 0;
@@ -856,8 +915,8 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
   for (int r0 = 0; r0 < nv; r0 += 32768) {
     const int nr = std::min(32768, nv - r0);
     LayerDev Yr = Y; Yr.negc_over_t += r0; Yr.strength_f += (size_t)r0 * h->niso;
-    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, st, h->L, Yr, h->niso,
-                       pruned ? h->d_cand.as<int32_t>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
+    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines)), (unsigned)((nr + kLayerMaxGroup - 1) / kLayerMaxGroup)), dim3(64), 0, st,
+                       h->L, Yr, h->niso, nr, pruned ? h->d_cand.as<int32_t>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
                        (unsigned long long *)(h->d_kmax.as<double>() + (size_t)r0 * nmx));
   }
   for (int r0 = 0; r0 < nv; r0 += 4096) {               // one wave per (layer, isotope)
@@ -1055,10 +1114,13 @@ void trx_destroy(trx_handle *h)
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream4) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamDestroy(h->stream4); }
   for (auto e : h->ev_ac) (void)hipEventDestroy(e);
+  for (auto e : h->ev_cb) (void)hipEventDestroy(e);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_cia) (void)hipEventDestroy(h->ev_cia);
+  if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->h_in) (void)hipHostFree(h->h_in);
   delete h;
 }
 
@@ -1125,6 +1187,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // ---- layer prologue (extinction.c:364-395) --------------------------------
   LayerHost LH;
   if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
+  h->walk_temp_ok = true;
+  for (int r = 0; r < nr; r++) if (a->temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
   const size_t nli = LH.nli;
   std::vector<double> &f64 = LH.f64;
   const int32_t *psmax = LH.psmax;
@@ -1193,47 +1257,73 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
   const int sg_layers = any_wide ? (user_chunk ? std::min(user_chunk, kMaxChunk) : kMaxChunk) : 1;
   if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * sg_layers)) || (rc = ensure(h, h->d_idop8, gr_b * sg_layers)) ||
-      (rc = ensure(h, h->d_counters, 24 * (size_t)nr)) ||
-      (rc = ensure(h, h->d_flags, 64)) ||
+      (rc = ensure_small(h, nr)) ||
       (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
       (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
       (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
-      (rc = ensure(h, h->d_status, 16)) || (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)))
+      (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)))
     return rc;
   if (pipelined)
     while ((int)h->ev_ac.size() < nr + 1) {
-      hipEvent_t e1;
-      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
-      h->ev_ac.push_back(e1);
+      hipEvent_t e1, e2;
+      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+      h->ev_ac.push_back(e1); h->ev_cb.push_back(e2);
     }
   if (prof && any_wide && (rc = ensure(h, h->d_part3, 24 * (size_t)kMaxChunk * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
     return rc;
-  if ((rc = upload(h, h->d_layer_f64, f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_geom, geom)) ||
-      (rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh)))
-    return rc;
-  if ((rc = upload(h, h->d_ip, ipv))) return rc;
-  HIPCHK(h, hipMemsetAsync(h->d_counters.p, 0, 24 * (size_t)nr, st));
+  if ((rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh))) return rc;
+  // ---- per-run inputs: one pinned block, one transfer ------------------------------------
+  // [layer scalars f64 | ray geometry | impact parameters | CIA density products | layer scalars i32]
+  const size_t n_f64 = f64.size(), n_geom = geom.size(), n_ip = ipv.size(), n_cd = (size_t)nr * h->cia.size(), n_i32 = LH.i32.size();
+  const size_t off_geom = n_f64, off_ip = off_geom + n_geom, off_cd = off_ip + n_ip, off_i32 = off_cd + n_cd;    // in doubles
+  const size_t in_bytes = 8 * off_i32 + 4 * n_i32 + 8;
+  if (h->h_in_bytes < in_bytes) {
+    if (h->h_in) (void)hipHostFree(h->h_in);
+    h->h_in = nullptr; h->h_in_bytes = 0;
+    HIPCHK(h, hipHostMalloc(&h->h_in, in_bytes, hipHostMallocDefault));
+    h->h_in_bytes = in_bytes;
+  }
+  if ((rc = ensure(h, h->d_in, in_bytes))) return rc;
+  {
+    double *hin = (double *)h->h_in;
+    std::memcpy(hin, f64.data(), 8 * n_f64);
+    std::memcpy(hin + off_geom, geom.data(), 8 * n_geom);
+    std::memcpy(hin + off_ip, ipv.data(), 8 * n_ip);
+    cia_densities(h, a, hin + off_cd);
+    std::memcpy(hin + off_i32, LH.i32.data(), 4 * n_i32);
+  }
+  // the whole front end of a run goes to the stream the line sweep runs on (the main stream
+  // joins it at the first optical depth): no cross-stream hop before the first sweep kernel
+  hipStream_t st_sweep = pipelined ? h->stream4 : st;
+  HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep));
   // With lines, every element of e the path reads is written first (the accumulation kernels
   // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
   // in-range line (empty list, all lines outside the band, a CIA-only run) no kernel writes
   // e, but the optical-depth kernels still read it: it must be zero then.
   if (dbg || eager || (h->ngroups == 0 && !h->has_grid))
-    HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st));
+    HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st_sweep));
   if (dbg || eager)
-    HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st));
-  HIPCHK(h, hipMemsetAsync(h->d_last.p, 0xFF, sizeof(int) * nsh, st));
-  HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));
-  HIPCHK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(double) * 2 * nsh, st));
-  { const int f0[8] = {(int)std::min<int64_t>(nsh, 0x7fffffff), 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(h, hipMemcpyAsync(h->d_flags.p, f0, sizeof(f0), hipMemcpyHostToDevice, st)); }
+    HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st_sweep));
+  if ((rc = ensure(h, h->d_kmax, sizeof(double) * (size_t)nr))) return rc;
+  {
+    RunInit R{};
+    R.last = h->d_last.as<int>(); R.nsh = nsh; R.acc = h->d_acc.as<double>();
+    R.counters = h->d_counters.as<unsigned long long>(); R.ncounters = 3 * nr;
+    R.kmax = h->d_kmax.as<double>(); R.nkmax = nr;
+    R.status = h->d_status.as<int>(); R.flags = h->d_flags.as<int>(); R.rays = (int)std::min<int64_t>(nsh, 0x7fffffff);
+    const long long nt = std::max<long long>(nsh, 3LL * nr);
+    hipLaunchKernelGGL(k_run_init, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st_sweep, R);
+  }
 
-  const double *df = h->d_layer_f64.as<double>();
+  const double *df = h->d_in.as<double>();
   LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
-  layer_dev(h, LH, nr, Y, d_wcut, d_npre);
+  layer_dev(df, (const int32_t *)(df + off_i32), LH, nr, Y, d_wcut, d_npre);
   const double *d_press = df + LH.extra_off, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
-  const double *d_gw = h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
+  const double *d_gw = df + off_geom, *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride, *d_pw = d_mh0 + (nr + 1);
+  const double *d_ipv = df + off_ip, *d_ciadens = df + off_cd;
   (void)nli;
 
   // ---- opacity grid: temperature bracket and weights per layer (extinction.c:549-574) ----
@@ -1261,20 +1351,19 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     trx_handle *h; bool armed = true;
     ~Drain() { if (armed) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->stream); } }
   } drain{h};
-  // ---- inputs are on the device: release the other streams -----------------------------
-  HIPCHK(h, hipEventRecord(h->ev_inputs, st));
+  // ---- inputs are on their way: release the other streams --------------------------------
+  HIPCHK(h, hipEventRecord(h->ev_inputs, st_sweep));
   HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
-  if (pipelined) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0));
-  hipStream_t st_sweep = pipelined ? h->stream4 : st;
+  if (pipelined) HIPCHK(h, hipStreamWaitEvent(st, h->ev_inputs, 0));
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
   if (!h->has_grid &&
-      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep))) return rc;
+      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, true))) return rc;
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
   // after that step's kernels, which are what the GPU is waiting for.
   auto queue_cia = [&]() -> int {
     const auto t0 = std::chrono::steady_clock::now();
-    const int rcc = cia_device(h, a, o, d_tempk, h->stream2);
+    const int rcc = cia_device(h, a, o, d_tempk, d_ciadens, h->stream2);
     if (rcc) return rcc;
     if (hipEventRecord(h->ev_cia, h->stream2) != hipSuccess) return fail(h, TRX_E_HIP, "event");
     ms_cia = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1288,8 +1377,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev.a, st));
 
   // ---- top-down sweep in steps of layers (tau.c:235-290) ----
-  int nchunks = 0, r_top = nr - 1;
-  bool stop_at_hint = stop_at_hint_ok;
+  int nchunks = 0, nwalks = 0, r_top = nr - 1;
+  bool stop_at_hint = stop_at_hint_ok, resumed = false;
   int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
   std::vector<unsigned long long> counters(3 * (size_t)nr);
   double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
@@ -1336,16 +1425,22 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
     } else {
       SweepMode M{};
+      bool walked = false;
       M.eager = eager; M.prof = prof; M.ethresh = o->ethresh;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
       M.d_e = h->d_e.as<double>(); M.d_kmax = h->d_kmax.as<double>(); M.d_sticky = h->d_sticky.as<int>();
       M.st = st_sweep;
       if (h->ngroups > 0) {
-        if (nb) rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr);
+        if (nb) {
+          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, pipelined ? st : nullptr, h->ev_ac[nchunks],
+                          nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()]);
+          nwalks++;
+        }
         else    rc = sweep_chunk(h, Y, d_wcut, psmax, r_top, nc, sg_layers, M, prof ? &spans : nullptr);
         if (rc) return rc;
+        walked = nb != 0;
       }
-      if (pipelined) {     // the optical depth of this step follows its extinction
+      if (pipelined && !walked) {     // the optical depth of this step follows its extinction
         HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], h->stream4));
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_ac[nchunks], 0));
       }
@@ -1392,7 +1487,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
 
   // ---- spectrum ---------------------------------------------------------------
-  HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes it a second time)
+  if (resumed) HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes the spectrum a second time)
   if (o->solution == TRX_SOL_ECLIPSE) {
     EmisArgs E{};
     E.nr = nr; E.nang = o->nangles; E.nsh = nsh; E.lo = h->lo; E.wn_i = h->wn_i; E.wn_d = h->wn_d; E.wn_fct = o->wn_fct;
@@ -1410,7 +1505,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     ModArgs M{};
     M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
     M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
-    M.ip = h->d_ip.as<double>(); M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
+    M.ip = d_ipv; M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
     hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
   }
   if (pipelined) {   // nothing of this run may still be in flight on the sweep stream when it returns
@@ -1421,13 +1516,18 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev.b, st));
 
   // ---- results back -----------------------------------------------------------
-  HIPCHK(h, hipMemcpyAsync(flags_host, h->d_flags.p, sizeof(flags_host), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(status_host, h->d_status.p, sizeof(status_host), hipMemcpyDeviceToHost, st));
-  if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(counters.data(), h->d_counters.p, 24 * (size_t)nr, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  {   // one copy into pinned memory: flags, status and (profiled runs) the counters
+    const size_t nb = prof ? 128 + 24 * (size_t)nr : 128;
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
+    if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    std::memcpy(flags_host, h->h_small, sizeof(flags_host));
+    std::memcpy(status_host, (const char *)h->h_small + 64, sizeof(status_host));
+    if (prof) std::memcpy(counters.data(), (const char *)h->h_small + 128, 24 * (size_t)nr);
+    else std::fill(counters.begin(), counters.end(), 0ull);
+  }
   // rays still descending below the expected depth (the atmosphere changed): go on from there
-  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) { stop_at_hint = false; h->hint_layers = 0; continue; }
+  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) { stop_at_hint = false; resumed = true; h->hint_layers = 0; continue; }
   break;
   }
 
@@ -1488,20 +1588,22 @@ int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double
   int rc;
   LayerHost LH;
   if ((rc = prep_layers(h, nv, temp, density, zpart, 0, LH))) return rc;
+  h->walk_temp_ok = true;
+  for (int r = 0; r < nv; r++) if (temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
   const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
   std::vector<int32_t> slots(iso_slot, iso_slot + std::max(niso, 1));
   bool any_wide = false;
   for (int r = 0; r < nv && !any_wide; r++) any_wide = walk_frame_bins(h, LH.psmax, r) == 0;
   const int sg_layers = any_wide ? 12 : 1;
   if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * sg_layers)) || (rc = ensure(h, h->d_idop8, gr_b * sg_layers)) ||
-      (rc = ensure(h, h->d_flags, 64)) || (rc = ensure(h, h->d_counters, 24 * (size_t)nv)) ||
+      (rc = ensure_small(h, nv)) ||
       (rc = ensure(h, h->d_pm, sizeof(double) * (size_t)nv * nslot * nsh)) ||
-      (rc = upload(h, h->d_layer_f64, LH.f64)) || (rc = upload(h, h->d_layer_i32, LH.i32)) || (rc = upload(h, h->d_iso_mx, slots)))
+      (rc = upload(h, h->d_pm_f64, LH.f64)) || (rc = upload(h, h->d_pm_i32, LH.i32)) || (rc = upload(h, h->d_iso_mx, slots)))
     return rc;
   HIPCHK(h, hipMemsetAsync(h->d_pm.p, 0, sizeof(double) * (size_t)nv * nslot * nsh, st));
   LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
-  layer_dev(h, LH, nv, Y, d_wcut, d_npre);
-  if ((rc = layer_maxima_and_sticky(h, Y, d_npre, nv, temp, nslot, h->d_iso_mx.as<int32_t>(), ethresh, st))) return rc;
+  layer_dev(h->d_pm_f64.as<double>(), h->d_pm_i32.as<int32_t>(), LH, nv, Y, d_wcut, d_npre);
+  if ((rc = layer_maxima_and_sticky(h, Y, d_npre, nv, temp, nslot, h->d_iso_mx.as<int32_t>(), ethresh, st, false))) return rc;
   for (int r_top = nv - 1; r_top >= 0 && h->ngroups > 0; ) {
     int nb = walk_frame_bins(h, LH.psmax, r_top);
     int nc = 1;
@@ -1511,7 +1613,7 @@ int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double
     SweepMode M{};
     M.eager = true; M.ethresh = ethresh; M.nmx = nslot; M.d_iso_mx = h->d_iso_mx.as<int32_t>();
     M.permol = true; M.d_e = h->d_pm.as<double>(); M.d_kmax = h->d_kmax.as<double>(); M.d_sticky = h->d_sticky.as<int>();
-    if (nb) rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr);
+    if (nb) rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr, 0, nullptr, nullptr);
     else    rc = sweep_chunk(h, Y, d_wcut, LH.psmax, r_top, nc, sg_layers, M, nullptr);
     if (rc) return rc;
     r_top -= nc;

@@ -78,6 +78,12 @@ __device__ __forceinline__ int xcd_grouped_x()
   return (x / span) * span + (x % kXcds) * G + (x % span) / kXcds;
 }
 
+// Latency chains on a handful of waves (optical depth, CIA splines, the spectrum) share the
+// machine with the line sweep of the NEXT step, which keeps every SIMD's issue slots busy:
+// at equal priority a chain gets one issue slot in seven.  Raised issue priority lets its
+// instructions go first; the sweep loses almost nothing (the chain is a few dozen waves).
+__device__ __forceinline__ void latency_critical() { __builtin_amdgcn_s_setprio(3); }
+
 // Gate of the line-sweep kernels: rays still descending (the device counter flags[0],
 // maintained by the optical-depth kernel of the step before).
 __device__ __forceinline__ bool sweep_active(const int *flags, int eager)
@@ -850,6 +856,7 @@ void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ m
 {
   const int j = fj + blockIdx.x * 64 + threadIdx.x;
   if (j >= lj) return;
+  latency_critical();
   const long n = C.nwave;
   const double *__restrict__ x = C.wn, *__restrict__ uw = C.uw;
   const double *y = mid + j; double *z = z2 + j, *vv = v + j;
@@ -1016,6 +1023,7 @@ __global__ __launch_bounds__(256)
 void k_optical_depth(TauArgs T)
 {
   if (!T.eager && T.flags[0] == 0) return;
+  latency_critical();
   __shared__ double s_y0[kTauH][kTauW];
   __shared__ double s_tv[kTauH][kTauW];
   __shared__ int s_alive[kTauW];
@@ -1118,15 +1126,20 @@ void k_optical_depth(TauArgs T)
 // which is the reference's sum re-associated (top-down instead of bottom-up) with
 // interval lengths taken as rad[k+1]-rad[k] rather than differences of their running
 // sum: ~1e-15 relative.  One lane per wavenumber walks the chunk's layers.
-// STAGED (one wave per block, small shards): the step's outputs wait in LDS and are stored
-// after the chain.  On this part stores and loads share one in-order counter, so a store in
-// the loop would make every wait for a prefetched load wait for the store's round trip too.
+// STAGED (one wave per block, small shards): the step's inputs are fetched into LDS before
+// the chain starts -- all loads of a ray independent and in flight together, one memory round
+// trip per step instead of one per layer -- and its outputs wait in LDS until the chain is
+// done (on this part stores and loads share one in-order counter, so a store in the loop would
+// make every wait for a load wait for the store's round trip too).  The chain itself then runs
+// at arithmetic latency.
 template <bool STAGED, bool EXTRAS>      // EXTRAS: a scattering or cloud model is switched on
 __global__ __launch_bounds__(256)
 void k_optical_depth_vertical(TauArgs T)
 {
   if (!T.eager && T.flags[0] == 0) return;
+  latency_critical();
   __shared__ double s_out[STAGED ? 2 * kMaxChunk * 64 : 1];
+  __shared__ double s_in[STAGED ? (kMaxChunk + 1) * 64 : 1];
   const int nr = T.nr;
   int nstill = 0, deep = 0;
   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
@@ -1138,8 +1151,6 @@ void k_optical_depth_vertical(TauArgs T)
     double y1 = 0, y2 = 0;
     if (T.r_top + 1 < nr) y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
     if (T.r_top + 2 < nr) y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
-    // total extinction of the layers ahead is requested six steps before it is used, so
-    // that the sequential part runs on arithmetic latency, not on memory round trips
     auto total_ext = [&](int c) -> double {
       if (c >= T.nc) return 0.0;
       const int rs = T.r_top - c;
@@ -1147,13 +1158,22 @@ void k_optical_depth_vertical(TauArgs T)
       if (EXTRAS) return T.e[k] + scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[k];   // tau.c:231-232
       return T.e[k] + T.ecs[k];
     };
-    double q0 = total_ext(0), q1 = total_ext(1), q2 = total_ext(2), q3 = total_ext(3), q4 = total_ext(4), q5 = total_ext(5);
+    double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+    if (STAGED) {
+#pragma unroll 8
+      for (int c = 0; c < T.nc; c++) s_in[c * 64 + threadIdx.x] = total_ext(c);
+      s_in[T.nc * 64 + threadIdx.x] = 0.0;
+    } else {
+      // total extinction of the layers ahead is requested six steps before it is used
+      q0 = total_ext(0); q1 = total_ext(1); q2 = total_ext(2); q3 = total_ext(3); q4 = total_ext(4); q5 = total_ext(5);
+    }
     int done = 0;
     for (int c = 0; c < T.nc; c++) {
       const int rs = T.r_top - c, ri = nr - 1 - rs, n = nr - rs;
       const long long k = (long long)rs * T.nsh + w;
-      const double yraw = q0, ybelow = q1;
-      q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6);
+      double yraw, ybelow;
+      if (STAGED) { yraw = s_in[c * 64 + threadIdx.x]; ybelow = s_in[(c + 1) * 64 + threadIdx.x]; }
+      else { yraw = q0; ybelow = q1; q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6); }
       double tv, y0 = yraw;
       if (n == 1) {
         tv = 0.0;                                           // eclipse.c:45-46
@@ -1208,6 +1228,7 @@ struct EmisArgs {
 __global__ __launch_bounds__(256)
 void k_emission(EmisArgs E)
 {
+  latency_critical();
   __shared__ double s_I[kMaxAngles][16];
   const int wi = threadIdx.x % 16, a = threadIdx.x / 16;
   const long long w = (long long)blockIdx.x * 16 + wi;
@@ -1253,6 +1274,7 @@ struct ModArgs {
 __global__ __launch_bounds__(256)
 void k_modulation(ModArgs M)
 {
+  latency_critical();
   const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
   if (w >= M.nsh) return;
   const int nr = M.nr;

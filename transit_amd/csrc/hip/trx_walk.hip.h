@@ -109,42 +109,72 @@ void k_cand_select(long long n, const double *__restrict__ wavn, const double *_
   }
 }
 
-// Strongest single line of every layer: grid (candidate blocks, layers).  cand == null: all lines.
-// kmax is [layer][nmx] bit patterns, zeroed by the host.
-__global__ __launch_bounds__(256)
-void k_layer_max(LinesDev L, LayerDev Y, int niso, const int32_t *__restrict__ cand, long long ncand,
+// Strongest single line of every layer.  One wavefront per 256 candidates (four per lane) and
+// kLayerMaxGroup layers: the lines are read once, the lanes keep running maxima per layer and the
+// wave reduces them once at the end.  cand == null: all lines.  kmax is [layer][nmx] bit
+// patterns, zeroed beforehand.
+constexpr int kLayerMaxGroup = 16;
+constexpr int kLayerMaxLines = 4;
+
+__global__ __launch_bounds__(64)
+void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const int32_t *__restrict__ cand, long long ncand,
                  const double *__restrict__ e2tab, int nmx, const int32_t *__restrict__ iso_mx,
                  unsigned long long *__restrict__ kmax_bits)
 {
   __shared__ double s_e2[64];
-  __shared__ double s_red[4];
-  if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
-  __syncthreads();
-  const int r = blockIdx.y;
+  s_e2[threadIdx.x] = e2tab[threadIdx.x];
+  __builtin_amdgcn_wave_barrier();
+  double gf[kLayerMaxLines], elow[kLayerMaxLines], wavn[kLayerMaxLines]; int iso[kLayerMaxLines];
+#pragma unroll
+  for (int u = 0; u < kLayerMaxLines; u++) {
+    const long long t = ((long long)blockIdx.x * kLayerMaxLines + u) * 64 + threadIdx.x;
+    gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
+    if (t < ncand) {
+      const long long ln = cand ? cand[t] : t;
+      if (L.inrange[ln]) { gf[u] = L.gf[ln]; elow[u] = L.elow[ln]; wavn[u] = L.wavn[ln]; iso[u] = L.iso[ln]; }
+    }
+  }
+  const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
+  for (int r = r0; r < r1; r++) {
+    const double ct = Y.negc_over_t[r];
+    double best = 0.0;
+#pragma unroll
+    for (int u = 0; u < kLayerMaxLines; u++) {
+      const double s = gf[u] * exp_neg(ct * elow[u], s_e2) * (1 - exp_neg(ct * wavn[u], s_e2));
+      const double k = s * Y.strength_f[r * niso + iso[u]];
+      if (nmx == 1) best = fmax(best, k);
+      else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
+        unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso[u]]];
+        const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
+        if (kb > *slot) atomicMax(slot, kb);
+      }
+    }
+    if (nmx == 1) {
+      const double m = wave_max(best);
+      if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(m));
+    }
+  }
+}
+
+// Start of a run: every small per-run buffer in ONE launch (a dozen memsets cost more than the
+// spectrum's arithmetic at demo size).
+struct RunInit {
+  int *last; long long nsh;            // -1: ray still descending
+  double *acc;                         // [2][nsh] running Simpson sums of the vertical rays
+  unsigned long long *counters; int ncounters;
+  double *kmax; int nkmax;
+  int *status, *flags; int rays;
+};
+
+__global__ __launch_bounds__(256)
+void k_run_init(RunInit R)
+{
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  double k = 0.0; int iso = 0;
-  if (t < ncand) {
-    const long long ln = cand ? cand[t] : t;
-    if (L.inrange[ln]) {
-      iso = L.iso[ln];
-      const double ct = Y.negc_over_t[r];
-      const double s = L.gf[ln] * exp_neg(ct * L.elow[ln], s_e2) * (1 - exp_neg(ct * L.wavn[ln], s_e2));
-      k = s * Y.strength_f[r * niso + iso];
-    }
-  }
-  if (nmx == 1) {
-    const double m = wave_max(k);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double mm = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-      if (mm > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(mm));
-    }
-  } else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
-    unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso]];
-    const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
-    if (kb > *slot) atomicMax(slot, kb);
-  }
+  if (t < R.nsh) { R.last[t] = -1; R.acc[t] = 0.0; R.acc[R.nsh + t] = 0.0; }
+  if (t < R.ncounters) R.counters[t] = 0ull;
+  if (t < R.nkmax) R.kmax[t] = 0.0;
+  if (t < 4) R.status[t] = 0;
+  if (t < 8) R.flags[t] = t == 0 ? R.rays : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -211,11 +241,21 @@ void k_wave_plan(WalkPlan P, int niso, const int32_t *__restrict__ gblock, const
 // ---------------------------------------------------------------------------
 // One 32-byte record per line, read with ONE scalar load per line.
 //   meta bit 0: the line anchors a co-added group (extinction.c:449-462), bit 1: it is the
-//   group's last member; bits 2..: iown % osamp of the group's anchor; cell = iown / osamp.
+//   group's last member, bit 2: the exponential is rebased on this line (below);
+//   bits 3..: iown % osamp of the group's anchor; cell = iown / osamp.
+// The array carries one record of padding: the walk requests record n+1 while it works on n.
 struct alignas(32) WalkLine { double wavn, elow, gf; int32_t meta, cell; };
 
 constexpr int kWalkLayers = 64;      // layers per step = lanes
-constexpr double kRebaseMax = 0.00390625;   // 2^-8: polynomial range of the rebased exponential
+// exp(ct*wavn) along a wavenumber-sorted range: with a base point t0 = fl(ct*w0), c0 = -t0 and
+// E0 = exp(t0), x = fma(ct, wavn, c0) is the EXACT difference ct*wavn - t0 (one rounding) and
+// exp(ct*wavn) = E0 * P5(x) to 5e-18 while 0 <= x <= 2^-8.  Base points are a property of the
+// LINE LIST (meta bit 2, set by trx_create: a range's first line, then every line more than
+// kRebaseSpan below the last base), so that every rounding depends on the list and the lane's
+// layer alone -- not on which other layers share a step nor on which groups a step can skip.
+// c*span/T <= 2^-8 needs T >= kWalkMinTemp (colder runs take the two-kernel path).
+constexpr double kRebaseSpan = 0.03125;     // cm-1
+constexpr double kWalkMinTemp = 1.4387752 * kRebaseSpan * 256.0 * 1.05;
 
 struct WalkArgs {
   const WalkLine *lines;
@@ -237,9 +277,6 @@ struct WalkArgs {
   const int *flags; const int *last; int eager;
 };
 
-// exp(ct*wavn) for consecutive lines of a wavenumber-sorted list: with the base point
-// t0 = fl(ct*w0) kept as c0 = -t0 and E0 = exp(t0), the argument x = fma(ct, wavn, c0) is the
-// EXACT difference ct*wavn - t0 (one rounding), 0 <= x <= 2^-8, and exp(ct*wavn) = E0 * P5(x).
 __device__ __forceinline__ double exp_small(double x)
 {
   double p = 0x1.1111111111111p-7;                 // 1/120
@@ -251,14 +288,18 @@ __device__ __forceinline__ double exp_small(double x)
   return p;
 }
 
+constexpr int kWalkWaves = 4;        // independent waves per workgroup (a CU holds few workgroups)
+
 template <int NB, bool PROF>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64 * kWalkWaves)
 void k_line_walk(WalkArgs A)
 {
   constexpr int Rc = NB / 2 - 1;
   if (!A.eager && A.flags[0] == 0) return;
-  const int w = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = blockIdx.x * kWalkWaves + wv;            // wave-uniform
+  if (w >= A.P.nwaves) return;
+  const int lane = threadIdx.x & 63;
   const int blo = A.P.blo[w], bhi = A.P.bhi[w];
   if (bhi < blo) return;                                  // nothing of this range reaches the shard
   if (A.last) {   // every ray of the range's bins has stopped (tau.c:277-287): nobody reads them
@@ -266,8 +307,9 @@ void k_line_walk(WalkArgs A)
     for (int j = blo + lane; j <= bhi; j += 64) open |= A.last[j - A.lo] < 0;
     if (__ballot(open) == 0ull) return;
   }
-  __shared__ double s_thr[kMaxDop + 1];
-  __shared__ double s_e2[64];
+  __shared__ double s_thr_w[kWalkWaves][kMaxDop + 1];     // per wave: waves come and go on their own
+  __shared__ double s_e2_w[kWalkWaves][64];
+  double *s_thr = s_thr_w[wv], *s_e2 = s_e2_w[wv];
   for (int i = lane; i <= A.ndop; i += 64) s_thr[i] = A.dthr[i];
   s_e2[lane] = A.e2tab[lane];
   __builtin_amdgcn_wave_barrier();
@@ -288,20 +330,26 @@ void k_line_walk(WalkArgs A)
   const int il = A.Y.ilor[ri];
   const int idst = A.sticky_idop[ri];
   const int ps_st = A.psize[idst * A.nlor + il];
-  const unsigned vo_st = (unsigned)(A.poff[idst * A.nlor + il] + ps_st);     // table index of the profile centre
-  // widest profile any lane of this step can use for this isotope: wave-uniform bound for the bin loop
-  const int psm_s = wave_max_i(valid ? A.Y.psmax[ri] : 0);
+  const unsigned vo_st = (unsigned)(A.poff[idst * A.nlor + il] + ps_st);     // table index of the sticky profile's centre
+  // widest profile any lane of this step can use for this isotope: wave-uniform bound for the bin
+  // loop, split into whole cells and the rest (psm_s = psq*osamp + psr)
+  const int psm_s = __builtin_amdgcn_readfirstlane(wave_max_i(valid ? A.Y.psmax[ri] : 0));
+  const int psq = psm_s / A.osamp, psr = psm_s - psq * A.osamp;
+  const int lo32 = (int)A.lo, hi32 = (int)A.hi;            // (the grid has < 2^31 bins: trx_create)
+  // every bin this range can reach lies inside the shard: no clipping of the slot masks
+  const bool interior = A.lines[A.gfirst[g1 - 1]].cell - Rc >= lo32 && A.lines[l0].cell + Rc + 1 < hi32;
 
   // Doppler index of the first anchor, then followed downwards (wavenumbers descend => it never rises)
   int lo_i = index_from(s_thr, ad * A.lines[l0].wavn, A.Y.idop0[ri]);
   double thr_lo = s_thr[lo_i];
   int ps_cur = A.psize[lo_i * A.nlor + il];
-  unsigned vo_cur = (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);
+  unsigned vo_cur = 4u * (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);   // byte offset of the profile centre
+  const unsigned vo_st4 = 4u * vo_st;
 
   double acc[NB];
 #pragma unroll
   for (int k = 0; k < NB; k++) acc[k] = 0.0;
-  int jc = A.lines[l0].cell;                               // frame: acc[k] <-> bin jc - Rc + k
+  int jc = __builtin_amdgcn_readfirstlane(A.lines[l0].cell);   // frame: acc[k] <-> bin jc - Rc + k
   unsigned long long nb = 0, nev = 0, nsk = 0;
 
   auto flush = [&](int k, double v) {                      // bin of slot k leaves the frame
@@ -309,83 +357,129 @@ void k_line_walk(WalkArgs A)
     if (j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = v;
   };
 
-  double c0 = 0.0, E0 = 1.0;
-  bool based = false;
-  double pk = 0.0, wav_a = 0.0;
-  int cell = jc, imod = 0;
+  // bins of the interval that no frame position covers (a jump over empty or skipped cells, the
+  // tail below the last evaluated group) still get their record: zeros
+  auto fill_zero = [&](int ja, int jb) {                   // bins ja..jb inclusive
+    ja = max(ja, blo); jb = min(jb, bhi);
+    for (int j = ja; j <= jb; j++) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = 0.0;
+  };
 
-  for (int ln = l0; ln < l1; ln++) {
-    const WalkLine Ln = A.lines[ln];                       // wave-uniform: one scalar load
-    // ---- strength of the line in every layer
-    const double e1 = exp_neg(ct * Ln.elow, s_e2);
-    double x = __builtin_fma(ct, Ln.wavn, c0);
-    // (a lane rebases on ITS OWN argument only, so that its sums do not depend on which other
-    // layers share the step)
-    const bool reb = !based || x > kRebaseMax;
-    if (__any(reb)) {
-      if (reb) {
-        const double t0 = ct * Ln.wavn;
-        E0 = exp_neg(t0, s_e2); c0 = -t0; x = 0.0;
-      }
-      based = true;
-    }
-    const double q = __builtin_fma(-E0, exp_small(x), 1.0);
-    const double s = Ln.gf * e1 * q;
-    if (Ln.meta & 1) { pk = s; wav_a = Ln.wavn; cell = Ln.cell; imod = Ln.meta >> 2; }
-    else pk += s;
-    if (!(Ln.meta & 2)) continue;
-    // ---- the group is complete: threshold, density, profile, bins (extinction.c:464-509)
-    const double pkf = pk * f;
-    const bool below = pkf < lim;                          // :467
-    if (PROF && cell >= A.lo && cell < A.hi && valid) { if (below) nsk++; else nev++; }
-    const double kk = pkf * dens;                          // :472-473
-    // nearest Doppler-width index: own one while alphad*wn/alphal >= 0.1, else the sticky one (:480-483)
-    const double v = ad * wav_a;
-    while (__any(v < thr_lo)) {
-      if (v < thr_lo) {
-        lo_i--; thr_lo = s_thr[lo_i];
-        ps_cur = A.psize[lo_i * A.nlor + il];
-        vo_cur = (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);
-      }
-    }
-    const bool own = wav_a >= wc;
-    const int ps = own ? ps_cur : ps_st;
-    const unsigned vo = own ? vo_cur : vo_st;
-    const bool act = valid && !below;
-    // ---- move the frame down to the group's cell
-    if (cell != jc) {
-      int sh = jc - cell;
-      if (sh >= NB) {
+  double pk = 0.0;                   // strength of the group so far (0 between groups)
+  int cell = jc, imod = 0;
+  unsigned cand = 0u;                // slots of the frame (once it sits on the group's cell) that some
+                                     // layer of this step can reach from the current group; 0: skip it
+  // table entries requested for the previous group, added when the next group is complete (or
+  // the frame moves): a gather's round trip then overlaps a line's worth of arithmetic
+  // (every slot takes part, a slot the line does not reach with a table value of 0: adding
+  // kk * 0 leaves the sum as it is, and eight unconditional multiply-adds are fewer instructions
+  // than eight scalar tests around six of them)
+  float pv_p[NB]; double kk_p = 0.0; bool pend = false;    // pend: wave-uniform
 #pragma unroll
-        for (int k = 0; k < NB; k++) { flush(k, acc[k]); acc[k] = 0.0; }
-        jc = cell;
-      } else {
-        for (; sh > 0; sh--) {
-          flush(NB - 1, acc[NB - 1]);
+  for (int k = 0; k < NB; k++) pv_p[k] = 0.f;
+  auto settle = [&]() {
 #pragma unroll
-          for (int k = NB - 1; k > 0; k--) acc[k] = acc[k - 1];
-          acc[0] = 0.0;
-          jc--;
+    for (int k = 0; k < NB; k++) acc[k] += kk_p * (double)pv_p[k];     // :507 (two roundings, as compiled there)
+    pend = false;
+  };
+  const char *tab_bytes = (const char *)A.table;
+
+  // line records through the scalar cache: the address is wave-uniform and the data constant
+  typedef const __attribute__((address_space(4))) double *ScalarF64;
+  typedef const __attribute__((address_space(4))) int32_t *ScalarI32;
+  ScalarF64 rp = (ScalarF64)(A.lines + l0);
+  double L_wavn = rp[0], L_elow = rp[1], L_gf = rp[2];
+  int L_meta = ((ScalarI32)rp)[6] | 4, L_cell = ((ScalarI32)rp)[7];    // (a range starts on a base point)
+  double c0 = 0.0, E0 = 1.0, wav_a = L_wavn;
+  for (int left = l1 - l0; left > 0; left--) {
+    rp += 4;                                               // next record, requested a line ahead
+    const double N_wavn = rp[0], N_elow = rp[1], N_gf = rp[2];
+    const int N_meta = ((ScalarI32)rp)[6], N_cell = ((ScalarI32)rp)[7];
+    if (L_meta & 4) {                                      // base point of the rebased exponential
+      const double t0 = ct * L_wavn;
+      E0 = exp_neg(t0, s_e2); c0 = -t0;
+    }
+    if (L_meta & 1) {
+      // slots some layer of this step can reach from this group: |(k - Rc)*osamp - imod| <= psm_s
+      // and the bin inside the shard.  All wave-uniform integer arithmetic.
+      cell = L_cell; imod = L_meta >> 3; wav_a = L_wavn;
+      if (NB == 2) cand = (imod <= psm_s ? 1u : 0u) | (A.osamp - imod <= psm_s ? 2u : 0u);
+      else {
+        const int klo = Rc - psq + (imod > psr ? 1 : 0), khi = Rc + psq + (imod + psr >= A.osamp ? 1 : 0);
+        cand = ((2u << khi) - 1u) & ~((1u << klo) - 1u);   // (0 <= klo <= khi < NB by the choice of NB)
+      }
+      if (!interior) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int j = cell - Rc + k; if (j < lo32 || j >= hi32) cand &= ~(1u << k); }
+      }
+      if (PROF) cand |= 0x80000000u;                       // (counting runs evaluate every group)
+    }
+    if (cand) {
+      // ---- strength of the line in every layer
+      const double e1 = exp_neg(ct * L_elow, s_e2);
+      const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, L_wavn, c0)), 1.0);
+      pk += L_gf * e1 * q;
+      if (L_meta & 2) {
+        // ---- the group is complete: threshold, density, profile, bins (extinction.c:464-509)
+        const double pkf = pk * f;
+        pk = 0.0;
+        const bool below = pkf < lim;                          // :467
+        if (PROF && cell >= lo32 && cell < hi32 && valid) { if (below) nsk++; else nev++; }
+        const double kk = pkf * dens;                          // :472-473
+        // nearest Doppler-width index: own one while alphad*wn/alphal >= 0.1, else the sticky one (:480-483)
+        const double v = ad * wav_a;
+        if (__any(v < thr_lo)) {
+          do {
+            if (v < thr_lo) {
+              lo_i--; thr_lo = s_thr[lo_i];
+              ps_cur = A.psize[lo_i * A.nlor + il];
+              vo_cur = 4u * (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);
+            }
+          } while (__any(v < thr_lo));
+        }
+        const bool own = wav_a >= wc;
+        const int ps = own ? ps_cur : ps_st;
+        const unsigned vo4 = own ? vo_cur : vo_st4;
+        const bool act = valid && !below;
+        if (pend) settle();
+        // ---- move the frame down to the group's cell
+        if (cell != jc) {
+          int sh = jc - cell;
+          if (sh >= NB) {
+#pragma unroll
+            for (int k = 0; k < NB; k++) { flush(k, acc[k]); acc[k] = 0.0; }
+            fill_zero(cell + Rc + 2, jc - Rc - 1);
+            jc = cell;
+          } else {
+            for (; sh > 0; sh--) {
+              flush(NB - 1, acc[NB - 1]);
+#pragma unroll
+              for (int k = NB - 1; k > 0; k--) acc[k] = acc[k - 1];
+              acc[0] = 0.0;
+              jc--;
+            }
+          }
+        }
+        // ---- bins: slot k is bin jc - Rc + k at fine distance d = (k - Rc)*osamp - imod from the line
+        // (a bin outside the shard may be accumulated too: it never leaves the frame, see flush)
+        kk_p = kk;
+        pend = true;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          const int d = (k - Rc) * A.osamp - imod;              // wave-uniform
+          const bool ok = act && (d < 0 ? -d : d) <= ps;
+          float pv = 0.f;
+          if (ok) pv = *(const float *)(tab_bytes + (vo4 + 4u * (unsigned)d));     // 32-bit byte offset (table < 4 GB)
+          pv_p[k] = pv;
+          if (PROF && ok && cell - Rc + k >= lo32 && cell - Rc + k < hi32) nb++;
         }
       }
     }
-    // ---- bins: slot k is bin jc - Rc + k at fine distance d = (k - Rc)*osamp - imod from the line
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      const int d = (k - Rc) * A.osamp - imod;              // wave-uniform
-      const int ad_ = d < 0 ? -d : d;
-      const int j = jc - Rc + k;
-      if (ad_ <= psm_s && j >= A.lo && j < A.hi) {          // wave-uniform: some layer may reach this bin
-        if (act && ad_ <= ps) {
-          const float pv = A.table[(long long)vo + d];
-          acc[k] += kk * (double)pv;                       // :507 (two roundings, as compiled there)
-          if (PROF) nb++;
-        }
-      }
-    }
+    L_wavn = N_wavn; L_elow = N_elow; L_gf = N_gf; L_meta = N_meta; L_cell = N_cell;
   }
+  if (pend) settle();
 #pragma unroll
   for (int k = 0; k < NB; k++) flush(k, acc[k]);
+  fill_zero(blo, jc - Rc - 1);
   if (PROF && valid && A.counters) {
     if (nb)  atomicAdd(&A.counters[(long long)r * 3 + 0], nb);
     if (nev) atomicAdd(&A.counters[(long long)r * 3 + 1], nev);
@@ -394,8 +488,9 @@ void k_line_walk(WalkArgs A)
 }
 
 // e[layer][j] = sum of the partial records of bin j, isotope blocks in order, ranges in order.
-// One wavefront (lanes = layers) per 8 consecutive bins; lanes then hold 8 consecutive doubles
-// of their layer's row and store them as one 64-byte segment.
+// A block handles 8 consecutive bins, one wavefront (lanes = layers) per bin; the records of a
+// bin are requested four at a time and added in order; the 8 x 64 results cross an LDS tile so
+// that every layer's row receives its 8 bins as one 64-byte segment.
 struct CombineArgs {
   WalkPlan P; int niso; const int32_t *gblock;
   long long lo, nsh; int r_top, nc;
@@ -406,54 +501,58 @@ struct CombineArgs {
 
 constexpr int kCombineBins = 8;
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64 * kCombineBins)
 void k_walk_combine(CombineArgs C)
 {
   if (!C.eager && C.flags[0] == 0) return;
-  const int lane = threadIdx.x;
+  latency_critical();
+  __shared__ double s_t[kCombineBins][kWalkLayers + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long j0 = C.lo + (long long)blockIdx.x * kCombineBins;
   const int nbins = (int)min((long long)kCombineBins, C.lo + C.nsh - j0);
-  if (C.last) {
-    const bool open = lane < nbins && C.last[j0 - C.lo + lane] < 0;
-    if (__ballot(open) == 0ull) return;
+  if (C.last) {   // every ray of these bins has stopped: nobody reads them (block-uniform)
+    bool open = false;
+    for (int t = 0; t < nbins; t++) open |= C.last[j0 - C.lo + t] < 0;
+    if (!open) return;
   }
-  const bool valid = lane < C.nc;
-  const int r = C.r_top - (valid ? lane : 0);
-  double sum[kCombineBins];
+  const long long j = j0 + wv;                       // this wave's bin
+  const bool have = wv < nbins;
   int cur_mx = -1;
-  auto store = [&](int mx) {
-    if (!valid) return;
-    double *dst = C.e + ((long long)r * C.nmx + mx) * C.nsh + (j0 - C.lo);
-#pragma unroll
-    for (int t = 0; t < kCombineBins; t++) if (t < nbins) dst[t] = sum[t];
+  double sum = 0.0;
+  auto store = [&](int mx) {                         // all waves of the block arrive here together
+    s_t[wv][lane] = sum;
+    __syncthreads();
+    const int layer = threadIdx.x / kCombineBins, t = threadIdx.x % kCombineBins;
+    if (layer < C.nc && t < nbins)
+      C.e[((long long)(C.r_top - layer) * C.nmx + mx) * C.nsh + (j0 - C.lo) + t] = s_t[t][layer];
+    __syncthreads();
   };
   for (int b = 0; b < C.niso; b++) {
     if (C.gblock[b] == C.gblock[b + 1]) continue;
     const int mx = C.nmx == 1 ? 0 : C.iso_mx[b];
     if (mx != cur_mx) {
       if (cur_mx >= 0) store(cur_mx);
-      cur_mx = mx;
-#pragma unroll
-      for (int t = 0; t < kCombineBins; t++) sum[t] = 0.0;
+      cur_mx = mx; sum = 0.0;
     }
+    if (!have) continue;
     const int w0 = C.P.wbase[b], w1 = C.P.wbase[b + 1];
-    const long long jl = j0, jh = j0 + nbins - 1;
-    // ranges of the block that touch [jl, jh]: bhi and blo descend with w
-    int a = w0, z = w1;                      // first w with blo[w] <= jh
-    while (a < z) { const int m = (a + z) >> 1; if (C.P.blo[m] <= jh) z = m; else a = m + 1; }
+    // ranges of the block that touch bin j: bhi and blo descend with w
+    int a = w0, z = w1;                      // first w with blo[w] <= j
+    while (a < z) { const int m = (a + z) >> 1; if (C.P.blo[m] <= j) z = m; else a = m + 1; }
     const int wa = a;
-    a = wa; z = w1;                          // first w >= wa with bhi[w] < jl
-    while (a < z) { const int m = (a + z) >> 1; if (C.P.bhi[m] < jl) z = m; else a = m + 1; }
+    z = w1;                                  // first w >= wa with bhi[w] < j
+    while (a < z) { const int m = (a + z) >> 1; if (C.P.bhi[m] < j) z = m; else a = m + 1; }
     const int wz = a;
-    for (int w = wa; w < wz; w++) {
-      const int bl = C.P.blo[w], bh = C.P.bhi[w];
-      if (bh < bl) continue;
-      const long long rec = C.P.off[w];
+    for (int w = wa; w < wz; w += 4) {
+      double v[4];
 #pragma unroll
-      for (int t = 0; t < kCombineBins; t++) {
-        const long long j = j0 + t;
-        if (t < nbins && j >= bl && j <= bh) sum[t] += C.part[(rec + (j - bl)) * kWalkLayers + lane];
+      for (int u = 0; u < 4; u++) {
+        const int ww = min(w + u, wz - 1);
+        const long long rec = C.P.off[ww] + (j - C.P.blo[ww]);
+        v[u] = (w + u < wz) ? C.part[rec * kWalkLayers + lane] : 0.0;
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (w + u < wz) sum += v[u];
     }
   }
   if (cur_mx >= 0) store(cur_mx);
