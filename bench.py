@@ -47,41 +47,56 @@ def parse():
     ap.add_argument("--layer-chunk", type=int, default=0)
     ap.add_argument("--solution", choices=("eclipse", "transit"), default="eclipse")
     ap.add_argument("--ncia", type=int, default=1)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N>1: weak = every GPU gets its own CH4-demo-sized slice (band and line list grow with N); "
-                         "strong = the one CH4-demo run split N ways")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N>1 headline: strong = the ONE CH4-demo run split N ways (BASELINE's metric: the demo's "
+                         "wall-clock at 1/2/4/8 GPUs); weak = every GPU gets its own demo-sized slice")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N>1: skip the secondary measurements (weak scaling; BASELINE configs[4] split N ways)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
-                    help="N>1 on FEWER GPUs (ranks share devices): gloo instead of RCCL -- the engine's "
-                         "exchanges go over the host transport and the gather through host memory. "
-                         "Exercises the multi-rank code path; its timing means nothing")
+                    help="N>1 on FEWER GPUs (ranks share devices): gloo instead of RCCL, the gather goes through host "
+                         "memory.  Exercises the multi-rank code path; its timing means nothing")
     ap.add_argument("--comm-single", action="store_true",
                     help="N=1 only: run through a 1-rank RCCL communicator (the code path every rank of an N>1 job takes)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = full workload)")
     return ap.parse_args()
 
 
+def kernel_source_hash():
+    """Fingerprint of the kernel sources a committed PMC profile must match to be quoted."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h"):
+        h.update(open(os.path.join(ROOT, "transit_amd", "csrc", "hip", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch (all launches, like avg_launch_ms) of `kernel` from the committed rocprofv3 PMC
-    passes (profiles/*pmc_traffic*.json; FETCH_SIZE/WRITE_SIZE collected in separate
-    --pmc runs and corrected as MI355X_MICROARCH.md prescribes).  None when no
-    profile of the current kernels is committed."""
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_traffic*.json; FETCH_SIZE / WRITE_SIZE from separate --pmc passes, corrected as
+    MI355X_MICROARCH.md prescribes) -- quoted ONLY when that summary was collected from the kernel
+    sources of this tree (its `kernel_sources` fingerprint); otherwise None: a stale number is
+    worse than none.  Returns (bytes_per_launch, file) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        k = d["kernels"]["trx::" + kernel]
-        return float(k.get("hbm_bytes_per_launch", k.get("hbm_bytes_per_active_launch")))
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel_sources") != kernel_source_hash():
+                continue
+            for name, k in d["kernels"].items():
+                if kernel in name:
+                    return float(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def make_workload(args, tag, nlines, verb=2, wnhigh=None, unique=True):
     from transit_amd import synth
     d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%s" % (
         tag, nlines, args.layers, os.getpid() if unique else os.environ.get("MASTER_PORT", "0")))
+    if not unique and os.path.exists(os.path.join(d, "case.cfg")):
+        return d
     synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=wnhigh or args.wnhigh, wndelt=args.wndelt,
                     wnosamp=args.wnosamp,
                     nlayers=args.layers, solution=args.solution, toomuch=10.0, ethresh=1e-50, nwidth=20.0,
@@ -136,6 +151,20 @@ def cpu_baseline(args, gpu_spectrum_full):
     return out
 
 
+def time_steps(step, fence, warmup, steps, reduce_max=None):
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if reduce_max:
+        el = reduce_max(el)
+    return 1e3 * el / steps
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,122 +184,156 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
-    cdev = torch.device("cpu") if (world > 1 and args.rehearse) else dev       # where collectives run
+    cdev = torch.device("cpu") if (world > 1 and args.rehearse) else dev       # where torch collectives run
 
     from transit_amd.host import Problem
     from transit_amd.engine import Engine
-    from transit_amd.shard import shard_bounds
+    from transit_amd.shard import balanced_bounds, bin_costs
     from transit_amd import dist as tdist
 
-    # N=1: the CH4-demo run.  N>1, weak: the band and the line list grow N-fold at the
-    # same resolution and line density, so every GPU owns one CH4-demo-sized slice of one
-    # spectrum (2501 bins, ~1e6 lines + halo).  N>1, strong: the N=1 run split N ways.
-    grow = world if args.scaling == "weak" else 1
-    wnhigh = args.wnlow + grow * (args.wnhigh - args.wnlow)
-    if world > 1:       # one copy of the input files, written by rank 0
-        if rank == 0:
-            d = make_workload(args, "w%d" % world, grow * args.lines, wnhigh=wnhigh, unique=False)
-        dist.barrier()
-        if rank != 0:
-            d = os.path.join(tempfile.gettempdir(), "transit_bench_w%d_%d_%d_%s" % (
-                world, grow * args.lines, args.layers, os.environ.get("MASTER_PORT", "0")))
-    else:
-        d = make_workload(args, "r0", args.lines)
-    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
-    nwn, nlayer = P.nwn, P.nlayer
-    lo, hi = shard_bounds(nwn, world, rank)
-    P.set_shard(lo, hi)
-    st = P.static
-    st.device = local
-    comm = None
-    if (world > 1 and not args.rehearse) or args.comm_single:   # RCCL communicator of the handle: its one gather
-        comm = tdist.create_comm(world, rank, local)
-        st.comm, st.nranks, st.rank = comm, world, rank
-    t0 = time.time()
-    eng = Engine(st)
-    t_create = time.time() - t0
-    opts = P.opts
-    opts.layer_chunk = args.layer_chunk
-    opts.profile = 0
-
-    mpad = tdist.padded_len(nwn, world)
-    spec_local = torch.zeros(mpad, dtype=torch.float64, device=dev)      # slice + padding to equal counts
-    gathered = torch.zeros(mpad * world, dtype=torch.float64, device=cdev) if world > 1 else None
-
-    def step():
-        eng.run_device(P.atm, opts, spec_local.data_ptr())
-        if world > 1:       # the single exchange of the path
-            if comm is not None:      # trx_gather: ncclAllGather on the handle's stream (C ABI)
-                eng.gather(spec_local.data_ptr(), gathered.data_ptr(), mpad)
-            else:                     # rehearsal on a shared GPU: gloo through host memory
-                dist.all_gather_into_tensor(gathered, spec_local.cpu())
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_step = 1e3 * elapsed / args.steps
+    comm = tdist.create_comm(world, rank, local) if ((world > 1 and not args.rehearse) or args.comm_single) else None
 
-    # one profiled run for the per-kernel event timings and the counters
-    opts.profile = 1
-    r = eng.run(P.atm, opts, debug=("last",))
-    opts.profile = 0
-    stats = eng.stats()
-    layers_needed = int(r["last"].max()) + 1
-    if world > 1:
-        t = torch.tensor([layers_needed], dtype=torch.int64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        layers_needed = int(t.item())
-        full = tdist.gather_spectrum(spec_local if cdev == dev else spec_local.cpu(), nwn, world, rank,
-                                     out=gathered).cpu().numpy()
-    else:
-        full = spec_local[: hi - lo].cpu().numpy()
+    def shared_case(tag, nlines, wnhigh=None, **over):
+        """Input files of one workload: written by rank 0, read by every rank."""
+        a2 = argparse.Namespace(**{**vars(args), **over})
+        if world == 1:
+            return make_workload(a2, tag, nlines, wnhigh=wnhigh)
+        if rank == 0:
+            d = make_workload(a2, "%s_w%d" % (tag, world), nlines, wnhigh=wnhigh, unique=False)
+        dist.barrier()
+        if rank != 0:
+            d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_w%d_%d_%d_%s" % (
+                tag, world, nlines, a2.layers, os.environ.get("MASTER_PORT", "0")))
+        return d
+
+    def sharded_run(d, steps, warmup, keep=False):
+        """One workload on `world` ranks: bins split by cost, every rank runs its shard on its own
+        handle, trx_gather collects the slices.  Returns a dict of measurements (rank 0: complete)."""
+        P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+        nwn = P.nwn
+        bounds = balanced_bounds(bin_costs(P.static, P.nlayer), world)
+        lo, hi = bounds[rank]
+        P.set_shard(lo, hi)
+        st = P.static
+        st.device = local
+        if comm is not None:
+            st.comm, st.nranks, st.rank = comm, world, rank
+        t0 = time.time()
+        eng = Engine(st)
+        t_first_create = time.time() - t0
+        opts = P.opts
+        opts.layer_chunk = args.layer_chunk
+        opts.profile = 0
+        mpad = max(h - l for l, h in bounds)
+        spec_local = torch.zeros(mpad, dtype=torch.float64, device=dev)      # slice + padding to equal counts
+        gathered = torch.zeros(mpad * world, dtype=torch.float64, device=dev if comm is not None else cdev) if world > 1 else None
+
+        def step():
+            eng.run_device(P.atm, opts, spec_local.data_ptr())
+            if world > 1:       # the single exchange of the path
+                if comm is not None:      # trx_gather: ncclAllGather on the handle's stream (C ABI)
+                    eng.gather(spec_local.data_ptr(), gathered.data_ptr(), mpad)
+                else:                     # rehearsal on a shared GPU: gloo through host memory
+                    dist.all_gather_into_tensor(gathered, spec_local.cpu())
+
+        ms_step = time_steps(step, fence, warmup, steps, reduce_max if world > 1 else None)
+        opts.profile = 1                 # one profiled run: per-kernel event timings and counters
+        r = eng.run(P.atm, opts, debug=("last",))
+        opts.profile = 0
+        stats = eng.stats()
+        layers_needed = int(r["last"].max()) + 1
+        if world > 1:
+            layers_needed = int(reduce_max(layers_needed))
+            g = gathered.cpu().numpy()
+            full = np.concatenate([g[k * mpad: k * mpad + (h - l)] for k, (l, h) in enumerate(bounds)])
+        else:
+            full = spec_local[: hi - lo].cpu().numpy()
+        out = dict(P=P, eng=eng, stats=stats, ms_step=ms_step, layers_needed=layers_needed, full=full, nwn=nwn,
+                   bounds=bounds, t_first_create=t_first_create, opts=opts, dir=d, static=st)
+        if not keep:
+            eng.close()
+            out["eng"] = None
+        return out
+
+    # ---- headline: the CH4-demo run.  N>1: strong scaling (BASELINE's metric is the demo's
+    # wall-clock at 1/2/4/8 GPUs) unless --scaling weak.
+    grow = world if (args.scaling == "weak" and world > 1) else 1
+    wnhigh = args.wnlow + grow * (args.wnhigh - args.wnlow)
+    d = shared_case("demo", grow * args.lines, wnhigh=wnhigh)
+    M = sharded_run(d, args.steps, args.warmup, keep=True)
+    P, eng, stats, ms_step, layers_needed, full, nwn = (M[k] for k in ("P", "eng", "stats", "ms_step", "layers_needed", "full", "nwn"))
+    opts, st = M["opts"], M["static"]
+    lo, hi = M["bounds"][rank]
+    nlayer = P.nlayer
+
+    extras = {"ms_create_first_in_process": 1e3 * M["t_first_create"]}
+    if world == 1:
+        # a handle made in a warm process (the first create of a process also pays for loading the
+        # code object and the runtime's lazy initialisation), its first -- unhinted -- spectrum
+        t0 = time.time(); e2 = Engine(st); extras["ms_create_total"] = 1e3 * (time.time() - t0)
+        t0 = time.time(); e2.run(P.atm, opts); extras["ms_first_spectrum_cold"] = 1e3 * (time.time() - t0)
+        e2.close()
+        exe = os.path.join(ROOT, "transit_amd", "lib", "transit_hip")
+        if os.path.exists(exe):          # the one-shot command, fresh process, same input files
+            t0 = time.time()
+            pr = subprocess.run([exe, "-c", "case.cfg", "--outspec", "cli_spectrum.dat"], cwd=M["dir"], capture_output=True, text=True)
+            extras["ms_cli_wall"] = 1e3 * (time.time() - t0) if pr.returncode == 0 else None
+    elif not args.no_extras:
+        # secondary: the other scaling mode, and BASELINE configs[4] (retrieval scale) split N ways --
+        # the one configuration large enough for 8 GPUs to show their worth
+        other = "weak" if args.scaling == "strong" else "strong"
+        g2 = world if other == "weak" else 1
+        d2 = shared_case("alt", g2 * args.lines, wnhigh=args.wnlow + g2 * (args.wnhigh - args.wnlow))
+        M2 = sharded_run(d2, max(5, args.steps // 10), 3)
+        extras[other] = {"ms_per_step": M2["ms_step"], "value": M2["nwn"] * M2["layers_needed"] / (M2["ms_step"] * 1e-3),
+                         "n_wn": M2["nwn"], "n_lines": g2 * args.lines}
+        d5 = shared_case("c5", 10_000_000, wnhigh=10000.0, wnlow=333.33, wndelt=0.0009667, wnosamp=1, layers=150)
+        M5 = sharded_run(d5, 3, 2)
+        extras["c5_strong"] = {"ms_per_step": M5["ms_step"], "value": M5["nwn"] * M5["layers_needed"] / (M5["ms_step"] * 1e-3),
+                               "n_wn": M5["nwn"], "n_layers": 150, "n_lines": 10_000_000,
+                               "workload": "BASELINE configs[4]: 333.33-10000 cm-1 @0.0009667 cm-1, 150 layers, 1e7 lines"}
 
     if rank == 0:
         L, R, nang = stats["nlines_inrange"], stats["layers_swept"], int(opts.nangles)
         launches = max(int(stats["sweep_launches"]), 1)
-        kern = {"k_group_sweep": stats["ms_k_sweep"], "k_sticky_index": stats["ms_k_sticky"],
-                "k_accumulate": stats["ms_k_accum"]}
+        walked = int(stats["walk_steps"]) == launches
+        line_k = "k_line_walk" if walked else "k_group_sweep"
+        acc_k = "k_walk_combine" if walked else "k_accumulate"
+        kern = {line_k: stats["ms_k_sweep"], acc_k: stats["ms_k_accum"]}
         dom = max(kern, key=kern.get)
-        # Two byte counts per kernel:
-        #  * ref  = the REFERENCE's data flow: the line list (26 B/line) is scanned once per layer
-        #           and per pass -- 52 B per line-layer for the strength kernel, which does both
-        #           passes' scans; 4 B per accumulated bin + 8 B per stored e for the accumulation;
-        #  * kmin = what THIS data flow has to move (SURVEY's B_min idea): the strength kernel reads
-        #           a line ONCE per launch (27 B) for all the launch's layers and writes 9 B per
-        #           (group, layer); the accumulation reads those 9 B + the group's fine-grid index
-        #           (4 B) per (group, layer), the table entries and writes e.
-        # Fusing a launch's layers makes ref/launch-time exceed the HBM peak (it is not HBM traffic),
-        # so roofline.achieved uses kmin -- it cannot exceed 1 -- and ref is reported beside it.
-        G = stats["ngroups"]
-        ref = {"k_group_sweep": 52.0 * L * R, "k_sticky_index": 0.0,
-               "k_accumulate": 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
-        kmin = {"k_group_sweep": 27.0 * L * launches + 9.0 * G * R, "k_sticky_index": 0.0,
-                "k_accumulate": 13.0 * G * R + 4.0 * stats["sum_bins"] + 8.0 * R * (hi - lo)}
-        alg = kmin
-        ach = alg[dom] / launches / (kern[dom] / launches * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
-        ref_gbs = ref[dom] / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
-        # rank 0's share (its lines, bins and slice); x world for the job when N>1
-        b_alg_run = world * (52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * (hi - lo) + 8.0 * (hi - lo) * (1 + nang))
+        nbins = hi - lo
+        # Bytes the dominant kernel's data flow must move per launch.  The walk reads one 32-byte
+        # record per line, 4 bytes per accumulated bin (table) and writes its partial records
+        # (512 B each); the combine reads those and writes e.  Two-kernel form: see DESIGN.md.
+        if walked:
+            alg = {line_k: 32.0 * L * launches + 4.0 * stats["sum_bins"] + 512.0 * stats["walk_records"],
+                   acc_k: 512.0 * stats["walk_records"] + 8.0 * R * nbins}
+        else:
+            G = stats["ngroups"]
+            alg = {line_k: 27.0 * L * launches + 9.0 * G * R, acc_k: 13.0 * G * R + 4.0 * stats["sum_bins"] + 8.0 * R * nbins}
+        ach = alg[dom] / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        # whole run against SURVEY 8(d): B_alg follows the reference's flow (two scans of the 26-byte
+        # line record per layer), B_min is the layer-fused minimum (lines once, 4 B per bin, the
+        # per-(wn, layer) arrays, the outputs).  Rank 0's share x world for the job.
+        b_alg_run = world * (52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
+        b_min_run = world * (52.0 * L + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
+        traffic, traffic_file = measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else (None, None)
         out = {
             "metric": "wavenumber-points*layers/sec (CH4 2-4um emission spectrum)",
             "value": nwn * layers_needed / (ms_step * 1e-3),
             "unit": "wavenumber-points*layers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]%s): %g-%g cm-1 @%g cm-1, wnosamp %d, "
                                    "%s, H2-H2%s CIA" % (
@@ -279,41 +342,38 @@ def main():
                                        "eclipse, 5 angles" if args.solution == "eclipse" else "transit (slant paths)",
                                        " + H2-He" if args.ncia > 1 else ""),
                        "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
-                       "n_lines": int(P.static.nlines), "n_groups": stats["ngroups"], "n_kmax_candidates": stats["ncandidates"], "sum_bins": stats["sum_bins"],
+                       "n_lines": int(st.nlines), "n_groups": stats["ngroups"], "n_kmax_candidates": stats["ncandidates"],
+                       "sum_bins": stats["sum_bins"],
                        "voigt_grid": "%dx%d" % (st.ndop, st.nlor), "table_floats": stats["table_floats"],
-                       "parallelism": "wn-shard x%d" % world,
-                       "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps of <= 32 "
-                                                          "layers (12 per step on a handle's first run)",
-                       "steps_per_run": launches,
+                       "parallelism": "wn-shard x%d, bins split by cost %s, one trx_gather per spectrum" % (
+                           world, [h - l for l, h in M["bounds"]]) if world > 1 else "one GPU",
+                       "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps (<= 64 layers where "
+                                                          "the line walk applies, one lane per layer)",
+                       "steps_per_run": launches, "line_kernel": line_k,
                        "depth_hint": "step plan ends at the previous run's deepest layer (retrieval-loop reuse; "
                                      "warm-up runs provide it); a run that needs more goes on from there",
-                       "ms_create_total": 1e3 * t_create, "ms_create_voigt_table_kernels": stats["ms_create_table"],
+                       "ms_create_voigt_table_kernels": stats["ms_create_table"],
                        "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
                        "ms_tau": stats["ms_tau"], "ms_run_device": stats["ms_run_total"],
                        "ms_host_cia": stats["ms_cia"], "ms_host_total_profiled_run": stats["ms_host_total"],
-                       "b_min_run_bytes": world * (27.0 * L * launches + 22.0 * G * R + 4.0 * stats["sum_bins"]
-                                                   + 24.0 * R * (hi - lo) + 8.0 * (hi - lo) * (1 + nang)),
-                       "b_alg_run_bytes": b_alg_run,
+                       "b_alg_run_bytes": b_alg_run, "b_min_run_bytes": b_min_run,
                        "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9,
                        "line_layer_bins_per_s": world * stats["sum_bins"] / (ms_step * 1e-3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else None,
-                         "note": "achieved = bytes this data flow must move per launch (lines once per launch + "
-                                 "9 B per group-layer out) / measured launch time; `traffic` = the PMC-measured HBM "
-                                 "bytes per launch.  The reference's own flow (52 B per line-layer) is in "
-                                 "ref_flow_GBs: above the HBM peak because a launch covers ~27 layers per line read. "
-                                 "This kernel is bound by the fp64 vector pipe (two exp per line-layer; 110 VALU "
-                                 "instructions per line-layer by SQ_INSTS_VALU, ~32 of them the exps), see "
-                                 "valu_issue_frac_est",
+                         "traffic": traffic, "traffic_source": traffic_file,
+                         "bmin_frac": b_min_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "balg_frac": b_alg_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
-                         "launches": launches, "ref_flow_GBs": ref_gbs,
-                         "ref_flow_bytes_per_launch": ref[dom] / launches},
+                         "launches": launches,
+                         "note": "achieved = bytes the dominant kernel's data flow must move (32 B per line record, 4 B "
+                                 "per accumulated bin, its partial records) / its measured time (HIP events on its own "
+                                 "stream).  bmin_frac / balg_frac = the whole spectrum against SURVEY 8(d)'s layer-fused "
+                                 "minimum / reference-flow byte counts.  The walk is not bandwidth bound: it is bound "
+                                 "by instruction issue (vector + scalar, ~75-200 per line and step; counters in "
+                                 "profiles/), see DESIGN.md section 4"},
         }
-        if dom == "k_group_sweep" and kern[dom] > 0:
-            # 110 wave instructions per line-layer (SQ_INSTS_VALU x 64 / line-layers), 4 cycles each
-            # on a 16-lane SIMD, 1024 SIMDs at 2.4 GHz
-            out["roofline"]["valu_issue_frac_est"] = (110.0 * L * R / 64.0) / (kern[dom] * 1e-3) / (1024 * 2.4e9 / 4.0)
+        out["config"].update(extras)
         if dom == "k_accumulate" and ach > HBM_PEAK_GBS:
             # wide-profile regime (fine grids): neighbouring lines re-read the same profile rows, which
             # therefore come out of L1/L2 -- the 4 B per accumulated bin never reach HBM and an HBM
@@ -327,6 +387,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, full)
+                if extras.get("ms_cli_wall") and out["cpu_baseline"].get("seconds_wall"):
+                    out["config"]["cli_wall_speedup_vs_reference"] = 1e3 * out["cpu_baseline"]["seconds_wall"] / extras["ms_cli_wall"]
             except Exception as e:          # the baseline must never sink the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -209,6 +209,9 @@ typedef struct {
   double  ms_spectrum;    /* intensity/flux or modulation                      */
   int64_t ncandidates;    /* lines that can be a layer's strongest line (the others are
                              dominated, trx_walk.hip.h); -1: every line is looked at */
+  int64_t walk_steps;     /* steps of the last run taken by the one-kernel line walk (the
+                             rest, sweep_launches - walk_steps, took the two-kernel form)  */
+  int64_t walk_records;   /* partial-sum records (64 doubles each) those steps wrote      */
 } trx_stats;
 
 typedef struct trx_handle trx_handle;

@@ -33,13 +33,13 @@ def test_bench_multirank_code_path_rehearsal():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "2", "--rehearse", "--lines", "30000", "--layers", "40",
-           "--wnhigh", "2700"]
+           "--gpus", "2", "--steps", "3", "--warmup", "2", "--rehearse", "--no-extras", "--lines", "30000",
+           "--layers", "40", "--wnhigh", "2700"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["n_wn"] == 401 and out["config"]["n_lines"] == 60000      # band and lines x2
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0      # the one run, split two ways
+    assert out["config"]["n_wn"] == 201 and out["config"]["n_lines"] == 30000
     assert {"roofline", "metric", "unit", "ms_per_step"} <= set(out)

@@ -122,6 +122,19 @@ void log_msg(int level, const std::string &msg)
   if (s.fn && level <= s.max_level) s.fn(level, msg.c_str(), s.user);
 }
 
+// stage timer of trx_create: logs "create: <stage> x.xx ms" at TRX_LOG_DEBUG
+struct StageTimer {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    const auto n = std::chrono::steady_clock::now();
+    if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
+      char b[128]; std::snprintf(b, sizeof b, "create: %-28s %8.2f ms", what, std::chrono::duration<double, std::milli>(n - t).count());
+      log_msg(TRX_LOG_DEBUG, b);
+    }
+    t = n;
+  }
+};
+
 int fail(trx_handle *h, int code, const std::string &msg)
 { if (h) h->err = msg; log_msg(TRX_LOG_ERROR, msg); return code; }
 
@@ -155,6 +168,15 @@ int ensure_small(trx_handle *h, int nlay)
     HIPCHK(h, hipHostMalloc(&h->h_small, bytes, hipHostMallocDefault));
     h->h_small_bytes = bytes;
   }
+  return TRX_OK;
+}
+
+template <class T>
+int upload_raw(trx_handle *h, DevBuf &b, const T *p, size_t n)
+{
+  int rc = ensure(h, b, n * sizeof(T));
+  if (rc) return rc;
+  if (n) HIPCHK(h, hipMemcpyAsync(b.p, p, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
   return TRX_OK;
 }
 
@@ -324,6 +346,7 @@ int build_table(trx_handle *h, const trx_static *s)
 int prepare_lines(trx_handle *h, const trx_static *s)
 {
   const int64_t n = s->nlines;
+  StageTimer T;
   const double wn0 = s->wn_i, odwn = s->wn_d / s->osamp;
   const double own_last = wn0 + (double)(s->nown - 1) * odwn;
   auto own = [&](long long k) { return wn0 + (double)k * odwn; };
@@ -336,6 +359,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     inr[i] = !(wavn[i] < wn0 || wavn[i] > own_last);             // extinction.c:410
     h->ninrange += inr[i];
   }
+  T.lap("wavn + range flags");
   // TLI order: isotope blocks in ascending id, wavelength ascending inside a
   // block (pylineread.py:369-383); the gather kernel relies on it.
   for (int64_t i = 1; i < n; i++) {
@@ -343,7 +367,10 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     if (s->isoid[i] == s->isoid[i-1] && wavn[i] > wavn[i-1])
       return fail(h, TRX_E_ORDER, "wavelengths are not ascending inside an isotope block");
   }
+  T.lap("order check");
   std::vector<int32_t> gfirst, gcount, giown; std::vector<int16_t> giso; std::vector<double> gwavn;
+  gfirst.reserve((size_t)h->ninrange); gcount.reserve((size_t)h->ninrange); giown.reserve((size_t)h->ninrange);
+  giso.reserve((size_t)h->ninrange); gwavn.reserve((size_t)h->ninrange);
   h->iso_wmin.assign(s->niso, HUGE_VAL); h->iso_wmax.assign(s->niso, 0.0);
   for (int64_t ln = 0; ln < n; ln++) {
     if (!inr[ln]) continue;
@@ -359,6 +386,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     giown.push_back(iown); giso.push_back((int16_t)iso); gwavn.push_back(w);
     h->iso_wmin[iso] = std::min(h->iso_wmin[iso], w); h->iso_wmax[iso] = std::max(h->iso_wmax[iso], w);
   }
+  T.lap("grouping");
   h->nlines = n; h->ngroups = (int64_t)gfirst.size();
   // isotope blocks and the coarse-bin index over them
   std::vector<int32_t> gblock(s->niso + 1, 0);
@@ -377,6 +405,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   for (size_t g = 1; g < giown.size(); g++)
     if (giso[g] == giso[g-1] && giown[g] > giown[g-1])
       return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
+  T.lap("cnt_ge");
   // the same counts at F sub-buckets per coarse cell (key iown*F/osamp): k_accumulate sizes its
   // windows with them, so that it does not stream whole cells of groups that lie between the
   // reach of two bins.  F = 1 (the table above) when the fine grid is no finer or the table
@@ -405,22 +434,13 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   for (size_t g = 0; g < gfirst.size(); g++) lgroup[(size_t)gfirst[g]] = (int32_t)g;
   std::vector<int32_t> gimod(giown.size()), gidiv(giown.size());
   for (size_t g = 0; g < giown.size(); g++) { gimod[g] = giown[g] % s->osamp; gidiv[g] = giown[g] / s->osamp; }
-  std::vector<double> elow(s->elow, s->elow + n), gf(s->gf, s->gf + n);
-  std::vector<int16_t> iso(s->isoid, s->isoid + n);
+  T.lap("cnt_sub, lgroup, gimod");
+  const double *elow = s->elow, *gf = s->gf;
   int rc;
   // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
   // ranges of ngw consecutive groups per isotope block
   h->walk_ok = s->osamp < (1 << 27) && h->tab_n < ((int64_t)1 << 30) && !gfirst.empty();
-  std::vector<WalkLine> walk;
   if (h->walk_ok) {
-    walk.resize((size_t)n + 1);                    // + one record of padding (the walk reads one line ahead)
-    for (int64_t i = 0; i < n; i++) { walk[i].wavn = wavn[i]; walk[i].elow = elow[i]; walk[i].gf = gf[i]; walk[i].meta = 0; walk[i].cell = 0; }
-    walk[(size_t)n] = WalkLine{0.0, 0.0, 0.0, 0, 0};
-    for (size_t g = 0; g < gfirst.size(); g++) {
-      WalkLine &a = walk[(size_t)gfirst[g]];
-      a.meta |= 1 | (gimod[g] << 3); a.cell = gidiv[g];
-      walk[(size_t)gfirst[g] + gcount[g] - 1].meta |= 2;
-    }
     int ngw = 32;
     if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
     else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 8192) ngw *= 2;
@@ -428,33 +448,31 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     h->h_wbase.assign(s->niso + 1, 0);
     for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
     h->nwaves = h->h_wbase[s->niso];
-    // base points of the rebased exponential (meta bit 2): a range's first line, then every
-    // line more than kRebaseSpan below the last base point
-    for (int b = 0; b < s->niso; b++)
-      for (int g0 = gblock[b]; g0 < gblock[b + 1]; g0 += ngw) {
-        const int g1 = std::min(g0 + ngw, gblock[b + 1]);
-        const int64_t l0 = gfirst[g0], l1 = (int64_t)gfirst[g1 - 1] + gcount[g1 - 1];
-        double w0 = HUGE_VAL;
-        for (int64_t l = l0; l < l1; l++)
-          if (l == l0 || w0 - walk[l].wavn > kRebaseSpan) { walk[l].meta |= 4; w0 = walk[l].wavn; }
-      }
-    if ((rc = upload(h, h->d_walk, walk)) || (rc = upload(h, h->d_wbase, h->h_wbase))) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));    // `walk` dies here
+    if ((rc = upload(h, h->d_wbase, h->h_wbase))) return rc;
   }
-  if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_elow, elow)) || (rc = upload(h, h->d_gf, gf)) ||
-      (rc = upload(h, h->d_iso, iso)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
+  if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload_raw(h, h->d_elow, elow, (size_t)n)) || (rc = upload_raw(h, h->d_gf, gf, (size_t)n)) ||
+      (rc = upload_raw(h, h->d_iso, s->isoid, (size_t)n)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
       (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
       (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gimod, gimod)) || (rc = upload(h, h->d_gidiv, gidiv)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)) ||
       (rc = upload(h, h->d_cntsub, cntsub)))
     return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
+  T.lap("17 uploads + sync");
   h->h_gwavn = gwavn; h->h_gblock = gblock; h->h_cntge = cntge; h->h_gfirst = gfirst; h->h_gcount = gcount;
+  T.lap("host copies");
   LinesDev &L = h->L;
   L.nlines = n; L.wavn = h->d_wavn.as<double>(); L.elow = h->d_elow.as<double>(); L.gf = h->d_gf.as<double>();
   L.iso = h->d_iso.as<int16_t>(); L.inrange = h->d_inr.as<uint8_t>(); L.lgroup = h->d_lgroup.as<int32_t>();
   L.ngroups = h->ngroups; L.gfirst = h->d_gfirst.as<int32_t>(); L.gcount = h->d_gcount.as<int32_t>();
   L.giown = h->d_giown.as<int32_t>(); L.giso = h->d_giso.as<int16_t>(); L.gwavn = h->d_gwavn.as<double>();
   L.gblock = h->d_gblock.as<int32_t>(); L.cnt_ge = h->d_cntge.as<int32_t>();
+  if (h->walk_ok) {   // the walk's records (trx_walk.hip.h), built where the arrays already are
+    if ((rc = ensure(h, h->d_walk, sizeof(WalkLine) * ((size_t)n + 1)))) return rc;
+    hipLaunchKernelGGL(k_walk_records, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, h->stream, (long long)n, L.wavn, L.elow, L.gf,
+                       L.lgroup, L.giown, s->osamp, h->d_walk.as<WalkLine>());
+    hipLaunchKernelGGL(k_walk_marks, dim3((unsigned)((h->nwaves + 63) / 64)), dim3(64), 0, h->stream, h->nwaves, h->ngw, s->niso,
+                       h->d_wbase.as<int32_t>(), L.gblock, L.gfirst, L.gcount, h->d_walk.as<WalkLine>());
+  }
   h->stats.nlines_inrange = h->ninrange; h->stats.ngroups = h->ngroups; h->stats.nadd = h->nadd;
   // ---- candidates for the layer maximum: lines no other line of their isotope dominates
   // (trx_walk.hip.h).  Falls back to "every line" when the filter would not pay.
@@ -483,6 +501,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     if (nc > 0 && nc <= cap) h->ncand = nc;
   }
   h->stats.ncandidates = h->ncand;
+  T.lap("candidates");
   return TRX_OK;
 }
 
@@ -775,6 +794,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   int rc = walk_plan(h, nb, st, P, pl);
   if (rc) return rc;
   DevBuf &part = h->d_part[parity & 1];
+  h->stats.walk_steps++; h->stats.walk_records += pl->records;
   const size_t pbytes = sizeof(double) * kWalkLayers * (size_t)std::max<int64_t>(pl->records, 1);
   if (part.bytes < pbytes) {
     HIPCHK(h, hipStreamSynchronize(st));                 // an earlier step may still be using the old buffer
@@ -1093,7 +1113,9 @@ int trx_create(const trx_static *s, trx_handle **out)
   // the handle does not survive a failed create, so its error text cannot be asked for later:
   // without a message callback it goes to stderr
   auto say = [&]() { if (!log_sink().fn) std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); };
+  StageTimer TC;
   if ((rc = build_table(h, s)) != TRX_OK) { *out = nullptr; say(); return bail(rc); }
+  TC.lap("Voigt table (plan+kernels+sync)");
   if ((rc = prepare_lines(h, s)) != TRX_OK) { say(); return bail(rc); }
   {
     char buf[256];
@@ -1376,6 +1398,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventCreate(&ev.a)); HIPCHK(h, hipEventCreate(&ev.b));
   HIPCHK(h, hipEventRecord(ev.a, st));
 
+  h->stats.walk_steps = 0; h->stats.walk_records = 0;
   // ---- top-down sweep in steps of layers (tau.c:235-290) ----
   int nchunks = 0, nwalks = 0, r_top = nr - 1;
   bool stop_at_hint = stop_at_hint_ok, resumed = false;

@@ -257,6 +257,41 @@ constexpr int kWalkLayers = 64;      // layers per step = lanes
 constexpr double kRebaseSpan = 0.03125;     // cm-1
 constexpr double kWalkMinTemp = 1.4387752 * kRebaseSpan * 256.0 * 1.05;
 
+// trx_create builds the records on the device from the line and group arrays it has just uploaded
+__global__ __launch_bounds__(256)
+void k_walk_records(long long n, const double *__restrict__ wavn, const double *__restrict__ elow, const double *__restrict__ gf,
+                    const int32_t *__restrict__ lgroup, const int32_t *__restrict__ giown, int osamp, WalkLine *__restrict__ out)
+{
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  WalkLine R{0.0, 0.0, 0.0, 0, 0};                         // i == n: the padding record
+  if (i < n) {
+    R.wavn = wavn[i]; R.elow = elow[i]; R.gf = gf[i];
+    const int g = lgroup[i];
+    if (g >= 0) { const int io = giown[g]; R.meta = 1 | ((io % osamp) << 3); R.cell = io / osamp; }
+  }
+  out[i] = R;
+}
+
+// one lane per line range: last members of the groups, base points of the rebased exponential
+__global__ __launch_bounds__(64)
+void k_walk_marks(int nwaves, int ngw, int niso, const int32_t *__restrict__ wbase, const int32_t *__restrict__ gblock,
+                  const int32_t *__restrict__ gfirst, const int32_t *__restrict__ gcount, WalkLine *__restrict__ out)
+{
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= nwaves) return;
+  int b = 0;
+  while (b + 1 < niso && w >= wbase[b + 1]) b++;
+  const int g0 = gblock[b] + (w - wbase[b]) * ngw, g1 = min(g0 + ngw, gblock[b + 1]);
+  for (int g = g0; g < g1; g++) out[gfirst[g] + gcount[g] - 1].meta |= 2;
+  const int l0 = gfirst[g0], l1 = gfirst[g1 - 1] + gcount[g1 - 1];
+  double w0 = HUGE_VAL;
+  for (int l = l0; l < l1; l++) {
+    const double wv = out[l].wavn;
+    if (l == l0 || w0 - wv > kRebaseSpan) { out[l].meta |= 4; w0 = wv; }
+  }
+}
+
 struct WalkArgs {
   const WalkLine *lines;
   const int32_t *gfirst, *gcount, *gblock;
