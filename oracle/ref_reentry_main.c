@@ -8,16 +8,19 @@
  * contains no reference code.  Usage:
  *     transit_reentry <cfg> <inputs.txt> <out_prefix>
  * inputs.txt: one run per line, (1+nmol)*nlayer numbers: T(nlayer), q_0(nlayer), ...
- * Writes <out_prefix><k>.dat with one flux/modulation value per line (%.17g).
+ * Writes <out_prefix><k>.dat with one flux/modulation value per line (%.17g) and
+ * <out_prefix><k>_radii.dat: per layer the reference's radius sampling after the reload
+ * (tr->rads.v, the output of radpress + makeradsample, readatm.c:787-865, makesample.c:409-549)
+ * at %.17g, so that the host side's restatement of radpress can be checked bit for bit.  (The
+ * impact parameters are these radii reversed, makesample.c:563-572, and are freed again at the
+ * end of every run, transit.c:203.)
+ * The reference's headers are included from where they lie (oracle/Makefile passes -I); the
+ * only thing read through them is the global `struct transit transit` (transit.h:36).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-
-void transit_init(int argc, char **argv);
-int  get_no_samples(void);
-void run_transit(double *re_input, int transint, double *transit_out, int transit_out_size);
-void free_memory(void);
+#include <transit.h>
 
 int main(int argc, char **argv)
 {
@@ -47,6 +50,11 @@ int main(int argc, char **argv)
     snprintf(name, sizeof name, "%s%d.dat", argv[3], ++run);
     FILE *o = fopen(name, "w");
     for (int i = 0; i < nwn; i++) fprintf(o, "%.17g\n", out[i]);
+    fclose(o);
+    snprintf(name, sizeof name, "%s%d_radii.dat", argv[3], run);
+    o = fopen(name, "w");
+    fprintf(o, "# rads.v  (rads.fct %.17g)\n", transit.rads.fct);
+    for (long i = 0; i < transit.rads.n; i++) fprintf(o, "%.17g\n", transit.rads.v[i]);
     fclose(o);
     free(v);
   }

@@ -899,6 +899,14 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
    * tau.c:92-104 and makesample.c:564-574 (ips = reversed radii) */
   for (long i = 0; i < nr; i++) hh[i] = rad[nr-1-i];
   const double rfct = a->rad_fct, hfct = a->rad_fct;
+  /* The impact parameter handed to the ray solution, tau.c:274 `h[ri]*hfct/rfct`, as the
+   * reference is BUILT (its Makefile's -ffast-math lets gcc hoist the reciprocal out of the
+   * loop: the object code multiplies h*hfct by a stored 1.0/rfct; checked in the disassembly
+   * of oracle/_ref/obj/tr_tau.o).  The result is the layer radius or an ulp above it; a true
+   * division instead puts it an ulp BELOW for some hydrostatic radii, and the slant-path bracket
+   * search (slantpath.c:36) then starts one layer lower -- a 1e-3 effect the reference does not
+   * have (tests/test_reentry.py). */
+  const double rfct_recip = 1.0 / rfct;
 
 #define SWEEP(L) do { \
     for (int m_ = 0; m_ < nmol; m_++) dens[m_] = a->density[m_*nr + (L)]; \
@@ -946,7 +954,7 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
           }
         } while (hh[ri]*hfct < rad[lastr]*rfct);
       }
-      const double bb = hh[ri]*hfct/rfct;
+      const double bb = (hh[ri]*hfct) * rfct_recip;
       const double t = (o->solution == TRX_SOL_ECLIPSE) ? tau_vertical(rad, nr, bb, er)
                                                         : tau_slant(rad, nr, bb, er);
       tw[ri] = rfct * t;

@@ -35,13 +35,44 @@ def test_oracle_follows_the_reference_through_three_reloads():
         assert rel_err(got, ref) < 1e-9
 
 
-def test_transit_geometry_reloads_within_the_reference_own_noise():
-    """Transmission geometry after radpress(): see the note in make_golden.py.  The
-    oracle reproduces the reference's bracket search; the remaining difference is the
-    last-bit difference of the hydrostatic radii (the reference is built with
-    -ffast-math) flipping that search for some layers."""
+def test_hydrostatic_radii_are_the_reference_s_bit_for_bit():
+    """radpress (readatm.c:787-865) + makeradsample: the radii after every reload, against the
+    reference's own rads.v dumped at %.17g by oracle/ref_reentry_main.c."""
+    for case in (CASE, CASE_T):
+        P = Problem.from_cfg(os.path.join(case, "case.cfg"))
+        for k, vec in enumerate(INPUTS):
+            P.reload_atm(vec)
+            ref = np.loadtxt(os.path.join(case, "reentry_out%d_radii.dat" % (k + 1)))
+            assert np.array_equal(P.layer_arrays()["radius"], ref), (case, k)
+
+
+def test_transit_geometry_reloads_follow_the_reference():
+    """Transmission geometry after radpress().  The impact parameter the reference hands to its
+    ray solution is h*hfct/rfct (tau.c:274), which its object code -- built with -ffast-math --
+    evaluates as (h*hfct)*(1/rfct).  With that arithmetic the restatement follows the reference
+    to round-off.  (Evaluated as a true division, as the restatement did at first, two of the
+    twenty hydrostatic radii come out an ulp BELOW the layer radius, the slant-path bracket
+    search, slantpath.c:36, starts a layer lower for them and the Simpson pairing of the whole ray
+    shifts: the 2e-3 this test used to allow was the restatement's, not the reference's.)"""
     for got, ref in zip(run_sequence(ol.OracleEngine, CASE_T), EXPECT_T):
-        assert rel_err(got, ref) < 2e-3
+        assert rel_err(got, ref) < 1e-9
+
+
+def test_the_form_of_the_impact_parameter_decides_the_brackets():
+    """The mechanism, isolated on the reference's own radii: the reciprocal form lands on the
+    radius or an ulp above it (same bracket, closest approach an ulp higher: a 1e-10 effect);
+    the division form lands an ulp below for some hydrostatic radii (bracket one layer lower:
+    a 1e-3 effect on those rays).  File radii (short decimals) survive both forms' brackets."""
+    fct = 1e5
+    for k in (1, 2, 3):
+        ref = np.loadtxt(os.path.join(CASE_T, "reentry_out%d_radii.dat" % k))
+        recip, div = (ref * fct) * (1.0 / fct), (ref * fct) / fct
+        assert np.count_nonzero(recip < ref) == 0 and np.count_nonzero(recip > ref) > 0
+        if k == 1:
+            assert np.count_nonzero(div < ref) > 0
+    for case in ("transit_small", "cloud_scatter", "transit_modm1", "midres_os4", "dumps_transit"):
+        g = Problem.from_cfg(os.path.join(GOLDEN, case, "case.cfg")).layer_arrays()["radius"]
+        assert np.count_nonzero((g * fct) * (1.0 / fct) < g) == 0 and np.array_equal((g * fct) / fct, g)
 
 
 def test_reload_needs_reference_level_options(tmp_path):
@@ -65,10 +96,10 @@ def test_gpu_follows_the_reference_through_three_reloads():
     for got, ora, ref in zip(gpu, cpu, EXPECT):
         assert rel_err(got, ref) < 1e-9
         assert rel_err(got, ora) < 1e-10
-    # transmission geometry: the GPU evaluates each ray at the layer radius itself (the
-    # intended algorithm); the reference's own answer is noisy at the 1e-4 level here
-    for got, ref in zip(run_sequence(Engine, CASE_T), EXPECT_T):
-        assert rel_err(got, ref) < 2e-3
+    # transmission geometry: same impact parameters, brackets and point sets as the reference
+    for got, ora, ref in zip(run_sequence(Engine, CASE_T), run_sequence(ol.OracleEngine, CASE_T), EXPECT_T):
+        assert rel_err(got, ref) < 1e-8
+        assert rel_err(got, ora) < 1e-8
 
 
 @pytest.mark.gpu

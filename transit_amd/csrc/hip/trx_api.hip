@@ -1242,28 +1242,46 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
   const int gstride = 4 * (nr / 2 + 1);
-  std::vector<double> geom((size_t)(nr + 1) * gstride * 2 + 2 * (size_t)(nr + 1) + 4 * (size_t)nr, 0.0);
+  std::vector<double> geom((size_t)(nr + 1) * gstride * 2 + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr, 0.0);
   double *gw = &geom[0], *gh0 = gw + (size_t)(nr + 1) * gstride;
   double *mw = gh0 + (nr + 1), *mh0 = mw + (size_t)(nr + 1) * gstride;
   double *pw = mh0 + (nr + 1);            // pair weights by starting layer (vertical rays)
+  double *hrs = pw + 4 * (size_t)nr, *hr0 = hrs + nr;     // slant rays: bracket layer and closest approach per height
   {
-    std::vector<double> sx(nr + 1);
-    for (int rs = 0; rs < nr - 1; rs++) {
-      int n = nr - rs;
-      const double *rad = a->radius + rs;
-      double r3[3];
-      if (n == 2) { r3[0] = rad[0]; r3[2] = rad[1]; r3[1] = (rad[0] + rad[1]) / 2.0; rad = r3; n = 3; }
+    std::vector<double> sx(nr + 1), rr(nr + 1);
+    if (o->solution == TRX_SOL_ECLIPSE) {
+      // only the two-point ray (start layer nr-2) integrates with tabulated weights (eclipse.c:68-80);
+      // all others run on the pair weights below
+      const int rs = nr - 2;
+      const double r3[3] = {a->radius[rs], (a->radius[rs] + a->radius[rs+1]) / 2.0, a->radius[rs+1]};
       sx[0] = 0.0;
-      if (o->solution == TRX_SOL_ECLIPSE) for (int i = 1; i < n; i++) sx[i] = sx[i-1] + (rad[i] - rad[i-1]);
-      else { const double r0 = rad[0]; for (int i = 1; i < n; i++) sx[i] = std::sqrt(rad[i] * rad[i] - r0 * r0); }
-      simpson_weights(sx.data(), n, gw + (size_t)rs * gstride, gh0 + rs);
-    }
-    for (int k = 0; k + 2 < nr; k++) { double h0; simpson_weights(a->radius + k, 3, pw + 4 * (size_t)k, &h0); }
-    if (o->solution == TRX_SOL_TRANSIT)                       // slantpath.c:399-408, per point count
-      for (int cnt = 3; cnt <= nr; cnt++) {
+      for (int i = 1; i < 3; i++) sx[i] = sx[i-1] + (r3[i] - r3[i-1]);
+      simpson_weights(sx.data(), 3, gw + (size_t)rs * gstride, gh0 + rs);
+      for (int k = 0; k + 2 < nr; k++) { double h0; simpson_weights(a->radius + k, 3, pw + 4 * (size_t)k, &h0); }
+    } else {
+      // impact parameter of every height as the reference's object code computes it
+      // (tau.c:274 under -ffast-math: the reciprocal of rfct is hoisted out of the loop)
+      const double fct = a->rad_fct, recip = 1.0 / fct;
+      for (int k = 0; k < nr; k++) {
+        const double b = (a->radius[k] * fct) * recip;
+        const int rs = bracket_ie(a->radius, 0, nr - 1, b);          // slantpath.c:36
+        hr0[k] = b;
+        if (rs == -5 || rs == -2) { hrs[k] = -1; continue; }         // :37-38
+        if (rs < 0) { hrs[k] = -3; continue; }                       // :39-44
+        hrs[k] = rs;
+        int n = nr - rs;
+        rr[0] = b;
+        for (int i = 1; i < n; i++) rr[i] = a->radius[rs + i];
+        if (n == 2) { rr[2] = rr[1]; rr[1] = (rr[0] + rr[2]) / 2.0; n = 3; }   // :62-74
+        sx[0] = 0.0;
+        for (int i = 1; i < n; i++) sx[i] = std::sqrt(rr[i] * rr[i] - b * b);  // :82-84
+        simpson_weights(sx.data(), n, gw + (size_t)k * gstride, gh0 + k);
+      }
+      for (int cnt = 3; cnt <= nr; cnt++) {                          // slantpath.c:399-408, per point count
         for (int q = 0; q < cnt; q++) sx[q] = a->radius[nr - 1 - (cnt - 1 - q)] * a->rad_fct;
         simpson_weights(sx.data(), cnt, mw + (size_t)cnt * gstride, mh0 + cnt);
       }
+    }
   }
   std::vector<double> ipv(nr);
   for (int i = 0; i < nr; i++) ipv[i] = a->radius[nr - 1 - i];
@@ -1489,6 +1507,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
       T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
       T.pw = d_pw; T.acc = h->d_acc.as<double>();
+      T.hrs = d_pw + 4 * (size_t)nr; T.hr0 = T.hrs + nr; T.status = h->d_status.as<int>();
       if (o->solution == TRX_SOL_ECLIPSE) {
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
         const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
@@ -1593,6 +1612,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
   if (status_host[0] == 1) return fail(h, TRX_E_NOTREACHED, "optical depth never reached toomuch (modlevel -1)");
   if (status_host[0] == 2) return fail(h, TRX_E_ARG, "fewer than three points for the radial integration");
+  if (status_host[0] == 3) return fail(h, TRX_E_RANGE, "closest approach of a ray lies below the bottom layer (slantpath.c:39-44)");
   return TRX_OK;
 }
 

@@ -940,6 +940,15 @@ struct TauArgs {
   // Simpson sums of both parities carried from chunk to chunk
   const double *pw;                  // [nr][4]
   double *acc;                       // [2][nsh]
+  // slant rays only.  The reference hands its ray solution b = h*hfct/rfct (tau.c:274), which its
+  // object code evaluates as (h*hfct)*(1/rfct): b comes out on the layer radius it was made from
+  // or an ulp beside it, and the bracket search (slantpath.c:36) then integrates from b instead of
+  // the radius (b high) or starts at the layer below (b low; not seen with fct = 1e5, handled).
+  // Per height k (layer index of the height): hrs = lowest layer of the bracket (-1: optical depth
+  // 0, -3: closest approach below the bottom layer), hr0 = b; the Simpson weights gw/gh0 are then
+  // those of the point set {b, rad[hrs+1], ...} and are indexed by k.
+  const double *hrs, *hr0;
+  int *status;
 };
 
 // (out of line: a dozen inlined pow() bodies per call site would push the optical-depth
@@ -1029,6 +1038,7 @@ void k_optical_depth(TauArgs T)
   __shared__ int s_alive[kTauW];
   const int wi = threadIdx.x % kTauW, hc = threadIdx.x / kTauW;
   const int nr = T.nr;
+  const int r_low = T.r_top - T.nc + 1;                  // lowest layer whose extinction exists so far
   const long long ntiles = (T.nsh + kTauW - 1) / kTauW;
   int nstill = 0, deep = 0;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1045,18 +1055,23 @@ void k_optical_depth(TauArgs T)
         const long long k = (long long)r * T.nsh + w;
         T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
       }
+      // extinction at the closest-approach radius of every height (slantpath.c:55-58).  The
+      // bracket's lowest layer rs is the height's own layer, or -- when the impact parameter came
+      // out an ulp below the layer radius (TauArgs.hrs) -- the layer under it.  That one may lie
+      // below this step: the reference, sweeping lazily, has no line extinction there yet either
+      // (tau.c:231-232 with an unswept row), and its weight in the parabola is ~1e-14.
       for (int c = 0; c < T.nc; c++) {
-        const int rs = T.r_top - c;
+        const int k = T.r_top - c;
+        const int rs = (int)T.hrs[k];
+        if (rs < 0) { s_y0[c][wi] = 0.0; continue; }
         const int n = nr - rs;
-        if (n < 2) { s_y0[c][wi] = 0.0; continue; }
+        const double r0 = T.hr0[k];
         const double *y = T.er + (long long)rs * T.nsh + w;
+        const double ylow = rs >= r_low ? y[0]
+                                        : scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[(long long)rs * T.nsh + w];
         double y0;
-        if (n == 2) {                                     // eclipse.c:65, restored at :75-76
-          y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], y[0], y[T.nsh], T.rad[rs]);
-        } else {
-          y0 = parab3(T.rad[rs], T.rad[rs+1], y[0], y[T.nsh], y[2*T.nsh], T.rad[rs]);
-          if (T.solution == 0) T.er[(long long)rs * T.nsh + w] = y0;    // not restored: eclipse.c:66
-        }
+        if (n == 2) y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], ylow, y[T.nsh], r0);
+        else        y0 = parab3(T.rad[rs], T.rad[rs+1], ylow, y[T.nsh], y[2*T.nsh], r0);
         s_y0[c][wi] = y0;
       }
     }
@@ -1065,17 +1080,20 @@ void k_optical_depth(TauArgs T)
 
   if (hc < T.nc && s_alive[wi]) {
     const int c = hc;
-    const int rs = T.r_top - c;
+    const int k = T.r_top - c;
+    const int rs = (int)T.hrs[k];
     double t;
-    if (rs == nr - 1) {
-      t = 0.0;                                            // eclipse.c:45-46, slantpath.c:37-38
+    if (rs == -1) {
+      t = 0.0;                                            // slantpath.c:37-38: the outermost layer
+    } else if (rs < 0) {
+      t = nan(""); *T.status = 3;                         // slantpath.c:39-44: the reference exits here
     } else {
       const int n = nr - rs;
       const double *y = T.er + (long long)rs * T.nsh + w;           // y[j*nsh] = er[rs+j][w]
-      const double *g = T.gw + (long long)rs * T.gstride;
+      const double *g = T.gw + (long long)k * T.gstride;            // weights of THIS height's point set
       const double y0 = s_y0[c][wi];
       double res;
-      if (n == 2) {                                       // eclipse.c:68-80, slantpath.c:62-74
+      if (n == 2) {                                       // slantpath.c:62-74
         const double y2 = y[T.nsh];
         const double y1 = (y2 + y0) / 2.0;
         res = ((y0 * g[0] + y1 * g[1] + y2 * g[2]) * g[3]) / 6.0;
@@ -1090,9 +1108,9 @@ void k_optical_depth(TauArgs T)
           acc += (ya * g[4*i] + yb * g[4*i+1] + yc * g[4*i+2]) * g[4*i+3];
         }
         res = acc / 6.0;
-        if (even) res += T.gh0[rs] * (y0 + y[T.nsh]) / 2;
+        if (even) res += T.gh0[k] * (y0 + y[T.nsh]) / 2;
       }
-      t = (T.solution == 0) ? res : 2 * res;
+      t = 2 * res;                                        // slantpath.c:107
     }
     s_tv[c][wi] = T.rad_fct * t;
   }
