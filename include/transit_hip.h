@@ -268,6 +268,8 @@ void trx_comm_destroy(void *comm);
  * per-layer maximum line strength, the only global quantity of the path (extinction.c:399-427),
  * is computed by every rank from the same small set of candidate lines. */
 int  trx_gather(trx_handle *h, const void *d_slice, void *d_all, int64_t count);
+/* The same with host buffers on both sides (slice: count doubles; all: nranks * count). */
+int  trx_gather_host(trx_handle *h, const double *slice, double *all, int64_t count);
 
 const char *trx_strerror(int status);
 const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */

@@ -52,6 +52,9 @@ void    trh_wavenumbers(const trh_problem *p, double *out);  /* get_waveno_arr()
 
 /* restrict the static description to coarse bins [lo,hi) (one GPU's shard) */
 void trh_set_shard(trh_problem *p, int64_t lo, int64_t hi);
+/* Shards of a multi-GPU job: bins [bounds[k], bounds[k+1]) for rank k, cut so that every rank
+ * gets about the same work (lines to walk + rays to integrate), not the same number of bins. */
+int  trh_shard_bounds(const trh_problem *p, int nranks, int64_t *bounds /* [nranks + 1] */);
 
 /* BART-style re-entry (run_transit -> reloadatm, readatm.c:722-784):
  * input = [T(nlayer), q_0(nlayer), ..., q_{nmol-1}(nlayer)] */

@@ -148,3 +148,34 @@ def test_multi_database_tli_and_species_mapping():
     assert [species[i] for i in imol] == ["H2O", "H2O", "H2O", "CH4", "CH4", "CO"]
     z = P.layer_arrays()["zpart"]
     assert z.shape == (6, P.nlayer) and np.all(z > 0)
+
+
+def test_shard_bounds_balance_the_work_not_the_bins(tmp_path):
+    """trh_shard_bounds / shard.balanced_bounds: with a line list three times denser in
+    the upper half of the band the cuts move so that every rank gets the same work within 10 %."""
+    import ctypes as C
+    from transit_amd import host as H
+    from transit_amd.shard import balanced_bounds, bin_costs, all_bounds
+    d = str(tmp_path / "dense")
+    lo = synth.synth_linedb(20000, 2500, 2750, seed=3)
+    hi = synth.synth_linedb(60000, 2750, 3000, seed=4, name="HITEMP CO (synthetic)", molname="CO",
+                            iso_names=("26",), iso_masses=(27.994915,), iso_ratios=(0.98654,), iso_split=(1.0,), z_scale=107.0)
+    synth.make_case(d, wnlow=2500, wnhigh=3000, nlayers=30, solution="eclipse", dbs=[lo, hi])
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    cost = bin_costs(P.static, P.nlayer)
+    for world in (2, 3, 8):
+        b = balanced_bounds(cost, world)
+        assert b[0][0] == 0 and b[-1][1] == P.nwn and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        work = np.array([cost[l:h].sum() for l, h in b])
+        assert work.max() / work.mean() < 1.1
+        even = np.array([cost[l:h].sum() for l, h in all_bounds(P.nwn, world)])
+        assert even.max() / even.mean() > work.max() / work.mean()        # the equal-bins split is worse
+        # the C++ host side cuts at the same places
+        lib = H._load()
+        lib.trh_shard_bounds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        lib.trh_shard_bounds.restype = C.c_int
+        out = (C.c_int64 * (world + 1))()
+        assert lib.trh_shard_bounds(P._h, world, out) == 0
+        assert list(out) == [b[0][0]] + [h for _, h in b]
+    with pytest.raises(ValueError):
+        balanced_bounds(cost, P.nwn + 1)

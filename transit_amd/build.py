@@ -73,7 +73,7 @@ def build_cli(force: bool = False) -> str:
         return ""
     deps = [src, lib_path("libtransit_host.so"), lib_path("libtransit_hip.so")]
     if force or _newer(out, deps):
-        _run([CXX, "-O2", "-std=c++17", "-Wall", "-o", out, src, "-I", os.path.join(ROOT, "include"),
+        _run([CXX, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", out, src, "-I", os.path.join(ROOT, "include"),
               "-L", LIB, "-ltransit_host", "-ltransit_hip", "-Wl,-rpath,$ORIGIN"])
     return out
 

@@ -1030,6 +1030,23 @@ int trx_gather(trx_handle *h, const void *d_slice, void *d_all, int64_t count)
   return TRX_OK;
 }
 
+// trx_gather for callers that keep their slices in host memory (the command-line driver): the
+// slice goes to the device, is gathered there, and the whole comes back -- on every rank.
+int trx_gather_host(trx_handle *h, const double *slice, double *all, int64_t count)
+{
+  if (!h || !slice || !all || count < 0) return TRX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int nranks = h->comm ? h->nranks : 1;
+  DevBuf d_slice, d_all;
+  int rc;
+  if ((rc = ensure(h, d_slice, sizeof(double) * (size_t)std::max<int64_t>(count, 1))) ||
+      (rc = ensure(h, d_all, sizeof(double) * (size_t)std::max<int64_t>(count, 1) * nranks))) return rc;
+  HIPCHK(h, hipMemcpyAsync(d_slice.p, slice, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+  if ((rc = trx_gather(h, d_slice.p, d_all.p, count))) return rc;
+  HIPCHK(h, hipMemcpy(all, d_all.p, sizeof(double) * (size_t)count * nranks, hipMemcpyDeviceToHost));
+  return TRX_OK;
+}
+
 void trx_set_log(trx_log_fn fn, void *user, int max_level)
 {
   LogSink &s = log_sink();

@@ -14,6 +14,7 @@
 #include "../../../include/transit_host.h"
 #include "../trx_numerics.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -976,6 +977,32 @@ void trh_wavenumbers(const trh_problem *p, double *out)
 { if (p && out) for (int64_t k = 0; k < p->nwn; k++) out[k] = p->wn_i + (double)k * p->wn_d; }
 void trh_set_shard(trh_problem *p, int64_t lo, int64_t hi)
 { if (p) { p->st.wn_lo = lo; p->st.wn_hi = hi; } }
+
+// Contiguous split of the coarse bins into nranks shards of near-equal WORK (SURVEY section 8e:
+// balance by the work, not by the number of bins).  Work of a bin = its ray's optical depth and
+// spectrum (~ layers) + the lines whose cell it is (every line is walked once per step whatever
+// its bin); the two weights are the measured times of the demo-sized run.
+// The k-th cut goes where the running sum crosses k/nranks of the total, to the nearer side.
+int trh_shard_bounds(const trh_problem *p, int nranks, int64_t *bounds /* [nranks + 1] */)
+{
+  if (!p || !bounds || nranks < 1 || nranks > p->nwn) return TRX_E_ARG;
+  const int64_t nwn = p->nwn;
+  std::vector<double> run((size_t)nwn + 1, 0.0), c((size_t)nwn, 0.04 * (double)p->rad.size());
+  for (size_t i = 0; i < p->wl.size(); i++) {
+    const int64_t cell = (int64_t)std::floor((1e4 / p->wl[i] - p->wn_i) / p->wn_d + 0.5);
+    if (cell >= 0 && cell < nwn) c[(size_t)cell] += 3.4e-4;
+  }
+  for (int64_t j = 0; j < nwn; j++) run[(size_t)j + 1] = run[(size_t)j] + c[(size_t)j];
+  bounds[0] = 0; bounds[nranks] = nwn;
+  for (int k = 1; k < nranks; k++) {
+    const double target = run[(size_t)nwn] * k / nranks;
+    int64_t j = std::lower_bound(run.begin(), run.end(), target) - run.begin();      // run[j-1] < target <= run[j]
+    if (j > 0 && target - run[(size_t)j - 1] < run[(size_t)j] - target) j--;
+    j = std::min<int64_t>(std::max<int64_t>(j, bounds[k - 1] + 1), nwn - (nranks - k));
+    bounds[k] = j;
+  }
+  return TRX_OK;
+}
 
 int trh_reload_atm(trh_problem *p, const double *input, int n)
 {

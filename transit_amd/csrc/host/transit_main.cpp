@@ -1,24 +1,46 @@
 // transit_main.cpp -- `transit_hip`: command-line drop-in for the reference's
 // `transit` binary on the spectrum path (transit/src/transit.c:233-242):
 //
-//     transit_hip -c run.cfg [--option value ...]
+//     transit_hip -c run.cfg [--option value ...] [--gpus N]
 //
 // Same options, same cfg grammar, same TLI / atmosphere / CIA / molecule files
-// in, same spectrum (and toomuch) files out.  transit_init() -> trh_load(),
-// do_transit() -> trx_create() + trx_run() on the GPU, free_memory() ->
-// trx_destroy() + trh_free().
+// in, same spectrum (and toomuch, intensity, dump, detail, sampling) files out.
+// transit_init() -> trh_load(), do_transit() -> trx_create() + trx_run() on the GPU,
+// free_memory() -> trx_destroy() + trh_free().
+//
+// --gpus N (the one option the reference does not have): the wavenumber axis is cut into N
+// shards of equal work (trh_shard_bounds), one handle per shard, one host thread per handle,
+// one GPU per thread; the shards need nothing from each other while they run and the spectrum
+// slices are collected by ONE ncclAllGather at the end (trx_gather_host; the communicator is
+// made with trx_comm_unique_id / trx_comm_create).  With fewer than N devices the ranks share
+// devices and the slices are joined in host memory instead (RCCL refuses two ranks on one
+// device): same code path otherwise, for rehearsal.  Files are written once, by rank 0.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "transit_hip.h"
-#include <string>
 #include "transit_host.h"
 
 static double now_s()
 { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+namespace {
+
+struct Rank {
+  int rank = 0, device = 0;
+  trx_static st{};                   // this rank's copy: shard, device, communicator
+  trx_handle *h = nullptr;
+  int rc = TRX_OK; std::string err;
+  std::vector<double> slice, tau, e, ecs, intens; std::vector<int64_t> last;
+  trx_stats stats{};
+};
+
+}  // namespace
 
 int main(int argc, char **argv)
 {
@@ -26,7 +48,16 @@ int main(int argc, char **argv)
   trh_problem *P = nullptr;
   const double t_start = now_s();
   double t0 = t_start;
-  int rc = trh_load(argc, argv, &P, err, sizeof(err));
+  // --gpus N is ours: take it out before the reference's option table sees the line
+  int ngpus = 1;
+  std::vector<char *> args;
+  for (int i = 0; i < argc; i++) {
+    if (std::strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) { ngpus = std::atoi(argv[++i]); continue; }
+    if (std::strncmp(argv[i], "--gpus=", 7) == 0) { ngpus = std::atoi(argv[i] + 7); continue; }
+    args.push_back(argv[i]);
+  }
+  if (ngpus < 1) { std::fprintf(stderr, "transit_hip: --gpus needs a positive number\n"); return EXIT_FAILURE; }
+  int rc = trh_load((int)args.size(), args.data(), &P, err, sizeof(err));
   if (rc == 1) return EXIT_SUCCESS;                       // --help / --version (argum.c:582-607)
   if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: %s (%s)\n", err, trx_strerror(rc)); return EXIT_FAILURE; }
   const char *verb = trh_option(P, "verb");
@@ -39,19 +70,20 @@ int main(int argc, char **argv)
     }
   if (verblevel > 3) std::printf("Check point: 00 - 04 inputs read and sampled:  dt = %.4f sec.\n\n", now_s() - t0);
 
-  t0 = now_s();
-  trx_handle *h = nullptr;
-  rc = trx_create(trh_static(P), &h);
-  if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: trx_create failed: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE; }
-  if (verblevel > 3) std::printf("Check point: 00 - 05 opacity (Voigt table on device, line list resident):  dt = %.4f sec.\n\n", now_s() - t0);
+  const int64_t nwn = trh_nwn(P);
+  const int nr = trh_atm(P)->nlayer;
+  if (ngpus > nwn) { std::fprintf(stderr, "transit_hip: more GPUs than wavenumbers\n"); trh_free(P); return EXIT_FAILURE; }
 
-  // --opacityfile names a file that does not exist yet: build the grid on the GPU
+  // --opacityfile names a file that does not exist yet: build the grid on ONE GPU
   // (calcopacity, opacity.c:282-427), write it, and go on with it as the reference does
+  t0 = now_s();
   if (trh_needs_opacity_build(P)) {
-    t0 = now_s();
+    trx_handle *h = nullptr;
+    rc = trx_create(trh_static(P), &h);
+    if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: trx_create failed: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE; }
     int32_t nv = 0, nslot = 0; const double *gt, *gd, *gz; const int32_t *gs;
     trh_grid_request(P, &nv, &gt, &gd, &gz, &nslot, &gs);
-    std::vector<double> grid((size_t)nv * nslot * trh_nwn(P));
+    std::vector<double> grid((size_t)nv * nslot * nwn);
     rc = trx_sweep_permol(h, nv, gt, gd, gz, trh_opts(P)->ethresh, nslot, gs, grid.data());
     if (rc == TRX_OK) rc = trh_install_opacity(P, grid.data());
     if (rc != TRX_OK) {
@@ -59,42 +91,110 @@ int main(int argc, char **argv)
       trx_destroy(h); trh_free(P); return EXIT_FAILURE;
     }
     if (verblevel > 3) std::printf("Check point: 00 - 05 opacity grid (%d states x %d molecules):  dt = %.4f sec.\n\n", nv, nslot, now_s() - t0);
-    trx_destroy(h); h = nullptr;
-    rc = trx_create(trh_static(P), &h);          // same problem, now in grid mode
-    if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: trx_create failed: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE; }
+    trx_destroy(h);
   }
-  if (trh_option(P, "justOpacity")) { trx_destroy(h); trh_free(P); return EXIT_SUCCESS; }   // transit.c:133-136
+  if (trh_option(P, "justOpacity")) { trh_free(P); return EXIT_SUCCESS; }   // transit.c:133-136
 
-  const int64_t nwn = trh_nwn(P);
-  const int nr = trh_atm(P)->nlayer;
-  std::vector<double> spectrum((size_t)nwn), tau, e, ecs;
-  std::vector<int64_t> last;
-  trx_debug dbg{};
+  // ---- what the run has to hand back
   const bool want_toomuch = trh_option(P, "outtoomuch") != nullptr;
   const char *sf = trh_option(P, "savefiles");
   const bool want_dumps = sf && std::strncmp(sf, "yes", 3) == 0;                // argum.c:461-470
   const bool det_tau = trh_wants_detail(P, 0), det_ext = trh_wants_detail(P, 1), det_cia = trh_wants_detail(P, 2);
+  const bool want_intens = trh_option(P, "outintens") != nullptr && trh_opts(P)->solution == TRX_SOL_ECLIPSE;
+  const bool need_tau = want_toomuch || want_dumps || det_tau, need_e = want_dumps || det_ext, need_ecs = want_dumps || det_cia;
+  const int nang = trh_opts(P)->nangles;
   if (want_dumps && trh_write_sample(P, nullptr) != TRX_OK)                     // makesample.c:598-599
     std::fprintf(stderr, "transit_hip: cannot write the sampling file\n");
-  if (want_toomuch || want_dumps || det_tau) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); dbg.tau = tau.data(); dbg.last = last.data(); }
-  if (want_dumps || det_ext) { e.resize((size_t)nwn * nr); dbg.e = e.data(); }
-  if (want_dumps || det_cia) { ecs.resize((size_t)nwn * nr); dbg.e_cs = ecs.data(); }
-  std::vector<double> intens;
-  const bool want_intens = trh_option(P, "outintens") != nullptr && trh_opts(P)->solution == TRX_SOL_ECLIPSE;
-  if (want_intens) { intens.resize((size_t)nwn * trh_opts(P)->nangles); dbg.intens = intens.data(); }
+
+  // ---- shards, devices, communicator
+  std::vector<int64_t> bounds((size_t)ngpus + 1);
+  if (trh_shard_bounds(P, ngpus, bounds.data()) != TRX_OK) { std::fprintf(stderr, "transit_hip: cannot cut %d shards\n", ngpus); trh_free(P); return EXIT_FAILURE; }
+  const int ndev = trx_device_count();
+  const bool rccl = ngpus > 1 && ndev >= ngpus;
+  unsigned char comm_id[TRX_COMM_ID_BYTES];
+  if (rccl && (rc = trx_comm_unique_id(comm_id)) != TRX_OK) {
+    std::fprintf(stderr, "transit_hip: no RCCL communicator: %s\n", trx_strerror(rc)); trh_free(P); return EXIT_FAILURE;
+  }
+  if (ngpus > 1 && !rccl && verblevel >= 2)
+    std::fprintf(stderr, "transit_hip: note: %d ranks on %d device(s): devices are shared and the slices are joined in host memory\n", ngpus, ndev);
+  int64_t count = 0;                                       // slice length every rank contributes
+  for (int k = 0; k < ngpus; k++) count = std::max<int64_t>(count, bounds[k + 1] - bounds[k]);
 
   t0 = now_s();
-  rc = trx_run(h, trh_atm(P), trh_opts(P), spectrum.data(), (dbg.tau || dbg.e || dbg.e_cs || dbg.intens) ? &dbg : nullptr);
-  if (rc != TRX_OK) {
-    std::fprintf(stderr, "transit_hip: trx_run failed: %s (%s)\n", trx_strerror(rc), trx_last_error(h));
-    trx_destroy(h); trh_free(P); return EXIT_FAILURE;
+  std::vector<Rank> R((size_t)ngpus);
+  std::vector<double> gathered((size_t)count * ngpus);    // rank 0's copy of the gather
+  auto work = [&](int k) {
+    Rank &r = R[(size_t)k];
+    r.rank = k; r.device = ndev > 0 ? k % ndev : 0;
+    r.st = *trh_static(P);
+    r.st.wn_lo = bounds[k]; r.st.wn_hi = bounds[k + 1]; r.st.device = r.device;
+    r.st.comm = nullptr; r.st.nranks = 1; r.st.rank = 0;
+    if (rccl) {
+      void *c = nullptr;
+      if ((r.rc = trx_comm_create(comm_id, ngpus, k, r.device, &c)) != TRX_OK) { r.err = "trx_comm_create"; return; }
+      r.st.comm = c; r.st.nranks = ngpus; r.st.rank = k;
+    }
+    if ((r.rc = trx_create(&r.st, &r.h)) != TRX_OK) { r.err = "trx_create"; return; }
+    const int64_t n = bounds[k + 1] - bounds[k];
+    r.slice.assign((size_t)count, 0.0);
+    trx_debug dbg{};
+    if (need_tau) { r.tau.resize((size_t)n * nr); r.last.resize((size_t)n); dbg.tau = r.tau.data(); dbg.last = r.last.data(); }
+    if (need_e) { r.e.resize((size_t)n * nr); dbg.e = r.e.data(); }
+    if (need_ecs) { r.ecs.resize((size_t)n * nr); dbg.e_cs = r.ecs.data(); }
+    if (want_intens) { r.intens.resize((size_t)n * nang); dbg.intens = r.intens.data(); }
+    r.rc = trx_run(r.h, trh_atm(P), trh_opts(P), r.slice.data(), (dbg.tau || dbg.e || dbg.e_cs || dbg.intens) ? &dbg : nullptr);
+    if (r.rc != TRX_OK) { r.err = std::string("trx_run: ") + trx_last_error(r.h); return; }
+    trx_get_stats(r.h, &r.stats);
+    if (rccl) {                                            // the one exchange: all slices to every rank
+      std::vector<double> all((size_t)count * ngpus);
+      r.rc = trx_gather_host(r.h, r.slice.data(), all.data(), count);
+      if (r.rc != TRX_OK) { r.err = std::string("trx_gather: ") + trx_last_error(r.h); return; }
+      if (k == 0) gathered = all;
+    }
+  };
+  if (ngpus == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < ngpus; k++) th.emplace_back(work, k);
+    for (auto &t : th) t.join();
+  }
+  auto cleanup = [&]() {
+    for (auto &r : R) { void *c = r.st.comm; if (r.h) trx_destroy(r.h); if (c) trx_comm_destroy(c); }
+    trh_free(P);
+  };
+  for (auto &r : R)
+    if (r.rc != TRX_OK) {
+      std::fprintf(stderr, "transit_hip: rank %d: %s failed: %s\n", r.rank, r.err.c_str(), trx_strerror(r.rc));
+      cleanup(); return EXIT_FAILURE;
+    }
+  if (!rccl) for (int k = 0; k < ngpus; k++) std::memcpy(&gathered[(size_t)k * count], R[(size_t)k].slice.data(), sizeof(double) * (size_t)count);
+
+  // ---- rank 0 stitches and writes
+  std::vector<double> spectrum((size_t)nwn);
+  for (int k = 0; k < ngpus; k++)
+    std::memcpy(&spectrum[(size_t)bounds[k]], &gathered[(size_t)k * count], sizeof(double) * (size_t)(bounds[k + 1] - bounds[k]));
+  std::vector<double> tau, e, ecs, intens; std::vector<int64_t> last;
+  if (need_tau) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); }
+  if (need_e) e.resize((size_t)nwn * nr);
+  if (need_ecs) ecs.resize((size_t)nwn * nr);
+  if (want_intens) intens.resize((size_t)nwn * nang);
+  for (int k = 0; k < ngpus; k++) {                       // debug layouts: tau [wn][height], e/e_cs [layer][wn], intens [angle][wn]
+    const Rank &r = R[(size_t)k];
+    const int64_t lo = bounds[k], n = bounds[k + 1] - bounds[k];
+    if (need_tau) { std::memcpy(&tau[(size_t)lo * nr], r.tau.data(), sizeof(double) * (size_t)n * nr); std::memcpy(&last[(size_t)lo], r.last.data(), sizeof(int64_t) * (size_t)n); }
+    for (int l = 0; l < nr; l++) {
+      if (need_e) std::memcpy(&e[(size_t)l * nwn + lo], &r.e[(size_t)l * n], sizeof(double) * (size_t)n);
+      if (need_ecs) std::memcpy(&ecs[(size_t)l * nwn + lo], &r.ecs[(size_t)l * n], sizeof(double) * (size_t)n);
+    }
+    for (int a = 0; a < nang && want_intens; a++) std::memcpy(&intens[(size_t)a * nwn + lo], &r.intens[(size_t)a * n], sizeof(double) * (size_t)n);
   }
   if (verblevel > 3) {
-    trx_stats s{}; trx_get_stats(h, &s);
-    std::printf("Check point: 00 - 14 spectrum (CIA + line sweep + optical depth + %s):  dt = %.4f sec.\n"
-                "  lines in range %lld, co-added %lld, layers swept %lld of %d, device time %.3f ms\n\n",
-                trh_opts(P)->solution == TRX_SOL_ECLIPSE ? "intensities + flux" : "modulation",
-                now_s() - t0, (long long)s.nlines_inrange, (long long)s.nadd, (long long)s.layers_swept, nr, s.ms_run_total);
+    long long inr = 0, nadd = 0, swept = 0; double dev_ms = 0;
+    for (auto &r : R) { inr += r.stats.nlines_inrange; nadd = std::max<long long>(nadd, r.stats.nadd); swept = std::max<long long>(swept, r.stats.layers_swept); dev_ms = std::max(dev_ms, r.stats.ms_run_total); }
+    std::printf("Check point: 00 - 14 opacity + spectrum on %d GPU%s (Voigt table, line list, CIA + line sweep + optical depth + %s):  dt = %.4f sec.\n"
+                "  lines in range %lld, co-added %lld, layers swept %lld of %d, device time of the spectrum %.3f ms\n\n",
+                ngpus, ngpus > 1 ? "s" : "", trh_opts(P)->solution == TRX_SOL_ECLIPSE ? "intensities + flux" : "modulation",
+                now_s() - t0, inr, nadd, swept, nr, dev_ms);
   }
   if (want_toomuch) trh_write_toomuch(P, tau.data(), last.data(), nullptr);
   if (want_intens) trh_write_intens(P, intens.data(), nullptr);
@@ -106,7 +206,6 @@ int main(int argc, char **argv)
   rc = trh_write_spectrum(P, spectrum.data(), nullptr);
   if (rc != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the spectrum file\n");
   if (verblevel > 3) std::printf("Check point: 00 - 15 outputs written:  wall since start = %.4f sec.\n", now_s() - t_start);
-  trx_destroy(h);
-  trh_free(P);
+  cleanup();
   return rc == TRX_OK ? EXIT_SUCCESS : EXIT_FAILURE;
 }
