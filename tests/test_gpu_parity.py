@@ -165,9 +165,12 @@ def test_shards_stitch_to_the_full_spectrum(case, world):
     assert rel_err(np.concatenate(parts), full["spectrum"]) < 1e-12
 
 
-def test_rccl_communicator_single_rank():
-    """The in-stream all-reduce of the layer maxima through a 1-rank RCCL
-    communicator: exercises library resolution, init and the stream call."""
+def test_rccl_gather_single_rank():
+    """trx_gather / trx_gather_host -- the one exchange of a sharded job -- through a 1-rank RCCL
+    communicator: library resolution, communicator init, ncclAllGather on the handle's stream.
+    (More ranks need more devices: the driver's 8-GPU node.)"""
+    import ctypes as C
+    import torch
     from transit_amd import dist as tdist
     g = golden("coadd_thresh")
     P = g.problem
@@ -179,12 +182,21 @@ def test_rccl_communicator_single_rank():
     try:
         st.comm, st.nranks, st.rank = comm, 1, 0
         eng = Engine(st)
-        # first run: default steps, gated to the bottom; later runs: steps planned from the
-        # all-reduced depth of the previous one, all-reduced stop decision
-        got = [eng.run(P.atm, P.opts)["spectrum"] for _ in range(3)]
+        n = P.nwn
+        d_slice = torch.zeros(n + 3, dtype=torch.float64, device="cuda:0")        # padded slice
+        d_all = torch.full((n + 3,), -1.0, dtype=torch.float64, device="cuda:0")
+        for _ in range(3):                           # unhinted run, then hinted ones
+            eng.run_device(P.atm, P.opts, d_slice.data_ptr())
+            eng.gather(d_slice.data_ptr(), d_all.data_ptr(), n + 3)
+            assert np.array_equal(d_all[:n].cpu().numpy(), ref) and float(d_all[n:].abs().sum()) == 0.0
+        host_all = np.full(n, -1.0)
+        lib = eng._lib
+        lib.trx_gather_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]
+        lib.trx_gather_host.restype = C.c_int
+        assert lib.trx_gather_host(eng._h, ref.ctypes.data_as(C.POINTER(C.c_double)),
+                                   host_all.ctypes.data_as(C.POINTER(C.c_double)), n) == 0
+        assert np.array_equal(host_all, ref)
         eng.close()
     finally:
         st.comm, st.nranks, st.rank = None, 1, 0
         tdist.destroy_comm(comm)
-    for g_ in got:
-        assert np.array_equal(g_, ref)
