@@ -797,6 +797,14 @@ static double modulation_int(const double *tau, long last, double toomuch, const
   return res;
 }
 
+/* The ray solutions on their own, for the analytic known-answer tests the reference keeps in
+ * transit/test/test_slantpath.c (:177-198 optical depth through a sphere, :231-307 modulation
+ * for prescribed optical depths): same arguments as totaltau1 / modulation1. */
+double trxo_tau_slant(const double *rad, long nlay, double b, double *ex) { return tau_slant(rad, nlay, b, ex); }
+double trxo_modulation(const double *tau, long last, double toomuch, const double *ip, long ipn,
+                       double ipfct, double srad, int transparent)
+{ return modulation_int(tau, last, toomuch, ip, ipn, ipfct, srad, transparent); }
+
 /* transit/src/slantpath.c:447-473 (modulationm1) */
 static double modulation_rad(const double *tau, long last, double toomuch, const double *ip,
                              double ipfct, double srad)

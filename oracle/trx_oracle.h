@@ -38,6 +38,9 @@ int  trxo_width_grids(const trxo_handle *h, double *adop, double *alor);
 int    trxo_voigt_profile(int nwn, double half, double alphaL, double alphaD, float *out, int quick);
 double trxo_parab3(const double *x, const double *y, double xr);
 double trxo_simpson(const double *x, const double *y, int n);
+double trxo_tau_slant(const double *rad, long nlay, double b, double *ex);
+double trxo_modulation(const double *tau, long last, double toomuch, const double *ip, long ipn,
+                       double ipfct, double srad, int transparent);
 int    trxo_nearest(const double *a, double v, int lo, int hi);
 void   trxo_spline_init(double *z, const double *x, const double *y, long n);
 double trxo_spline_eval(const double *z, long n, const double *x, const double *y, double xo);

@@ -33,6 +33,10 @@ def oracle_library():
         lib.trxo_parab3.restype = C.c_double
         lib.trxo_simpson.argtypes = [_abi.c_double_p, _abi.c_double_p, C.c_int]
         lib.trxo_simpson.restype = C.c_double
+        lib.trxo_tau_slant.argtypes = [_abi.c_double_p, C.c_long, C.c_double, _abi.c_double_p]
+        lib.trxo_tau_slant.restype = C.c_double
+        lib.trxo_modulation.argtypes = [_abi.c_double_p, C.c_long, C.c_double, _abi.c_double_p, C.c_long, C.c_double, C.c_double, C.c_int]
+        lib.trxo_modulation.restype = C.c_double
         lib.trxo_nearest.argtypes = [_abi.c_double_p, C.c_double, C.c_int, C.c_int]
         lib.trxo_nearest.restype = C.c_int
         lib.trxo_spline_init.argtypes = [_abi.c_double_p, _abi.c_double_p, _abi.c_double_p, C.c_long]
@@ -46,11 +50,6 @@ def oracle_library():
 class OracleEngine(CEngine):
     def __init__(self, static):
         super().__init__(oracle_library(), "trxo_", static)
-
-
-def ref_binary():
-    p = os.path.join(ORACLE_DIR, "_ref", "transit")
-    return p if os.path.exists(p) else None
 
 
 def ref_pu_library():
