@@ -182,6 +182,13 @@ typedef struct {
   int64_t *last;          /* [nwn_shard]                                       */
   double  *intens;        /* [nangles][nwn_shard] (eclipse)                    */
   uint8_t *computed;      /* [nlayer] 1 if the layer was swept                 */
+  /* the arrays behind the reference's total/cloud/scatt_extion.dat dumps (tau.c:293-329):      */
+  double  *er;            /* [nlayer][nwn_shard] total extinction as the ray solution left it:
+                             defined for the layers a ray went through (layer >= nlayer-1-last);
+                             eclipse geometry keeps its bottom-point parabola values in it
+                             (eclipse.c:65-66)                                               */
+  double  *e_scat;        /* [nlayer][nwn_shard] scattering extinction (extinction.c:587-624) */
+  double  *e_cloud;       /* [nlayer][nwn_shard] cloud extinction (extinction.c:630-693)     */
 } trx_debug;
 
 /* Counters and device timings of the last trx_run (reference DEBUG counters
@@ -272,7 +279,8 @@ int  trx_gather(trx_handle *h, const void *d_slice, void *d_all, int64_t count);
 int  trx_gather_host(trx_handle *h, const double *slice, double *all, int64_t count);
 
 const char *trx_strerror(int status);
-const char *trx_last_error(const trx_handle *h);   /* detail of the last failure */
+const char *trx_last_error(const trx_handle *h);   /* detail of the last failure; h NULL: of this thread's last
+                                                      trx_comm_create */
 
 /* Messages.  The reference prints through tr_output(level, ...) filtered by the global
  * `verblevel` (transit.h:70-75, levels flags_tr.h:107-111) and exit()s on errors; the

@@ -83,6 +83,15 @@ int  trh_write_intens(const trh_problem *p, const double *intens, const char *pa
 /* `savefiles yes`: tau.dat, CIA.dat, mol_extion.dat in the reference's dump formats (tau.c:386-515),
  * from the trx_debug arrays (any of them may be NULL); dir NULL = next to the cfg */
 int  trh_write_dumps(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const char *dir);
+/* the same with the reference's zero rows in mol_extion.dat: layers below the deepest ray
+ * (last = trx_debug.last) were never swept by its lazy sweep and are written as zeros */
+int  trh_write_dumps_masked(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const int64_t *last,
+                            const char *dir);
+/* the other three `savefiles` dumps: total_extion.dat, cloud_extion.dat, scatt_extion.dat
+ * (tau.c:180-190, 293-297), from trx_debug.e / e_cs / last / er / e_scat / e_cloud of a run
+ * whose e covers every needed layer (trx_opts.eager = 1) */
+int  trh_write_ext_dumps(const trh_problem *p, const double *e, const double *e_cs, const int64_t *last, const double *er,
+                         const double *e_scat, const double *e_cloud, const char *dir);
 /* detailtau / detailext / detailcia (detailout, tau.c:526-605): which = 0 tau [wn][height],
  * 1 molecular extinction [layer][wn], 2 CIA extinction [layer][wn] (trx_debug layouts).  Writes
  * the file named in the option; no-op when the option was not given. */

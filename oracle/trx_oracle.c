@@ -969,6 +969,11 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
       if (tw[ri] > o->toomuch) { last[wi] = ri; break; }   /* tau.c:277-287 */
     }
     if (ri == nr) last[wi] = ri - 1;                       /* tau.c:299-304 */
+    /* the reference's total / cloud / scattering dumps: the per-wavenumber arrays as they stand
+     * after the height loop (save1Darray, tau.c:293-297) */
+    if (dbg && dbg->er)      for (long r = 0; r < nr; r++) dbg->er[(size_t)r*nwn + wi] = er[r];
+    if (dbg && dbg->e_scat)  for (long r = 0; r < nr; r++) dbg->e_scat[(size_t)r*nwn + wi] = es[r];
+    if (dbg && dbg->e_cloud) for (long r = 0; r < nr; r++) dbg->e_cloud[(size_t)r*nwn + wi] = ec[r];
   }
 #undef SWEEP
 

@@ -80,11 +80,8 @@ def test_cli_savefiles_dumps_match_the_reference_dumps(tmp_path):
         gk, gv = ol.read_rows_dump(work / name, key)
         rk, rv = ol.read_rows_dump(ref_path, key)
         assert np.array_equal(gk, rk), name                       # row keys: same text
-        if name == "mol_extion.dat":                              # the reference leaves unswept layers at zero
-            sw = np.any(rv != 0, axis=1)
-            assert rel_err(gv[sw], rv[sw]) < 1e-8
-        else:
-            assert rel_err(gv, rv) < 1e-8, name
+        assert np.array_equal(gv == 0, rv == 0), name             # incl. the layers the reference never swept
+        assert rel_err(gv, rv) < 1e-8, name
 
 
 @pytest.mark.gpu
@@ -119,14 +116,16 @@ def test_cli_detail_and_sampling_files_match_the_reference(tmp_path, case):
     ref = lambda f: os.path.join(GOLDEN, case, f)
     assert open(work / "sample.dat").read() == open(ref("sample.dat")).read()
     assert rel_err(ol.read_spectrum(work / "spectrum.dat")[:, 1], ol.read_spectrum(ref("spectrum.dat"))[:, 1]) < 2e-8
+    from test_options import check_savefiles
+    check_savefiles(str(work), case, 1e-8)                               # all six `savefiles` dumps
     for f in ("detail_tau.dat", "detail_ext.dat", "detail_cia.dat"):
         got, want = open(work / f).read().split("\n"), open(ref(f)).read().split("\n")
         assert got[0] == want[0] and len(got) == len(want), f            # picked wavenumbers, row count
         a, b = np.loadtxt(work / f, comments="#", ndmin=2), np.loadtxt(ref(f), comments="#", ndmin=2)
         assert np.array_equal(a[:, 0], b[:, 0]), f                       # radius / impact-parameter column
         if f == "detail_ext.dat":
-            sw = np.any(b[:, 1:] != 0, axis=1)                           # the reference leaves unswept layers at zero
-            assert rel_err(a[sw, 1:], b[sw, 1:]) < 2e-6, f
+            assert np.array_equal(a[:, 1:] == 0, b[:, 1:] == 0)          # the reference leaves unswept layers at zero
+            assert rel_err(a[:, 1:], b[:, 1:]) < 2e-6, f
         elif f == "detail_tau.dat":
             assert np.array_equal(a[:, 1:] == 0, b[:, 1:] == 0)          # same toomuch cut
             assert rel_err(a[:, 1:], b[:, 1:]) < 2e-6, f
@@ -147,23 +146,20 @@ def test_cli_multi_gpu_shards_give_the_single_gpu_files(tmp_path, case, ngpus):
     for n in (1, ngpus):
         work = tmp_path / ("%s_%d" % (case, n))
         shutil.copytree(os.path.join(GOLDEN, case), work)
-        for f in ("spectrum.dat", "toomuch.dat", "intens.dat", "tau.dat", "CIA.dat", "mol_extion.dat"):
+        for f in ("spectrum.dat", "toomuch.dat", "intens.dat", "tau.dat", "CIA.dat", "mol_extion.dat", "total_extion.dat",
+                  "cloud_extion.dat", "scatt_extion.dat"):
             if os.path.exists(work / f):
                 os.remove(work / f)
-        p = subprocess.run([exe, "-c", "case.cfg", "--gpus", str(n)], cwd=work, capture_output=True, text=True, timeout=300)
+        p = subprocess.run([exe, "-c", "case.cfg", "--savefiles", "yes", "--gpus", str(n)], cwd=work, capture_output=True,
+                           text=True, timeout=300)
         assert p.returncode == 0, p.stderr
         outs[n] = work
-    for f in ("spectrum.dat", "toomuch.dat", "tau.dat", "CIA.dat"):
+    # byte for byte, the extinction dumps too: the line sum of a bin is ordered the same way
+    # whatever the shard, and the writers redo the reference's lazy-sweep zeros from the rays' depths
+    for f in ("spectrum.dat", "toomuch.dat", "tau.dat", "CIA.dat", "mol_extion.dat", "total_extion.dat",
+              "cloud_extion.dat", "scatt_extion.dat"):
         a, b = open(outs[1] / f).read(), open(outs[ngpus] / f).read()
-        assert a == b, f                                                   # byte for byte
-    # molecular extinction: a shard sweeps down to ITS deepest ray, so rows that only another
-    # shard's rays needed stay zero in its columns (the reference's lazy sweep, per shard); what
-    # both runs computed is identical -- the line sum of a bin is ordered the same way whatever the shard
-    _, a = ol.read_rows_dump(outs[1] / "mol_extion.dat", "radius")
-    _, b = ol.read_rows_dump(outs[ngpus] / "mol_extion.dat", "radius")
-    both = (a != 0) & (b != 0)
-    assert both.any() and np.array_equal(a[both], b[both])
-    assert np.all((b != 0) <= (a != 0) | (b != 0))
+        assert a == b, f
     got = ol.read_spectrum(outs[ngpus] / "spectrum.dat")
     ref = ol.read_spectrum(os.path.join(GOLDEN, case, "spectrum.dat"))
     assert rel_err(got[:, 1], ref[:, 1]) < 2e-8

@@ -17,6 +17,7 @@ from transit_amd.engine import Engine
 
 pytestmark = pytest.mark.gpu
 
+ALL = ("e", "e_cs", "tau", "last", "intens", "computed", "er", "e_scat", "e_cloud")
 TOL_ORACLE = 1e-9
 TOL_GOLDEN = 2e-8
 
@@ -26,10 +27,10 @@ def both(request):
     g = golden(request.param)
     P = g.problem
     ora = ol.OracleEngine(P.static)
-    o_out = ora.run(P.atm, P.opts, debug=True)
+    o_out = ora.run(P.atm, P.opts, debug=ALL)
     o_stats = ora.stats()
     hip = Engine(P.static)
-    h_out = hip.run(P.atm, P.opts, debug=True)
+    h_out = hip.run(P.atm, P.opts, debug=ALL)
     h_stats = hip.stats()
     yield g, o_out, o_stats, h_out, h_stats, ora, hip
     ora.close()
@@ -65,6 +66,18 @@ def test_cia(both):
     g, o, _, h, _, _, _ = both
     assert rel_err(h["e_cs"], o["e_cs"]) < 1e-13
     assert rel_err(h["e_cs"], g.e_cs) < TOL_GOLDEN
+
+
+def test_scattering_cloud_and_total_extinction(both):
+    """The arrays behind total/cloud/scatt_extion.dat (tau.c:180-190, 231-232, 293-297)."""
+    g, o, _, h, _, _, _ = both
+    assert rel_err(h["e_scat"], o["e_scat"]) < 1e-13 and np.array_equal(h["e_scat"] == 0, o["e_scat"] == 0)
+    assert rel_err(h["e_cloud"], o["e_cloud"]) < 1e-13 and np.array_equal(h["e_cloud"] == 0, o["e_cloud"] == 0)
+    if g.problem.opts.solution == 0:
+        # eclipse: the layers a ray went through hold the bottom-point values (eclipse.c:65-66)
+        nr = h["er"].shape[0]
+        through = np.arange(nr)[:, None] >= (nr - 1 - o["last"])[None, :]
+        assert rel_err(h["er"][through], o["er"][through]) < TOL_ORACLE
 
 
 def test_intensity_grid(both):

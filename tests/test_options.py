@@ -280,6 +280,42 @@ def test_detail_writer_on_the_reference_dumps(workdir):
         assert [l.split()[0] for l in got[1:] if l] == [l.split()[0] for l in ref[1:] if l]
 
 
+SAVEFILES = (("tau.dat", "wavenumber"), ("CIA.dat", "wavenumber"), ("mol_extion.dat", "radius"),
+             ("total_extion.dat", "wavenumber"), ("cloud_extion.dat", "wavenumber"), ("scatt_extion.dat", "wavenumber"))
+
+
+def check_savefiles(got_dir, case, tol):
+    """The six dumps of `savefiles yes` against the reference's own: same text skeleton (header,
+    row keys, line count), same zeros (layers the reference's lazy sweep never reached; heights
+    past the toomuch cut), values to `tol`."""
+    import oracle_lib as ol
+    for name, key in SAVEFILES:
+        ref_path = os.path.join(GOLDEN, case, name)
+        got_lines, ref_lines = open(os.path.join(got_dir, name)).read().split("\n"), open(ref_path).read().split("\n")
+        assert got_lines[:4] == ref_lines[:4], name
+        assert len(got_lines) == len(ref_lines), name
+        gk, gv = ol.read_rows_dump(os.path.join(got_dir, name), key)
+        rk, rv = ol.read_rows_dump(ref_path, key)
+        assert np.array_equal(gk, rk), name
+        assert np.array_equal(gv == 0, rv == 0), name
+        assert rel_err(gv, rv) < tol, name
+
+
+@pytest.mark.parametrize("case", ["qscale_eclipse", "dumps_transit"])
+def test_savefiles_writers_on_the_oracle_arrays(workdir, case):
+    """tau.dat, CIA.dat, mol/total/cloud/scatt_extion.dat (tau.c:180-190, 293-335, 386-515) from
+    the oracle's intermediates: pins the writers -- including the reference's lazily swept rows
+    and the eclipse solution's bottom-point values left in er -- without a GPU."""
+    import oracle_lib as ol
+    g = golden(case)
+    P = g.problem
+    out = ol.OracleEngine(P.static).run(P.atm, P.opts, debug=("e", "e_cs", "tau", "last", "er", "e_scat", "e_cloud"))
+    d = workdir / ("save_" + case)
+    d.mkdir()
+    P.write_savefiles(out, str(d))
+    check_savefiles(str(d), case, 2e-9)
+
+
 def test_cli_help_and_version_exit_cleanly():
     exe = build.build_cli() or build.lib_path("transit_hip")
     if not os.path.exists(exe):

@@ -71,7 +71,8 @@ class TrxOpts(C.Structure):
 
 class TrxDebug(C.Structure):
     _fields_ = [("e", c_double_p), ("e_cs", c_double_p), ("tau", c_double_p), ("last", c_int64_p),
-                ("intens", c_double_p), ("computed", c_uint8_p)]
+                ("intens", c_double_p), ("computed", c_uint8_p),
+                ("er", c_double_p), ("e_scat", c_double_p), ("e_cloud", c_double_p)]
 
 
 class TrxStats(C.Structure):

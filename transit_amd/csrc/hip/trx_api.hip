@@ -615,6 +615,7 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  const char *(*GetLastError)(ncclComm_t) = nullptr;
   bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 Rccl &rccl()
@@ -630,6 +631,7 @@ Rccl &rccl()
   R.CommDestroy  = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
   R.AllGather    = (decltype(R.AllGather))dlsym(R.lib, "ncclAllGather");
   R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
+  R.GetLastError = (decltype(R.GetLastError))dlsym(R.lib, "ncclGetLastError");
   return R;
 }
 
@@ -966,15 +968,24 @@ int trx_comm_unique_id(void *id_out)
   return TRX_OK;
 }
 
+// what went wrong in a call that has no handle to keep its message (trx_last_error(NULL))
+thread_local std::string g_comm_err;
+
 int trx_comm_create(const void *idp, int nranks, int rank, int device, void **comm_out)
 {
+  g_comm_err.clear();
   if (!idp || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return TRX_E_ARG;
   Rccl &R = rccl();
-  if (!R.ok()) return TRX_E_UNSUPPORTED;
+  if (!R.ok()) { g_comm_err = "librccl.so could not be loaded"; return TRX_E_UNSUPPORTED; }
   if (hipSetDevice(device) != hipSuccess) return TRX_E_NODEVICE;
   ncclUniqueId id; std::memcpy(&id, idp, sizeof(id));
   ncclComm_t c = nullptr;
-  if (R.CommInitRank(&c, nranks, id, rank) != ncclSuccess) return TRX_E_HIP;
+  const ncclResult_t st = R.CommInitRank(&c, nranks, id, rank);
+  if (st != ncclSuccess) {
+    g_comm_err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(st) : "failed");
+    if (R.GetLastError) { const char *m = R.GetLastError(nullptr); if (m && *m) g_comm_err += std::string(" -- ") + m; }
+    return TRX_E_HIP;
+  }
   *comm_out = (void *)c;
   return TRX_OK;
 }
@@ -1010,7 +1021,7 @@ const char *trx_strerror(int st)
   return "unknown status";
 }
 
-const char *trx_last_error(const trx_handle *h) { return h ? h->err.c_str() : ""; }
+const char *trx_last_error(const trx_handle *h) { return h ? h->err.c_str() : g_comm_err.c_str(); }
 
 // The single exchange of a wavenumber-sharded job: every rank contributes `count` doubles (its
 // spectrum slice, padded to the same length on every rank) and receives all of them, rank
@@ -1626,6 +1637,24 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if (dbg->intens && o->solution == TRX_SOL_ECLIPSE)
       HIPCHK(h, hipMemcpy(dbg->intens, h->d_intens.p, sizeof(double) * o->nangles * nsh, hipMemcpyDeviceToHost));
     if (dbg->computed) for (int r = 0; r < nr; r++) dbg->computed[r] = (r >= nr - S.layers_swept) ? 1 : 0;
+    if (dbg->er) HIPCHK(h, hipMemcpy(dbg->er, h->d_er.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    if (dbg->e_scat || dbg->e_cloud) {
+      DevBuf d_x;
+      if ((rc = ensure(h, d_x, sizeof(double) * 2 * (size_t)nr * nsh))) return rc;
+      TauArgs T{};
+      T.nr = nr; T.nsh = nsh; T.lo = h->lo; T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct;
+      T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
+      T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
+      T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
+      T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
+      T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
+      T.mdens = d_mdens; T.nH = d_nH;
+      double *xs = d_x.as<double>(), *xc = xs + (size_t)nr * nsh;
+      hipLaunchKernelGGL(k_extras_dump, dim3((unsigned)((nsh + 255) / 256), (unsigned)nr), dim3(256), 0, st, T, xs, xc);
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (dbg->e_scat)  HIPCHK(h, hipMemcpy(dbg->e_scat, xs, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+      if (dbg->e_cloud) HIPCHK(h, hipMemcpy(dbg->e_cloud, xc, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    }
   }
   if (status_host[0] == 1) return fail(h, TRX_E_NOTREACHED, "optical depth never reached toomuch (modlevel -1)");
   if (status_host[0] == 2) return fail(h, TRX_E_ARG, "fewer than three points for the radial integration");

@@ -983,6 +983,18 @@ __device__ __noinline__ double cloud_term(const TauArgs &T, int r, double wn)
   return 0.0;
 }
 
+// the two model terms on their own, for the reference's scatt_extion.dat / cloud_extion.dat dumps
+__global__ __launch_bounds__(256)
+void k_extras_dump(TauArgs T, double *__restrict__ e_scat, double *__restrict__ e_cloud)
+{
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (w >= T.nsh) return;
+  const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
+  if (e_scat)  e_scat [(long long)r * T.nsh + w] = scat_term(T, r, wcgs);
+  if (e_cloud) e_cloud[(long long)r * T.nsh + w] = cloud_term(T, r, wcgs);
+}
+
 // End of an optical-depth launch: every block adds its number of rays that are still
 // descending and its deepest stopping height ONCE (blocks loop over tiles, so the
 // same-address atomics stay in the low thousands at any grid size); the last block to

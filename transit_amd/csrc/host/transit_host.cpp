@@ -1245,11 +1245,18 @@ const char *trh_output_plan(trh_problem *p)
 // formats and under its fixed file names in the working directory -- tau.dat (savetau,
 // tau.c:491-515), CIA.dat (saveCIA, :420-446), mol_extion.dat (savemolExtion, :386-416).
 // Inputs in the layouts of trx_debug: e, e_cs [layer][wn]; tau [wn][height].
-// (total/cloud/scatt_extion.dat are not written: the ABI does not export those arrays.)
+// The reference leaves the rows of layers its lazy sweep never reached at zero in mol_extion.dat;
+// pass `last` (trx_debug.last) to get the same: rows below the deepest ray are written as zeros.
 int trh_write_dumps(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const char *dir)
+{ return trh_write_dumps_masked(p, e, e_cs, tau, nullptr, dir); }
+
+int trh_write_dumps_masked(const trh_problem *p, const double *e, const double *e_cs, const double *tau, const int64_t *last,
+                           const char *dir)
 {
   if (!p) return TRX_E_ARG;
   const int64_t nr = (int64_t)p->rad.size(), nw = p->nwn;
+  int64_t lowest = 0;                                       // lowest layer the reference would have swept
+  if (last) { int64_t deep = 0; for (int64_t w = 0; w < nw; w++) deep = std::max(deep, last[w]); lowest = nr - 1 - deep; }
   const std::string base = dir ? std::string(dir) : p->base_dir;
   auto wn_at = [&](int64_t w) { return p->wn_i + (double)w * p->wn_d; };
   auto row = [&](FILE *f, const double *v, int64_t n, int64_t stride) {          // print1dArrayDouble, tau.c:361-367
@@ -1282,13 +1289,61 @@ int trh_write_dumps(const trh_problem *p, const double *e, const double *e_cs, c
     FILE *f = std::fopen(join_path(base, "mol_extion.dat").c_str(), "w");
     if (!f) return TRX_E_ARG;
     std::fprintf(f, "\n# mol-line extinction\n# e [rad][wn]; rad[0]=bottom (max(p)); wn[0]=min(wn)\n\n");
+    const std::vector<double> zeros((size_t)nw, 0.0);
     for (int64_t r = 0; r < nr; r++) {
       std::fprintf(f, "radius: %-20.10g\n", p->rad[(size_t)r]);
-      row(f, e + r * nw, nw, 1);
+      row(f, r >= lowest ? e + r * nw : zeros.data(), nw, 1);
       std::fprintf(f, "\n");
     }
     std::fclose(f);
   }
+  return TRX_OK;
+}
+
+// total_extion.dat, cloud_extion.dat, scatt_extion.dat (tau.c:180-190, 293-297, 456-470): per
+// wavenumber the arrays er / e_c / e_s as they stand after that wavenumber's height loop.  The
+// reference builds er from the molecular extinction swept SO FAR -- layers no earlier or current
+// ray has needed still count as zero (tau.c:231-232 with unswept rows) -- and its eclipse
+// geometry leaves the bottom-point parabola values in the layers the ray went through
+// (eclipse.c:65-66).  Inputs in the trx_debug layouts ([layer][wn]); e must cover every layer a
+// ray needed (a run with trx_opts.eager = 1 covers all).
+int trh_write_ext_dumps(const trh_problem *p, const double *e, const double *e_cs, const int64_t *last, const double *er,
+                        const double *e_scat, const double *e_cloud, const char *dir)
+{
+  if (!p || !e || !e_cs || !last || !er || !e_scat || !e_cloud) return TRX_E_ARG;
+  const int64_t nr = (int64_t)p->rad.size(), nw = p->nwn;
+  const std::string base = dir ? std::string(dir) : p->base_dir;
+  auto wn_at = [&](int64_t w) { return p->wn_i + (double)w * p->wn_d; };
+  struct Out { const char *name, *head; } outs[3] = {
+    {"total_extion.dat", "# 2D total extinction\n# er [wn][rad]; wn[0]=min(wn), row[0]=bottom (max(p))\n"},
+    {"cloud_extion.dat", "# 2D cloud extinction\n# e_c [wn][rad]; wn[0]=min(wn), row[0]=bottom (max(p))\n"},
+    {"scatt_extion.dat", "# 2D scatt extinction\n# e_s [wn][rad]; wn[0]=min(wn), row[0]=bottom (max(p))\n"}};
+  FILE *f[3];
+  for (int k = 0; k < 3; k++) {
+    f[k] = std::fopen(join_path(base, outs[k].name).c_str(), "w");
+    if (!f[k]) { for (int j = 0; j < k; j++) std::fclose(f[j]); return TRX_E_ARG; }
+    std::fprintf(f[k], "\n%s", outs[k].head);                // openFile, tau.c:473-480
+  }
+  const bool eclipse = p->opts.solution == TRX_SOL_ECLIPSE;
+  int64_t lowest = nr - 1;                                  // lowest layer swept so far (the top one always is, tau.c:158-177)
+  std::vector<double> tot((size_t)nr);
+  for (int64_t w = 0; w < nw; w++) {
+    const int64_t mine = nr - 1 - last[w];                  // lowest layer this ray went through
+    lowest = std::min(lowest, mine);
+    for (int64_t r = 0; r < nr; r++) {
+      const size_t k = (size_t)(r * nw + w);
+      if (eclipse && r >= mine) tot[(size_t)r] = er[k];     // as the ray solution left it
+      else tot[(size_t)r] = (r >= lowest ? e[k] : 0.0) + e_scat[k] + e_cloud[k] + e_cs[k];     // tau.c:231-232
+    }
+    const double *src[3] = {tot.data(), nullptr, nullptr};
+    for (int k = 0; k < 3; k++) {                           // save1Darray, tau.c:456-470
+      std::fprintf(f[k], "\nwavenumber: %-20.10g\n", wn_at(w));
+      for (int64_t r = 0; r < nr; r++)
+        std::fprintf(f[k], "%-20.10g", k == 0 ? src[0][r] : (k == 1 ? e_cloud : e_scat)[(size_t)(r * nw + w)]);
+      std::fprintf(f[k], "\n");
+    }
+  }
+  for (int k = 0; k < 3; k++) std::fclose(f[k]);
   return TRX_OK;
 }
 

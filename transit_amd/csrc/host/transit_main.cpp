@@ -36,7 +36,7 @@ struct Rank {
   trx_static st{};                   // this rank's copy: shard, device, communicator
   trx_handle *h = nullptr;
   int rc = TRX_OK; std::string err;
-  std::vector<double> slice, tau, e, ecs, intens; std::vector<int64_t> last;
+  std::vector<double> slice, tau, e, ecs, intens, er, es, ec; std::vector<int64_t> last;
   trx_stats stats{};
 };
 
@@ -101,7 +101,7 @@ int main(int argc, char **argv)
   const bool want_dumps = sf && std::strncmp(sf, "yes", 3) == 0;                // argum.c:461-470
   const bool det_tau = trh_wants_detail(P, 0), det_ext = trh_wants_detail(P, 1), det_cia = trh_wants_detail(P, 2);
   const bool want_intens = trh_option(P, "outintens") != nullptr && trh_opts(P)->solution == TRX_SOL_ECLIPSE;
-  const bool need_tau = want_toomuch || want_dumps || det_tau, need_e = want_dumps || det_ext, need_ecs = want_dumps || det_cia;
+  const bool need_tau = want_toomuch || want_dumps || det_tau || det_ext, need_e = want_dumps || det_ext, need_ecs = want_dumps || det_cia;
   const int nang = trh_opts(P)->nangles;
   if (want_dumps && trh_write_sample(P, nullptr) != TRX_OK)                     // makesample.c:598-599
     std::fprintf(stderr, "transit_hip: cannot write the sampling file\n");
@@ -131,7 +131,7 @@ int main(int argc, char **argv)
     r.st.comm = nullptr; r.st.nranks = 1; r.st.rank = 0;
     if (rccl) {
       void *c = nullptr;
-      if ((r.rc = trx_comm_create(comm_id, ngpus, k, r.device, &c)) != TRX_OK) { r.err = "trx_comm_create"; return; }
+      if ((r.rc = trx_comm_create(comm_id, ngpus, k, r.device, &c)) != TRX_OK) { r.err = std::string("trx_comm_create: ") + trx_last_error(nullptr); return; }
       r.st.comm = c; r.st.nranks = ngpus; r.st.rank = k;
     }
     if ((r.rc = trx_create(&r.st, &r.h)) != TRX_OK) { r.err = "trx_create"; return; }
@@ -142,7 +142,13 @@ int main(int argc, char **argv)
     if (need_e) { r.e.resize((size_t)n * nr); dbg.e = r.e.data(); }
     if (need_ecs) { r.ecs.resize((size_t)n * nr); dbg.e_cs = r.ecs.data(); }
     if (want_intens) { r.intens.resize((size_t)n * nang); dbg.intens = r.intens.data(); }
-    r.rc = trx_run(r.h, trh_atm(P), trh_opts(P), r.slice.data(), (dbg.tau || dbg.e || dbg.e_cs || dbg.intens) ? &dbg : nullptr);
+    trx_opts opts = *trh_opts(P);
+    if (want_dumps) {                                      // the dump writers redo the reference's laziness from `last`
+      opts.eager = 1;
+      r.er.resize((size_t)n * nr); r.es.resize((size_t)n * nr); r.ec.resize((size_t)n * nr);
+      dbg.er = r.er.data(); dbg.e_scat = r.es.data(); dbg.e_cloud = r.ec.data();
+    }
+    r.rc = trx_run(r.h, trh_atm(P), &opts, r.slice.data(), (dbg.tau || dbg.e || dbg.e_cs || dbg.intens) ? &dbg : nullptr);
     if (r.rc != TRX_OK) { r.err = std::string("trx_run: ") + trx_last_error(r.h); return; }
     trx_get_stats(r.h, &r.stats);
     if (rccl) {                                            // the one exchange: all slices to every rank
@@ -173,7 +179,8 @@ int main(int argc, char **argv)
   std::vector<double> spectrum((size_t)nwn);
   for (int k = 0; k < ngpus; k++)
     std::memcpy(&spectrum[(size_t)bounds[k]], &gathered[(size_t)k * count], sizeof(double) * (size_t)(bounds[k + 1] - bounds[k]));
-  std::vector<double> tau, e, ecs, intens; std::vector<int64_t> last;
+  std::vector<double> tau, e, ecs, intens, er, es, ec; std::vector<int64_t> last;
+  if (want_dumps) { er.resize((size_t)nwn * nr); es.resize((size_t)nwn * nr); ec.resize((size_t)nwn * nr); }
   if (need_tau) { tau.resize((size_t)nwn * nr); last.resize((size_t)nwn); }
   if (need_e) e.resize((size_t)nwn * nr);
   if (need_ecs) ecs.resize((size_t)nwn * nr);
@@ -185,8 +192,18 @@ int main(int argc, char **argv)
     for (int l = 0; l < nr; l++) {
       if (need_e) std::memcpy(&e[(size_t)l * nwn + lo], &r.e[(size_t)l * n], sizeof(double) * (size_t)n);
       if (need_ecs) std::memcpy(&ecs[(size_t)l * nwn + lo], &r.ecs[(size_t)l * n], sizeof(double) * (size_t)n);
+      if (want_dumps) {
+        std::memcpy(&er[(size_t)l * nwn + lo], &r.er[(size_t)l * n], sizeof(double) * (size_t)n);
+        std::memcpy(&es[(size_t)l * nwn + lo], &r.es[(size_t)l * n], sizeof(double) * (size_t)n);
+        std::memcpy(&ec[(size_t)l * nwn + lo], &r.ec[(size_t)l * n], sizeof(double) * (size_t)n);
+      }
     }
     for (int a = 0; a < nang && want_intens; a++) std::memcpy(&intens[(size_t)a * nwn + lo], &r.intens[(size_t)a * n], sizeof(double) * (size_t)n);
+  }
+  if (need_e) {                                            // the run may have swept deeper than the deepest ray: give the rows
+    int64_t deep = 0;                                      // below it back the zeros the reference's lazy sweep leaves there
+    for (int64_t w = 0; w < nwn; w++) deep = std::max(deep, last[(size_t)w]);
+    std::fill(e.begin(), e.begin() + (size_t)(nr - 1 - deep) * nwn, 0.0);
   }
   if (verblevel > 3) {
     long long inr = 0, nadd = 0, swept = 0; double dev_ms = 0;
@@ -198,7 +215,8 @@ int main(int argc, char **argv)
   }
   if (want_toomuch) trh_write_toomuch(P, tau.data(), last.data(), nullptr);
   if (want_intens) trh_write_intens(P, intens.data(), nullptr);
-  if (want_dumps && trh_write_dumps(P, e.data(), ecs.data(), tau.data(), nullptr) != TRX_OK)
+  if (want_dumps && (trh_write_dumps_masked(P, e.data(), ecs.data(), tau.data(), last.data(), nullptr) != TRX_OK ||
+                     trh_write_ext_dumps(P, e.data(), ecs.data(), last.data(), er.data(), es.data(), ec.data(), nullptr) != TRX_OK))
     std::fprintf(stderr, "transit_hip: cannot write the savefiles dumps\n");
   if ((det_tau && trh_write_detail(P, 0, tau.data()) != TRX_OK) || (det_ext && trh_write_detail(P, 1, e.data()) != TRX_OK) ||
       (det_cia && trh_write_detail(P, 2, ecs.data()) != TRX_OK))

@@ -42,7 +42,8 @@ def create_comm(world: int, rank: int, device: int, broadcast: Optional[Callable
     comm = C.c_void_p()
     rc = lib.trx_comm_create(idbuf, world, rank, device, C.byref(comm))
     if rc != 0:
-        raise EngineError(rc, "trx_comm_create")
+        lib.trx_last_error.argtypes, lib.trx_last_error.restype = [C.c_void_p], C.c_char_p
+        raise EngineError(rc, "trx_comm_create", (lib.trx_last_error(None) or b"").decode(errors="replace"))
     return comm
 
 

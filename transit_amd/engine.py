@@ -70,13 +70,15 @@ class CEngine:
         if debug:
             want = ("e", "e_cs", "tau", "last", "intens", "computed") if debug is True else tuple(debug)
             make = {"e": lambda: np.zeros((nl, n)), "e_cs": lambda: np.zeros((nl, n)),
+                    "er": lambda: np.zeros((nl, n)), "e_scat": lambda: np.zeros((nl, n)), "e_cloud": lambda: np.zeros((nl, n)),
                     "tau": lambda: np.zeros((n, nl)), "last": lambda: np.zeros(n, dtype=np.int64),
                     "intens": lambda: np.zeros((na, n)), "computed": lambda: np.zeros(nl, dtype=np.uint8)}
             types = {"last": _abi.c_int64_p, "computed": _abi.c_uint8_p}
             for k in want:
                 out[k] = make[k]()
             ptr = lambda k: out[k].ctypes.data_as(types.get(k, _abi.c_double_p)) if k in out else None
-            dbg = _abi.TrxDebug(ptr("e"), ptr("e_cs"), ptr("tau"), ptr("last"), ptr("intens"), ptr("computed"))
+            dbg = _abi.TrxDebug(ptr("e"), ptr("e_cs"), ptr("tau"), ptr("last"), ptr("intens"), ptr("computed"),
+                                ptr("er"), ptr("e_scat"), ptr("e_cloud"))
         rc = self._f("run")(self._h, C.byref(atm), C.byref(opts),
                             out["spectrum"].ctypes.data_as(_abi.c_double_p),
                             C.byref(dbg) if dbg is not None else None)
@@ -135,6 +137,28 @@ class CEngine:
 _hip = None
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (same soname as /opt/rocm's, but loaded by path): if our library came first
+    and bound /opt/rocm's copy, a later `import torch` would map a second runtime, and RCCL
+    (torch's librccl.so) would then find its HSA uninitialised ("no ROCm-capable device").  So
+    when a torch wheel with a bundled runtime is installed, map that copy first -- ours then
+    binds to it by soname, whichever import order the caller uses.  torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                   # torch's runtime is mapped already
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def hip_library():
     """Load libtransit_hip.so or raise -- there is no CPU fallback."""
     global _hip
@@ -143,6 +167,7 @@ def hip_library():
         if not os.path.exists(path):
             raise RuntimeError("HIP extension %s is missing; build it with "
                                "`python -m transit_amd.build` (hipcc --offload-arch=gfx950)" % path)
+        _one_hip_runtime()
         lib = C.CDLL(path)
         _abi.bind_engine_api(lib, "trx_")
         lib.trx_run_device.argtypes = [C.c_void_p, C.POINTER(_abi.TrxAtm), C.POINTER(_abi.TrxOpts),

@@ -70,6 +70,12 @@ def _load():
         lib.trh_write_detail.restype = C.c_int
         lib.trh_write_sample.argtypes = [C.c_void_p, C.c_char_p]
         lib.trh_write_sample.restype = C.c_int
+        lib.trh_write_dumps_masked.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p,
+                                               _abi.c_int64_p, C.c_char_p]
+        lib.trh_write_dumps_masked.restype = C.c_int
+        lib.trh_write_ext_dumps.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_double_p, _abi.c_int64_p,
+                                            _abi.c_double_p, _abi.c_double_p, _abi.c_double_p, C.c_char_p]
+        lib.trh_write_ext_dumps.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -192,6 +198,19 @@ class Problem:
             os.chdir(old)
         if rc != 0:
             raise HostError(rc, "write_sample failed")
+
+    def write_savefiles(self, out: dict, directory: str):
+        """The six `savefiles yes` dumps (tau.c:180-190, 293-335) into `directory`, from a debug
+        run's arrays: e, e_cs, tau, last, er, e_scat, e_cloud."""
+        d = lambda k: np.ascontiguousarray(out[k], dtype=np.float64).ctypes.data_as(_abi.c_double_p)
+        last = np.ascontiguousarray(out["last"], dtype=np.int64)
+        lp = last.ctypes.data_as(_abi.c_int64_p)
+        rc = _load().trh_write_dumps_masked(self._h, d("e"), d("e_cs"), d("tau"), lp, directory.encode())
+        if rc == 0:
+            rc = _load().trh_write_ext_dumps(self._h, d("e"), d("e_cs"), lp, d("er"), d("e_scat"), d("e_cloud"),
+                                             directory.encode())
+        if rc != 0:
+            raise HostError(rc, "write_savefiles failed")
 
     def reload_atm(self, values: np.ndarray):
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
