@@ -68,17 +68,18 @@ static int bsearch_ie(const double *a, long i, long f, double v)
   return (int)i;
 }
 
-/* pu/src/numerical.c:182-195 (interp_parab): parabola through three points
- * assumed equispaced (only x[1]-x[0] is used). */
-double trxo_parab3(const double *x, const double *y, double xr)
+/* pu/src/numerical.c:182-195 (interp_parab): parabola through three nodes taken as
+ * equispaced (only node[1]-node[0] is used), in the coordinates t = x/step.  Same operations in
+ * the same order as the reference: the rounding noise is part of the result (tests/tolerances.py). */
+double trxo_parab3(const double *node, const double *v, double at)
 {
-  const double dx = x[1] - x[0];
-  const double x0 = x[0] / dx;
-  const double my = y[0] + y[2] - 2*y[1];
-  const double a  = my / (2.0 * dx * dx);
-  const double b  = (y[2] - y[1] - (x0 + 1.5) * my) / dx;
-  const double c  = y[0] + x0 * (y[2] - 4*y[1] + 3*y[0] + x0 * my) / 2.0;
-  return xr * xr * a + xr * b + c;
+  const double step = node[1] - node[0];
+  const double t0   = node[0] / step;
+  const double bend = v[0] + v[2] - 2*v[1];
+  const double quad = bend / (2.0 * step * step);
+  const double lin  = (v[2] - v[1] - (t0 + 1.5) * bend) / step;
+  const double cst  = v[0] + t0 * (v[2] - 4*v[1] + 3*v[0] + t0 * bend) / 2.0;
+  return at * at * quad + at * lin + cst;
 }
 
 /* pu/src/numerical.c:202-211 (interp_line) */

@@ -12,12 +12,12 @@ from cases import rel_err
 from transit_amd import synth
 from transit_amd.engine import Engine, EngineError
 from transit_amd.host import Problem
+from tolerances import DEBUG_KEYS, assert_tau_close
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("TRX_RANDOM_CASES", "24"))))
-def test_random_problem_against_oracle(tmp_path, seed):
+def random_case(seed):
     rng = np.random.default_rng(1000 + seed)
     solution = "eclipse" if rng.random() < 0.6 else "transit"
     wnlow = float(rng.choice([400.0, 2500.0, 4000.0, 9000.0]))
@@ -26,16 +26,21 @@ def test_random_problem_against_oracle(tmp_path, seed):
     osamp = int(rng.choice([1, 2, 7, 60, 2160])) if wndelt >= 0.5 else int(rng.choice([1, 2, 5]))
     nlines = int(rng.choice([17, 300, 2000, 5000]))          # (empty and one-line lists: test_gpu_properties.py)
     nlayers = int(rng.choice([3, 4, 9, 30, 70]))
-    kw = dict(nlines=nlines, wnlow=wnlow, wnhigh=wnlow + width, wndelt=wndelt, wnosamp=osamp, nlayers=nlayers,
-              solution=solution, toomuch=float(rng.choice([0.5, 5.0, 10.0, 50.0])),
-              ethresh=float(rng.choice([1e-50, 1e-8, 1e-5, 1e-3])), ncia=int(rng.integers(0, 3)),
-              seed=int(rng.integers(1, 10**6)), line_margin=float(rng.choice([0.0, 1.5])))
+    return dict(nlines=nlines, wnlow=wnlow, wnhigh=wnlow + width, wndelt=wndelt, wnosamp=osamp, nlayers=nlayers,
+                solution=solution, toomuch=float(rng.choice([0.5, 5.0, 10.0, 50.0])),
+                ethresh=float(rng.choice([1e-50, 1e-8, 1e-5, 1e-3])), ncia=int(rng.integers(0, 3)),
+                seed=int(rng.integers(1, 10**6)), line_margin=float(rng.choice([0.0, 1.5])))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TRX_RANDOM_CASES", "24"))))
+def test_random_problem_against_oracle(tmp_path, seed):
+    kw = random_case(seed)
     d = str(tmp_path / "r")
     synth.make_case(d, **kw)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
     ora = ol.OracleEngine(P.static)
     try:
-        ref = ora.run(P.atm, P.opts, debug=True)
+        ref = ora.run(P.atm, P.opts, debug=DEBUG_KEYS)
     except EngineError as e:                     # e.g. fewer than three points for the modulation
         ref = e
     finally:
@@ -50,15 +55,13 @@ def test_random_problem_against_oracle(tmp_path, seed):
                 continue
             got = hip.run(P.atm, P.opts, debug=True)
             assert np.array_equal(got["last"], ref["last"]), (kw, rep)
-            # (modulation of 3-4-layer atmospheres: R^2 - 2*integral cancels and the parabola noise
-            # described below enters; the stated tolerance of the path is 1e-6)
-            assert rel_err(got["spectrum"], ref["spectrum"]) < (1e-8 if nlayers > 4 else 1e-7), (kw, rep)
-            # optical depth: relative to the ray's largest value.  At the second height from the
-            # top the reference's parabola in absolute radius (numerical.c:182-195) turns last-bit
-            # differences of the extinction into ~1e-5 of the NEIGHBOURING layer's extinction --
-            # sign-flipping noise when the top layers are (nearly) empty
-            scale = np.maximum(np.abs(ref["tau"]).max(axis=1, keepdims=True), 1e-300)
-            assert np.max(np.abs(got["tau"] - ref["tau"]) / scale) < (1e-8 if nlayers > 4 else 1e-6), (kw, rep)
+            # optical depth: the arithmetic's 1e-9 plus the rounding steps of the reference's
+            # absolute-radius parabola where they apply (tests/tolerances.py) -- nothing else
+            noisy = assert_tau_close(P, got, ref, (kw, rep))
+            # spectrum: 1e-8; rays whose optical depth carries parabola noise pass it on (in the
+            # modulation of a 3-4-layer atmosphere R^2 - 2*integral cancels on top of it)
+            assert rel_err(got["spectrum"][~noisy], ref["spectrum"][~noisy]) < 1e-8, (kw, rep)
+            assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-7, (kw, rep)
             sw = got["computed"].astype(bool) & ref["computed"].astype(bool)
             assert rel_err(got["e"][sw], ref["e"][sw]) < 1e-9, (kw, rep)
             assert rel_err(got["e_cs"], ref["e_cs"]) < 1e-12, (kw, rep)

@@ -139,6 +139,56 @@ def test_tli_range_selection_drops_lines_outside_the_band(tmp_path):
         assert np.all(np.diff(w) <= 0)               # wavelength ascending = wavenumber descending
 
 
+def _tli_counts_offset(raw):
+    """Byte offset of (nlines int64, nisol int32, counts int64[nisol]) in a TLI v6 file."""
+    import struct
+    pos = 4 + 6 + 16
+    (ndb,) = struct.unpack_from("<H", raw, pos); pos += 2
+    for _ in range(ndb):
+        for _ in range(2):
+            (n,) = struct.unpack_from("<H", raw, pos); pos += 2 + n
+        nT, nI = struct.unpack_from("<2H", raw, pos); pos += 4 + 8 * nT
+        for _ in range(nI):
+            (n,) = struct.unpack_from("<H", raw, pos); pos += 2 + n + 16 + 8 * nT
+    return pos
+
+
+@pytest.mark.parametrize("damage", ["negative_total", "negative_count", "sum_mismatch", "huge_total", "too_many_isotopes",
+                                    "truncated", "no_temperatures"])
+def test_malformed_tli_headers_are_refused_not_followed(tmp_path, damage):
+    """The line blocks are mapped and indexed through the header's counts: a header whose counts
+    do not add up must end in TRX_E_ARG, never in a read outside the mapping."""
+    import struct
+    d = copy_case(tmp_path)
+    tli = [f for f in os.listdir(d) if f.endswith(".tli")][0]
+    raw = bytearray(open(d / tli, "rb").read())
+    o = _tli_counts_offset(raw)
+    nlines, nisol = struct.unpack_from("<qi", raw, o)
+    cnt = list(struct.unpack_from("<%dq" % nisol, raw, o + 12))
+    assert sum(cnt) == nlines and len(raw) == o + 12 + 8 * nisol + 26 * nlines
+    if damage == "negative_total":
+        struct.pack_into("<q", raw, o, -5)
+    elif damage == "negative_count":
+        struct.pack_into("<q", raw, o + 12, -cnt[0])
+    elif damage == "sum_mismatch":
+        struct.pack_into("<q", raw, o + 12, cnt[0] + 3)
+    elif damage == "huge_total":
+        struct.pack_into("<q", raw, o, 2**61)
+    elif damage == "too_many_isotopes":
+        struct.pack_into("<i", raw, o + 8, 10**6)
+    elif damage == "truncated":
+        raw = raw[: len(raw) - 26 * nlines // 3]
+    elif damage == "no_temperatures":
+        pos = 4 + 6 + 16 + 2
+        for _ in range(2):
+            (n,) = struct.unpack_from("<H", raw, pos); pos += 2 + n
+        struct.pack_into("<H", raw, pos, 0)
+    open(d / tli, "wb").write(bytes(raw))
+    with pytest.raises(HostError) as e:
+        Problem.from_cfg(str(d / "case.cfg"))
+    assert e.value.code == -1                            # TRX_E_ARG
+
+
 def test_multi_database_tli_and_species_mapping():
     P = golden("multi_species").problem
     st = P.static

@@ -542,6 +542,7 @@ void read_tli(trh_problem &P, const std::string &path)
   for (int d = 0; d < ndb; d++) {
     trh_problem::Db db; db.name = rstr(); db.molname = rstr();
     uint16_t nT, nI; rd(&nT, 2); rd(&nI, 2);
+    if (nT < 1) throw Fail(TRX_E_ARG, "TLI database '" + db.name + "' has no partition-function temperatures");
     db.T.resize(nT); rd(db.T.data(), 8 * (size_t)nT);
     P.tli_tmin = std::fmax(P.tli_tmin, db.T[0]);
     P.tli_tmax = std::fmin(P.tli_tmax, db.T[nT-1]);
@@ -567,8 +568,19 @@ void read_tli(trh_problem &P, const std::string &path)
     if (im < 0) throw Fail(TRX_E_ARG, "TLI molecule '" + P.dbs[P.iso_db[i]].molname + "' is not an atmosphere species");
     P.iso_imol.push_back(im);
   }
+  // the counts index straight into the mapping: nothing is read through them until they add up
   int64_t nlines; int32_t nisol; rd(&nlines, 8); rd(&nisol, 4);
+  if (nlines < 0 || nisol < 0 || (size_t)nisol > P.iso_name.size() || (uint64_t)nlines > bufsz / 26)
+    throw Fail(TRX_E_ARG, "TLI line counts are not consistent with the file (corrupt header?)");
   std::vector<int64_t> cnt((size_t)nisol); rd(cnt.data(), 8 * (size_t)nisol);
+  {
+    int64_t sum = 0;
+    for (int k = 0; k < nisol; k++) {
+      if (cnt[k] < 0 || cnt[k] > nlines) throw Fail(TRX_E_ARG, "TLI per-isotope line count is negative or exceeds the total");
+      sum += cnt[k];
+    }
+    if (sum != nlines) throw Fail(TRX_E_ARG, "TLI per-isotope line counts do not add up to the number of lines");
+  }
   const size_t wl0 = pos, iso0 = wl0 + 8 * (size_t)nlines, el0 = iso0 + 2 * (size_t)nlines, gf0 = el0 + 8 * (size_t)nlines;
   if (gf0 + 8 * (size_t)nlines > bufsz) throw Fail(TRX_E_ARG, "TLI line blocks truncated");
   const double iniw = 1.0 / (P.wn_f * 1.0) / trx::kTliWfct, finw = 1.0 / (P.wn_i * 1.0) / trx::kTliWfct;

@@ -61,16 +61,20 @@ TRX_HD int bracket_ie(const double *a, long i, long f, double v)
   return (int)i;
 }
 
-// pu/src/numerical.c:182-195 (interp_parab), scalar-argument form
-TRX_HD double parab3(double x0r, double x1r, double y0, double y1, double y2, double xr)
+// Parabola through three nodes taken as equispaced (only the first spacing is used), in the
+// coordinates t = x/step: the restatement of pu/src/numerical.c:182-195 (interp_parab) with
+// scalar arguments.  The operations and their order are the reference's on purpose -- the
+// result's rounding noise (tests/tolerances.py) is part of what parity is measured against.
+//   bend = second difference of the values; the three polynomial coefficients follow.
+TRX_HD double parab3(double node0, double node1, double v0, double v1, double v2, double at)
 {
-  const double dx = x1r - x0r;
-  const double x0 = x0r / dx;
-  const double my = y0 + y2 - 2*y1;
-  const double a  = my / (2.0 * dx * dx);
-  const double b  = (y2 - y1 - (x0 + 1.5) * my) / dx;
-  const double c  = y0 + x0 * (y2 - 4*y1 + 3*y0 + x0 * my) / 2.0;
-  return xr * xr * a + xr * b + c;
+  const double step = node1 - node0;
+  const double t0   = node0 / step;
+  const double bend = v0 + v2 - 2*v1;
+  const double quad = bend / (2.0 * step * step);
+  const double lin  = (v2 - v1 - (t0 + 1.5) * bend) / step;
+  const double cst  = v0 + t0 * (v2 - 4*v1 + 3*v0 + t0 * bend) / 2.0;
+  return at * at * quad + at * lin + cst;
 }
 
 // pu/src/spline.c:12-48 + 186-206 (tri / spline_init).  Scratch arrays u, v of
