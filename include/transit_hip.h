@@ -170,7 +170,10 @@ typedef struct {
                              per layer), up to 32 otherwise; the depth the previous spectrum
                              reached is split into equal steps                          */
   int32_t eager;          /* 1 = sweep every layer (debug dumps of all layers) */
-  int32_t profile;        /* 1 = bracket every kernel with HIP events (trx_stats timings) */
+  int32_t profile;        /* 1 = bracket the production kernels with HIP events on their own
+                             streams (trx_stats ms_* timings); 2 = also count evaluated /
+                             skipped groups and bins with the instrumented kernel variants
+                             (trx_stats neval/nskip/sum_bins; those kernels run slower)   */
 } trx_opts;
 
 /* Optional intermediate outputs (host buffers, any may be NULL).  They mirror

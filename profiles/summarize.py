@@ -27,8 +27,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+def find(d, suffix, prefix=""):
+    hits = sorted(glob.glob(os.path.join(d, "**", prefix + "*" + suffix), recursive=True))
     if not hits:
         raise SystemExit("no *%s under %s" % (suffix, d))
     return hits[0]
@@ -39,9 +39,9 @@ def short(name):
     return name.replace("void ", "").strip()
 
 
-def counter_by_kernel(d, counter):
+def counter_by_kernel(d, counter, prefix=""):
     per_dispatch = collections.OrderedDict()
-    with open(find(d, "_counter_collection.csv")) as f:
+    with open(find(d, "counter_collection.csv", prefix)) as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
@@ -53,18 +53,49 @@ def counter_by_kernel(d, counter):
     return out
 
 
+def kernel_source_hash():
+    """bench.kernel_source_hash(): bench.py quotes a traffic figure only from a summary whose
+    fingerprint matches the kernel sources of the tree it runs from."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h"):
+        h.update(open(os.path.join(HERE, "..", "transit_amd", "csrc", "hip", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def sq_mix(d, tag):
+    """SQ instruction counts per launch and kernel (the walk is issue-bound, not HBM-bound)."""
+    names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES")
+    out = collections.OrderedDict()
+    for c in names:
+        try:
+            for k, v in counter_by_kernel(d, c, "sq").items():
+                if "trx::" in k:
+                    out.setdefault(k, collections.OrderedDict())[c + "_avg_launch"] = sum(v) / len(v)
+                    out[k]["launches"] = len(v)
+        except SystemExit:
+            return
+    dst = os.path.join(HERE, tag + "_sq_mix.json")
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc " + " ".join(names) + " (own pass)", "kernels": out},
+              open(dst, "w"), indent=1)
+    print("wrote", dst)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--from", dest="src", help="directory written by profiles/collect.sh (trace/fetch/write/sq CSVs)")
     ap.add_argument("--tag", required=True)
     ap.add_argument("--cmd", default="python3 bench.py --steps 3 --warmup 1")
-    ap.add_argument("--workload", default="CH4-demo shape, 1e6 lines, 2501 wn, 100 layers, chunk 12")
+    ap.add_argument("--workload", default="CH4-demo shape, 1e6 lines, 2501 wn, 100 layers (bench.py defaults)")
     a = ap.parse_args()
+    if a.src:
+        a.trace = a.fetch = a.write = a.src
 
     if a.trace:
-        src = find(a.trace, "_kernel_stats.csv")
+        src = find(a.trace, "kernel_stats.csv", "trace" if a.src else "")
         dst = os.path.join(HERE, a.tag + "_kernel_stats.csv")
         with open(src) as f, open(dst, "w", newline="") as g:
             r = csv.reader(f)
@@ -77,7 +108,8 @@ def main():
         print("wrote", dst)
 
     if a.fetch and a.write:
-        fe, wr = counter_by_kernel(a.fetch, "FETCH_SIZE"), counter_by_kernel(a.write, "WRITE_SIZE")
+        fe = counter_by_kernel(a.fetch, "FETCH_SIZE", "fetch" if a.src else "")
+        wr = counter_by_kernel(a.write, "WRITE_SIZE", "write" if a.src else "")
         kernels = collections.OrderedDict()
         for k in fe:
             if "trx::" not in k or k not in wr:
@@ -98,12 +130,19 @@ def main():
         doc = {
             "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + a.cmd,
             "workload": a.workload,
+            "kernel_sources": kernel_source_hash(),
             "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (HBM section)",
             "kernels": kernels,
         }
         dst = os.path.join(HERE, a.tag + "_pmc_traffic.json")
         json.dump(doc, open(dst, "w"), indent=1)
         print("wrote", dst)
+    if a.src:
+        sq_mix(a.src, a.tag)
+        line = os.path.join(a.src, "bench_line_under_trace.json")
+        if os.path.exists(line):
+            import shutil
+            shutil.copy(line, os.path.join(HERE, a.tag + "_bench_line_under_trace.json"))
 
 
 if __name__ == "__main__":

@@ -97,7 +97,7 @@ def test_counters(both):
     keep = opts.eager
     try:
         opts.eager = 1
-        opts.profile = 1            # counters are collected in profiling runs only
+        opts.profile = 2            # counters are collected in counting runs only
         he = both[6].run(P.atm, opts, debug=False)
         hst2 = both[6].stats()
         oe = both[5].run(P.atm, opts, debug=False)

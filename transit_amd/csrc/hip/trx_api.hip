@@ -258,8 +258,10 @@ int build_table(trx_handle *h, const trx_static *s)
   HIPCHK(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_voigt_coef), coef, sizeof(coef), 0, hipMemcpyHostToDevice, h->stream));
   DevBuf d_jobs;
   if ((rc = upload(h, d_jobs, jobs))) return rc;
-  if ((rc = ensure(h, h->d_tab, sizeof(float) * ((size_t)h->tab_n + 2 * kTabPad)))) return rc;
-  HIPCHK(h, hipMemsetAsync(h->d_tab.p, 0, sizeof(float) * ((size_t)h->tab_n + 2 * kTabPad), h->stream));
+  // (behind the table: kWalkMaxFrame cells of zeros, where the walk's lanes read what a slot does not reach)
+  const size_t tab_alloc = (size_t)h->tab_n + 2 * kTabPad + (size_t)kWalkMaxFrame * (size_t)std::min<int64_t>(s->osamp, 1 << 21);
+  if ((rc = ensure(h, h->d_tab, sizeof(float) * tab_alloc))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->d_tab.p, 0, sizeof(float) * tab_alloc, h->stream));
   h->tab = h->d_tab.as<float>() + kTabPad;
   std::vector<int32_t> ps32(h->psize.begin(), h->psize.end());
   if ((rc = upload(h, h->d_psize, ps32))) return rc;
@@ -439,7 +441,8 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   int rc;
   // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
   // ranges of ngw consecutive groups per isotope block
-  h->walk_ok = s->osamp < (1 << 27) && h->tab_n < ((int64_t)1 << 30) && !gfirst.empty();
+  // (32-bit byte offsets into the widened table: 8*tab_n + 64*osamp must stay below 2^32)
+  h->walk_ok = s->osamp < (1 << 21) && h->tab_n < ((int64_t)1 << 28) && !gfirst.empty();
   if (h->walk_ok) {
     int ngw = 32;
     if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
@@ -749,7 +752,7 @@ int walk_frame_bins(const trx_handle *h, const int32_t *psmax, int r)
 {
   if (!h->walk_ok || !h->walk_temp_ok) return 0;
   const long long rc = layer_psmax(h, psmax, r) / h->osamp;
-  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : rc <= 7 ? 16 : 0;
+  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : rc <= 7 ? 16 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
 }
 
 // plan of the line ranges for a frame of nb bins (built once per handle and frame size)
@@ -791,7 +794,6 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
                int parity, hipStream_t st_comb, hipEvent_t ev_walk, hipEvent_t ev_reuse = nullptr, hipEvent_t ev_done = nullptr)
 {
   hipStream_t st = M.st ? M.st : h->stream;
-  if (const char *e = std::getenv("TRX_WALK_NB")) nb = std::max(nb, std::atoi(e));      // (experiments)
   WalkPlan P{}; trx_handle::Plan *pl = nullptr;
   int rc = walk_plan(h, nb, st, P, pl);
   if (rc) return rc;
@@ -813,7 +815,8 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.r_top = r_top; A.nc = nc; A.Y = Y; A.wcut = d_wcut; A.kmax = M.d_kmax; A.ethresh = M.ethresh;
   A.nmx = M.nmx; A.iso_mx = M.d_iso_mx; A.permol = M.permol; A.sticky_idop = M.d_sticky;
   A.dthr = h->d_dopthr.as<double>(); A.e2tab = h->d_e2tab.as<double>();
-  A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>(); A.table = h->tab;
+  A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
+  A.table = h->tab; A.zero_index = h->tab_n;
   A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
   const unsigned nw = (unsigned)h->nwaves;
@@ -1228,7 +1231,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   for (int i = 1; i < nr; i++) if (!(a->radius[i] > a->radius[i-1])) return fail(h, TRX_E_ARG, "radii must ascend");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
-  const bool eager = o->eager != 0, prof = o->profile != 0;
+  const bool eager = o->eager != 0, prof = o->profile != 0, count = o->profile >= 2;
   // A handle remembers how deep the previous spectrum went (hint_layers) and plans its steps to
   // end exactly there; the run returns at that depth and goes on only if rays are still open.
   const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
@@ -1338,7 +1341,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
           hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
       h->ev_ac.push_back(e1); h->ev_cb.push_back(e2);
     }
-  if (prof && any_wide && (rc = ensure(h, h->d_part3, 24 * (size_t)kMaxChunk * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
+  if (count && any_wide && (rc = ensure(h, h->d_part3, 24 * (size_t)kMaxChunk * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
     return rc;
   if ((rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh))) return rc;
   // ---- per-run inputs: one pinned block, one transfer ------------------------------------
@@ -1495,7 +1498,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     } else {
       SweepMode M{};
       bool walked = false;
-      M.eager = eager; M.prof = prof; M.ethresh = o->ethresh;
+      M.eager = eager; M.prof = count; M.ethresh = o->ethresh;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
       M.d_e = h->d_e.as<double>(); M.d_kmax = h->d_kmax.as<double>(); M.d_sticky = h->d_sticky.as<int>();
       M.st = st_sweep;
@@ -1587,13 +1590,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- results back -----------------------------------------------------------
   {   // one copy into pinned memory: flags, status and (profiled runs) the counters
-    const size_t nb = prof ? 128 + 24 * (size_t)nr : 128;
+    const size_t nb = count ? 128 + 24 * (size_t)nr : 128;
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
     if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));
     std::memcpy(status_host, (const char *)h->h_small + 64, sizeof(status_host));
-    if (prof) std::memcpy(counters.data(), (const char *)h->h_small + 128, 24 * (size_t)nr);
+    if (count) std::memcpy(counters.data(), (const char *)h->h_small + 128, 24 * (size_t)nr);
     else std::fill(counters.begin(), counters.end(), 0ull);
   }
   // rays still descending below the expected depth (the atmosphere changed): go on from there

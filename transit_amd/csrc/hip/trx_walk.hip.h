@@ -257,6 +257,8 @@ constexpr int kWalkLayers = 64;      // layers per step = lanes
 constexpr double kRebaseSpan = 0.03125;     // cm-1
 constexpr double kWalkMinTemp = 1.4387752 * kRebaseSpan * 256.0 * 1.05;
 
+constexpr int kWalkMaxFrame = 16;    // bins of the widest frame (k_line_walk<16>)
+
 // trx_create builds the records on the device from the line and group arrays it has just uploaded
 __global__ __launch_bounds__(256)
 void k_walk_records(long long n, const double *__restrict__ wavn, const double *__restrict__ elow, const double *__restrict__ gf,
@@ -306,7 +308,9 @@ struct WalkArgs {
   const int *sticky_idop;           // [layer][iso]
   const double *dthr;               // [ndop + 1] steps of the nearest-Doppler-index function
   const double *e2tab;              // [64]
-  const int32_t *psize; const long long *poff; const float *table;
+  const int32_t *psize; const long long *poff;
+  long long zero_index;             // index (in `table`) where kWalkMaxFrame*osamp zeros begin
+  const float *table;               // the Voigt table, followed by kWalkMaxFrame cells of zeros (k_table_padded)
   double *part;                     // [records][64]
   unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
   const int *flags; const int *last; int eager;
@@ -379,7 +383,7 @@ void k_line_walk(WalkArgs A)
   double thr_lo = s_thr[lo_i];
   int ps_cur = A.psize[lo_i * A.nlor + il];
   unsigned vo_cur = 4u * (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);   // byte offset of the profile centre
-  const unsigned vo_st4 = 4u * vo_st;
+  const unsigned vo_st8 = 4u * vo_st;
 
   double acc[NB];
 #pragma unroll
@@ -413,10 +417,21 @@ void k_line_walk(WalkArgs A)
   for (int k = 0; k < NB; k++) pv_p[k] = 0.f;
   auto settle = [&]() {
 #pragma unroll
-    for (int k = 0; k < NB; k++) acc[k] += kk_p * (double)pv_p[k];     // :507 (two roundings, as compiled there)
+    for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);     // :507
     pend = false;
   };
-  const char *tab_bytes = (const char *)A.table;
+  // Slot k reads the table at (profile centre) + d, d = (k - Rc)*osamp - imod.  The part of d that
+  // does not depend on the group goes into a per-slot base pointer (wave-uniform, set up once),
+  // the rest into ONE per-lane offset per group, kept >= 0 by moving a whole cell into the
+  // pointer: entry = tab_k[k] + (vo8 - 8*imod + 8*osamp).  A lane the slot does not reach reads
+  // zero padding instead -- at the same offset vzero for every slot: the widened table ends in
+  // kWalkMaxFrame cells of zeros, slot k lands k cells into them.  No branch, no mask, one load
+  // per slot.
+  const char *tab_k[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) tab_k[k] = (const char *)A.table + 4LL * (k - Rc - 1) * A.osamp;
+  const unsigned vzero = 4u * (unsigned)(A.zero_index + (long long)(Rc + 1) * A.osamp);
+  const unsigned cell8 = 4u * (unsigned)A.osamp;
 
   // line records through the scalar cache: the address is wave-uniform and the data constant
   typedef const __attribute__((address_space(4))) double *ScalarF64;
@@ -473,7 +488,7 @@ void k_line_walk(WalkArgs A)
         }
         const bool own = wav_a >= wc;
         const int ps = own ? ps_cur : ps_st;
-        const unsigned vo4 = own ? vo_cur : vo_st4;
+        const unsigned vo8 = own ? vo_cur : vo_st8;
         const bool act = valid && !below;
         if (pend) settle();
         // ---- move the frame down to the group's cell
@@ -498,13 +513,14 @@ void k_line_walk(WalkArgs A)
         // (a bin outside the shard may be accumulated too: it never leaves the frame, see flush)
         kk_p = kk;
         pend = true;
+        const int ps_act = act ? ps : -1;                       // a lane that sits out reaches no slot
+        const unsigned vbase = vo8 + cell8 - 4u * (unsigned)imod;
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-          const int d = (k - Rc) * A.osamp - imod;              // wave-uniform
-          const bool ok = act && (d < 0 ? -d : d) <= ps;
-          float pv = 0.f;
-          if (ok) pv = *(const float *)(tab_bytes + (vo4 + 4u * (unsigned)d));     // 32-bit byte offset (table < 4 GB)
-          pv_p[k] = pv;
+          // |d| with the sign known per slot: d <= 0 up to the centre slot, > 0 beyond (imod < osamp)
+          const int dist = k <= Rc ? (Rc - k) * A.osamp + imod : (k - Rc) * A.osamp - imod;      // wave-uniform
+          const bool ok = dist <= ps_act;
+          pv_p[k] = *(const float *)(tab_k[k] + (ok ? vbase : vzero));
           if (PROF && ok && cell - Rc + k >= lo32 && cell - Rc + k < hi32) nb++;
         }
       }
