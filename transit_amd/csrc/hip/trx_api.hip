@@ -446,7 +446,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   if (h->walk_ok) {
     int ngw = 32;
     if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
-    else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 8192) ngw *= 2;
+    else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;     // ~2 rounds of resident waves: the hardware balances them
     h->ngw = ngw;
     h->h_wbase.assign(s->niso + 1, 0);
     for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
@@ -802,11 +802,11 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   const size_t pbytes = sizeof(double) * kWalkLayers * (size_t)std::max<int64_t>(pl->records, 1);
   if (part.bytes < pbytes) {
     HIPCHK(h, hipStreamSynchronize(st));                 // an earlier step may still be using the old buffer
-    if (st_comb) HIPCHK(h, hipStreamSynchronize(st_comb));
+    HIPCHK(h, hipStreamSynchronize(h->stream4));          // (combines of earlier steps run there)
     if ((rc = ensure(h, part, pbytes))) return rc;
   }
   // this buffer's previous records (two steps ago) must have been combined
-  if (st_comb && ev_reuse) HIPCHK(h, hipStreamWaitEvent(st, ev_reuse, 0));
+  if (ev_reuse) HIPCHK(h, hipStreamWaitEvent(st, ev_reuse, 0));
   if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
   WalkArgs A{};
   A.lines = h->d_walk.as<WalkLine>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
@@ -1366,7 +1366,20 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
   // the whole front end of a run goes to the stream the line sweep runs on (the main stream
   // joins it at the first optical depth): no cross-stream hop before the first sweep kernel
-  hipStream_t st_sweep = pipelined ? h->stream4 : st;
+  // Streams.  The front end (inputs, layer maxima), the walks and everything that follows the
+  // LAST walk of the plan -- its combine, optical depth, the spectrum, the copies back -- sit on
+  // ONE queue: that chain is the critical path, and a hop between queues costs it ~30 us of
+  // signalling.  The combines and optical depths of the earlier steps go to a second queue, where
+  // they overlap the next step's walk.
+  hipStream_t st_sweep = st;
+  hipStream_t st_early = pipelined ? h->stream4 : st;
+  bool early_dirty = false;                    // work queued on st_early that st has not waited for
+  auto join_early = [&]() -> int {
+    if (!early_dirty) return TRX_OK;
+    if (hipEventRecord(h->ev_join, st_early) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+    early_dirty = false;
+    return TRX_OK;
+  };
   HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep));
   // With lines, every element of e the path reads is written first (the accumulation kernels
   // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
@@ -1425,7 +1438,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // ---- inputs are on their way: release the other streams --------------------------------
   HIPCHK(h, hipEventRecord(h->ev_inputs, st_sweep));
   HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
-  if (pipelined) HIPCHK(h, hipStreamWaitEvent(st, h->ev_inputs, 0));
+  if (pipelined) HIPCHK(h, hipStreamWaitEvent(st_early, h->ev_inputs, 0));
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
   if (!h->has_grid &&
       (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, true))) return rc;
@@ -1485,6 +1498,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       nb = std::max(nb, v);
     }
     if (!nb && !h->has_grid && nc > sg_layers) nc = sg_layers;
+    // the plan's last step (bottom reached, or the depth the previous spectrum needed): its
+    // combine and optical depth stay on the walk's queue
+    const bool last_step = r_top - nc < 0 || (stop_at_hint && nr - 1 - (r_top - nc) >= h->hint_layers);
+    hipStream_t st_tau = (pipelined && !last_step) ? st_early : st;
     if (h->has_grid) {
       if (prof && spans.begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
       GridArgs Gd{};
@@ -1504,7 +1521,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       M.st = st_sweep;
       if (h->ngroups > 0) {
         if (nb) {
-          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, pipelined ? st : nullptr, h->ev_ac[nchunks],
+          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, st_tau != st ? st_tau : nullptr, h->ev_ac[nchunks],
                           nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()]);
           nwalks++;
         }
@@ -1512,16 +1529,18 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         if (rc) return rc;
         walked = nb != 0;
       }
-      if (pipelined && !walked) {     // the optical depth of this step follows its extinction
-        HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], h->stream4));
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_ac[nchunks], 0));
+      if (st_tau != st && !walked) {     // the optical depth of this step follows its extinction
+        HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], st));
+        HIPCHK(h, hipStreamWaitEvent(st_tau, h->ev_ac[nchunks], 0));
       }
     }
     if (nchunks == 0) {
       if ((rc = queue_cia())) return rc;
-      HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+      HIPCHK(h, hipStreamWaitEvent(st_tau, h->ev_cia, 0));
     }
-    if (prof && spans.begin(Spans::kTau, st)) return fail(h, TRX_E_HIP, "event");
+    if (st_tau == st) { if ((rc = join_early())) return rc; }       // the optical depths of the earlier steps
+    else early_dirty = true;
+    if (prof && spans.begin(Spans::kTau, st_tau)) return fail(h, TRX_E_HIP, "event");
     for (int done = 0; done < nc; ) {          // optical depth in sub-steps of at most tau_cap layers
       int nt = std::min(tau_cap, nc - done);
       if (swept == 0 && done == 0) nt = std::min(nc, std::max(nt, 3));
@@ -1543,16 +1562,16 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
         const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
         const dim3 grid((unsigned)std::min<int64_t>((nsh + (small ? 63 : 255)) / (small ? 64 : 256), kTauMaxBlocks)), block(small ? 64 : 256);
-        if (small && extras)       hipLaunchKernelGGL((k_optical_depth_vertical<true, true>), grid, block, 0, st, T);
-        else if (small)            hipLaunchKernelGGL((k_optical_depth_vertical<true, false>), grid, block, 0, st, T);
-        else if (extras)           hipLaunchKernelGGL((k_optical_depth_vertical<false, true>), grid, block, 0, st, T);
-        else                       hipLaunchKernelGGL((k_optical_depth_vertical<false, false>), grid, block, 0, st, T);
+        if (small && extras)       hipLaunchKernelGGL((k_optical_depth_vertical<true, true>), grid, block, 0, st_tau, T);
+        else if (small)            hipLaunchKernelGGL((k_optical_depth_vertical<true, false>), grid, block, 0, st_tau, T);
+        else if (extras)           hipLaunchKernelGGL((k_optical_depth_vertical<false, true>), grid, block, 0, st_tau, T);
+        else                       hipLaunchKernelGGL((k_optical_depth_vertical<false, false>), grid, block, 0, st_tau, T);
       } else
         hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
-                           dim3(256), 0, st, T);
+                           dim3(256), 0, st_tau, T);
       done += nt;
     }
-    if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
+    if (prof && spans.end(st_tau)) return fail(h, TRX_E_HIP, "event");
     r_top -= nc; nchunks++;
     // the previous spectrum stopped here: compute the spectrum now and look at the outcome
     // on the host (which this call waits for anyway) instead of queueing gated no-op steps
@@ -1560,6 +1579,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
 
   // ---- spectrum ---------------------------------------------------------------
+  if ((rc = join_early())) return rc;
   if (resumed) HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes the spectrum a second time)
   if (o->solution == TRX_SOL_ECLIPSE) {
     EmisArgs E{};
@@ -1573,17 +1593,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
     }
     E.intens = h->d_intens.as<double>(); E.flux = d_out;
-    hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + 15) / 16)), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + kEmisWaves - 1) / kEmisWaves)), dim3(64 * kEmisWaves), 0, st, E);
   } else {
     ModArgs M{};
     M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
     M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
     M.ip = d_ipv; M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
     hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
-  }
-  if (pipelined) {   // nothing of this run may still be in flight on the sweep stream when it returns
-    HIPCHK(h, hipEventRecord(h->ev_join, h->stream4));
-    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(ev.b, st));

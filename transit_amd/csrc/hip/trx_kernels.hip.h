@@ -1253,40 +1253,65 @@ struct EmisArgs {
 };
 
 // eclipse.c:118-160 (eclipse_intens) + eclipse.c:243-287 (flux).
-// Block = 16 wavenumbers x 16 angle slots: one lane per (wavenumber, angle)
-// integrates the intensity, then the angle-0 lanes add the flux in angle order.
-__global__ __launch_bounds__(256)
+// One wavefront per wavenumber, lanes = heights: every lane evaluates the Planck function and
+// the nang attenuations exp(-tau/cos) of its own height, takes its upper neighbour's through a
+// lane shift, and the trapezoid terms (numerical.c:168-170) are added over the wave in a fixed
+// butterfly order.  (The ray's ~80 heights used to be one lane's serial loop of ~500 dependent
+// exponentials: 38 us of pure latency at the end of every spectrum.)
+constexpr int kEmisWaves = 4;
+
+__global__ __launch_bounds__(64 * kEmisWaves)
 void k_emission(EmisArgs E)
 {
   latency_critical();
-  __shared__ double s_I[kMaxAngles][16];
-  const int wi = threadIdx.x % 16, a = threadIdx.x / 16;
-  const long long w = (long long)blockIdx.x * 16 + wi;
-  const bool ok = w < E.nsh;
-  if (ok && a < E.nang) {
-    const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
-    const int last = E.last[w];
-    const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
-    const double pl_exp = kH * wv * kLs;
-    const double ca = E.cosang[a];
-    double Bp = 0, dtp = 0, sum = 0;
-    for (int i = 0; i <= last; i++) {
-      const double tv = E.tau[(long long)i * E.nsh + w];
-      const double B = pl_num / (exp(pl_exp / (kKb * E.temp[E.nr - 1 - i])) - 1.0);
-      const double dt = exp(-tv / ca);
-      if (i > 0) sum += (dt - dtp) * (B + Bp);            // numerical.c:168-170
-      dtp = dt; Bp = B;
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * kEmisWaves + (threadIdx.x >> 6);     // wave-uniform
+  if (w >= E.nsh) return;
+  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
+  const int last = __builtin_amdgcn_readfirstlane(E.last[w]);      // (< 0: the ray is still descending -- provisional spectrum, zero)
+  const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
+  const double pl_exp = kH * wv * kLs;
+  double sum[kMaxAngles], dt_c[kMaxAngles], dt_last[kMaxAngles];
+#pragma unroll
+  for (int a = 0; a < kMaxAngles; a++) { sum[a] = 0.0; dt_c[a] = 0.0; dt_last[a] = 0.0; }
+  double B_c = 0.0, B_last = 0.0;             // carry: the previous pass's last height
+  for (int i0 = 0; i0 <= last; i0 += 64) {
+    const int i = i0 + lane;
+    const bool have = i <= last;
+    double B = 0.0, tv = 0.0;
+    if (have) {
+      tv = E.tau[(long long)i * E.nsh + w];
+      B = pl_num / (exp(pl_exp / (kKb * E.temp[E.nr - 1 - i])) - 1.0);
     }
-    const double I = Bp * dtp - 0.5 * sum;
-    E.intens[(long long)a * E.nsh + w] = I;
-    s_I[a][wi] = I;
+    double Bp = __shfl_up(B, 1, 64);
+    if (lane == 0) Bp = B_c;
+    const int top = min(63, last - i0);        // lane of the pass's last height
+#pragma unroll
+    for (int a = 0; a < kMaxAngles; a++) {
+      if (a < E.nang) {
+        const double dt = have ? exp(-tv / E.cosang[a]) : 0.0;
+        double dtp = __shfl_up(dt, 1, 64);
+        if (lane == 0) dtp = dt_c[a];
+        const double term = (have && i > 0) ? (dt - dtp) * (B + Bp) : 0.0;
+        sum[a] += wave_sum(term);
+        dt_c[a] = readlane_f64(dt, 63);
+        dt_last[a] = readlane_f64(dt, top);
+      }
+    }
+    B_c = readlane_f64(B, 63);
+    B_last = readlane_f64(B, top);
   }
-  __syncthreads();
-  if (ok && a == 0) {
-    double fl = 0.0;
-    for (int k = 0; k < E.nang; k++) fl += kPi * s_I[k][wi] * E.area[k];
-    E.flux[w] = fl;
+  // sum, B_last and dt_last are wave-uniform: lane a writes angle a, lane 0 the flux in angle order
+  double fl = 0.0;
+#pragma unroll
+  for (int a = 0; a < kMaxAngles; a++) {
+    if (a < E.nang) {
+      const double I = B_last * dt_last[a] - 0.5 * sum[a];
+      if (lane == a) E.intens[(long long)a * E.nsh + w] = I;
+      fl += kPi * I * E.area[a];
+    }
   }
+  if (lane == 0) E.flux[w] = fl;
 }
 
 struct ModArgs {
