@@ -1461,6 +1461,11 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventRecord(ev.a, st));
 
   h->stats.walk_steps = 0; h->stats.walk_records = 0;
+  if (!h->has_grid && log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
+    std::string ln = "run: walk frame (bins) per layer, top first; 0 = two-kernel form:";
+    for (int r = nr - 1; r >= 0; r--) ln += " " + std::to_string(walk_frame_bins(h, psmax, r));
+    log_msg(TRX_LOG_DEBUG, ln);
+  }
   // ---- top-down sweep in steps of layers (tau.c:235-290) ----
   int nchunks = 0, nwalks = 0, r_top = nr - 1;
   bool stop_at_hint = stop_at_hint_ok, resumed = false;
@@ -1488,6 +1493,17 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       else if (!nb && !stop_at_hint_ok) cap = std::min(cap, 12);      // depth unknown, expensive layers: small steps
       const int steps = (run + cap - 1) / cap;
       nc = (run + steps - 1) / steps;
+      if (nb && steps > 1 && !user_chunk) {
+        // A walk step costs what its WIDEST layer's frame costs, whatever the number of layers
+        // (<= 64, one per lane), and frames grow with depth.  So this step takes the layers it
+        // cannot leave to the later steps, and then as many more as share their frame: the wide
+        // frames further down are paid for by as few lanes as possible.
+        const int must = run - (steps - 1) * cap;
+        int f = 0;
+        for (int c = 0; c < must; c++) f = std::max(f, walk_frame_bins(h, psmax, r_top - c));
+        nc = must;
+        while (nc < cap && nc < run && walk_frame_bins(h, psmax, r_top - nc) <= f) nc++;
+      }
       if (nb) for (int c = 1; c < nc; c++) nb = std::max(nb, walk_frame_bins(h, psmax, r_top - c));
     }
     if (swept == 0) nc = std::max(nc, 3);          // the first step holds the 2- and 3-point rays (eclipse.c:65-80)
