@@ -83,9 +83,15 @@ def measured_traffic(kernel):
             d = json.load(open(f))
             if d.get("kernel_sources") != kernel_source_hash():
                 continue
+            # every production instantiation of the kernel (k_line_walk<2|4|8|16, false>), weighted by
+            # its launches: the per-launch average a kernel trace reports for the kernel as a whole
+            tot = n = 0.0
             for name, k in d["kernels"].items():
-                if kernel in name:
-                    return float(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+                if kernel in name and ", true>" not in name:
+                    tot += float(k["hbm_bytes_per_launch"]) * k["launches_FETCH_pass"]
+                    n += k["launches_FETCH_pass"]
+            if n:
+                return tot / n, os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
