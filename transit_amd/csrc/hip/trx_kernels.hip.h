@@ -4,9 +4,11 @@
 // dense contraction, hence no MFMA.  Wavefront = 64 lanes.
 //
 //   k_voigt_bins / k_voigt_bins_wave  Voigt-profile table      (opacity.c:219-277, voigt.c)
-//   k_group_sweep                     passes 1+2a: co-added group strength, Doppler
-//                                     index, layer maximum      (extinction.c:399-483)
-//   k_sticky_index                    sticky Doppler index      (extinction.c:393, 480-483)
+//   (the line sweep of layers whose profiles reach <= 7 cells is trx_walk.hip.h: k_line_walk)
+//   k_group_sweep                     two-kernel form, wider profiles: passes 1+2a, co-added
+//                                     group strength and Doppler index (extinction.c:399-483)
+//   k_sticky_index                    sticky Doppler index, all layers of a run up front
+//                                                               (extinction.c:393, 480-483)
 //   k_accumulate                      pass 2b: threshold + profile accumulation into
 //                                     e[layer][wn], gather per 4-bin tile (extinction.c:467-509)
 //   k_accumulate_wide                 the same for profiles >= 64 coarse bins: lanes own bins,
@@ -16,7 +18,9 @@
 //   k_optical_depth(_vertical)        total extinction + ray quadrature + toomuch cut
 //                                                               (tau.c:216-305, eclipse.c:29-105,
 //                                                                slantpath.c:19-108)
-//   k_emission / k_modulation         spectrum from tau         (eclipse.c:118-287, slantpath.c:351-473)
+//   k_extras_dump                     scattering / cloud terms alone (savefiles dumps, tau.c:180-190)
+//   k_emission / k_modulation         spectrum from tau         (eclipse.c:118-287, slantpath.c:351-473);
+//                                     k_emission: one wave per wavenumber, lanes = heights
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
