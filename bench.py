@@ -76,7 +76,7 @@ def measured_traffic(kernel):
     (profiles/*pmc_traffic*.json; FETCH_SIZE / WRITE_SIZE from separate --pmc passes, corrected as
     MI355X_MICROARCH.md prescribes) -- quoted ONLY when that summary was collected from the kernel
     sources of this tree (its `kernel_sources` fingerprint); otherwise None: a stale number is
-    worse than none.  Returns (bytes_per_launch, file) or (None, None)."""
+    worse than none.  Returns ((corrected, uncorrected) bytes per launch, file) or (None, None)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
@@ -85,13 +85,14 @@ def measured_traffic(kernel):
                 continue
             # every production instantiation of the kernel (k_line_walk<2|4|8|16, false>), weighted by
             # its launches: the per-launch average a kernel trace reports for the kernel as a whole
-            tot = n = 0.0
+            tot = raw = n = 0.0
             for name, k in d["kernels"].items():
                 if kernel in name and ", true>" not in name:
                     tot += float(k["hbm_bytes_per_launch"]) * k["launches_FETCH_pass"]
+                    raw += float(k.get("hbm_bytes_per_launch_uncorrected", 0.0)) * k["launches_FETCH_pass"]
                     n += k["launches_FETCH_pass"]
             if n:
-                return tot / n, os.path.relpath(f, ROOT)
+                return (tot / n, raw / n), os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
@@ -350,7 +351,8 @@ def main():
         # per-(wn, layer) arrays, the outputs).  Rank 0's share x world for the job.
         b_alg_run = world * (52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
         b_min_run = world * (52.0 * L + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
-        traffic, traffic_file = measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else (None, None)
+        tr_pair, traffic_file = measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else (None, None)
+        traffic, traffic_raw = tr_pair if tr_pair else (None, None)
         out = {
             "metric": "wavenumber-points*layers/sec (CH4 2-4um emission spectrum)",
             "value": nwn * layers_needed / (ms_step * 1e-3),
@@ -386,7 +388,7 @@ def main():
                        "line_layer_bins_per_s": world * stats["sum_bins"] / (ms_step * 1e-3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_file,
+                         "traffic": traffic, "traffic_uncorrected": traffic_raw, "traffic_source": traffic_file,
                          "bmin_frac": b_min_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "balg_frac": b_alg_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,

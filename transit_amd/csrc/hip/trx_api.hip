@@ -1219,6 +1219,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 {
   if (!h || !a || !o) return TRX_E_ARG;
   const auto t_host0 = std::chrono::steady_clock::now();
+  auto t_host_queued = t_host0;
   const int nr = a->nlayer, nmol = h->nmol;
   const int64_t nsh = h->nsh;
   if (nr < 3) return fail(h, TRX_E_ARG, "at least three layers are needed");
@@ -1272,10 +1273,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
 
   // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
-  const int gstride = 4 * (nr / 2 + 1);
-  std::vector<double> geom((size_t)(nr + 1) * gstride * 2 + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr, 0.0);
+  // (eclipse geometry uses tabulated weights for its one three-point ray only: rows of one pair,
+  // no modulation table -- 9 KB instead of 330 KB to build, copy and ship per run at 100 layers)
+  const bool vertical = o->solution == TRX_SOL_ECLIPSE;
+  const int gstride = vertical ? 4 : 4 * (nr / 2 + 1);
+  const size_t mw_doubles = vertical ? 0 : (size_t)(nr + 1) * gstride;
+  std::vector<double> geom((size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr, 0.0);
   double *gw = &geom[0], *gh0 = gw + (size_t)(nr + 1) * gstride;
-  double *mw = gh0 + (nr + 1), *mh0 = mw + (size_t)(nr + 1) * gstride;
+  double *mw = gh0 + (nr + 1), *mh0 = mw + mw_doubles;
   double *pw = mh0 + (nr + 1);            // pair weights by starting layer (vertical rays)
   double *hrs = pw + 4 * (size_t)nr, *hr0 = hrs + nr;     // slant rays: bracket layer and closest approach per height
   {
@@ -1380,7 +1385,17 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     early_dirty = false;
     return TRX_OK;
   };
+  const auto t_host_prep = std::chrono::steady_clock::now();
+  const bool lap_on = log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG;
+  std::string laps; auto t_lap = t_host_prep;
+  auto lap = [&](const char *what) {
+    if (!lap_on) return;
+    const auto n = std::chrono::steady_clock::now();
+    char b[64]; std::snprintf(b, sizeof b, " %s %.0f", what, 1e3 * std::chrono::duration<double, std::milli>(n - t_lap).count());
+    laps += b; t_lap = n;
+  };
   HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep));
+  lap("h2d");
   // With lines, every element of e the path reads is written first (the accumulation kernels
   // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
   // in-range line (empty list, all lines outside the band, a CIA-only run) no kernel writes
@@ -1399,6 +1414,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     const long long nt = std::max<long long>(nsh, 3LL * nr);
     hipLaunchKernelGGL(k_run_init, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st_sweep, R);
   }
+  lap("init");
 
   const double *df = h->d_in.as<double>();
   LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
@@ -1406,7 +1422,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const double *d_press = df + LH.extra_off, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
   const double *d_gw = df + off_geom, *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
-               *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + (size_t)(nr + 1) * gstride, *d_pw = d_mh0 + (nr + 1);
+               *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + mw_doubles, *d_pw = d_mh0 + (nr + 1);
   const double *d_ipv = df + off_ip, *d_ciadens = df + off_cd;
   (void)nli;
 
@@ -1442,6 +1458,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
   if (!h->has_grid &&
       (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, true))) return rc;
+  lap("kmax");
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
   // after that step's kernels, which are what the GPU is waiting for.
@@ -1550,8 +1567,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         HIPCHK(h, hipStreamWaitEvent(st_tau, h->ev_ac[nchunks], 0));
       }
     }
+    lap("sweep");
     if (nchunks == 0) {
       if ((rc = queue_cia())) return rc;
+      lap("cia");
       HIPCHK(h, hipStreamWaitEvent(st_tau, h->ev_cia, 0));
     }
     if (st_tau == st) { if ((rc = join_early())) return rc; }       // the optical depths of the earlier steps
@@ -1588,6 +1607,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       done += nt;
     }
     if (prof && spans.end(st_tau)) return fail(h, TRX_E_HIP, "event");
+    lap("tau");
     r_top -= nc; nchunks++;
     // the previous spectrum stopped here: compute the spectrum now and look at the outcome
     // on the host (which this call waits for anyway) instead of queueing gated no-op steps
@@ -1625,6 +1645,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     const size_t nb = count ? 128 + 24 * (size_t)nr : 128;
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
     if (spectrum) HIPCHK(h, hipMemcpyAsync(spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
+    lap("spectrum+copies");
+    t_host_queued = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(st));
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));
     std::memcpy(status_host, (const char *)h->h_small + 64, sizeof(status_host));
@@ -1645,6 +1667,14 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   float ms = 0; (void)hipEventElapsedTime(&ms, ev.a, ev.b); S.ms_run_total = ms;
   S.ms_cia = ms_cia;
   S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+  if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
+    char b[160];
+    std::snprintf(b, sizeof b, "run: host %.0f us preparing inputs, %.0f us queueing, %.0f us waiting for the device",
+                  1e3 * std::chrono::duration<double, std::milli>(t_host_prep - t_host0).count(),
+                  1e3 * std::chrono::duration<double, std::milli>(t_host_queued - t_host_prep).count(),
+                  1e3 * (S.ms_host_total - std::chrono::duration<double, std::milli>(t_host_queued - t_host0).count()));
+    log_msg(TRX_LOG_DEBUG, std::string(b) + "; queueing by phase (us):" + laps);
+  }
   S.ms_k_sweep = S.ms_k_sticky = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
   if (prof) {
     // every launch counts (also the ~4 us gated ones after all rays stopped), so that
