@@ -73,11 +73,9 @@ CASES = {
     # (reloadatm + radpress + makeradsample, readatm.c:722-865); see oracle/ref_reentry_main.c
     "reentry": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="eclipse", seed=55,
                     reentry=True, extra={"refpress": "0.1", "gsurf": "1000.0"}),
-    # same in transmission geometry.  Kept with a LOOSE tolerance on purpose: with the
-    # hydrostatic radii of radpress() the reference's impact parameter b = r*fct/fct does not
-    # always round back to r, its bracket search (slantpath.c:36) then lands one layer low
-    # and reads the extinction of a layer its lazy sweep may not have filled yet
-    # (tau.c:238-274) -- a wavenumber-order-dependent 1e-4 effect
+    # same in transmission geometry: the case that exposed the reference's compiled form of
+    # tau.c:274, b = (h*hfct)*(1/rfct); the radii after every radpress()
+    # are kept too (<prefix>N_radii.dat)
     "reentry_transit": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="transit", seed=55,
                             reentry=True, extra={"refpress": "0.1", "gsurf": "1000.0"}),
     # abundance scaling while the atmosphere is read (qmol/qscale, readatm.c:394-405, 519-540:
@@ -97,6 +95,12 @@ CASES = {
                           extra={"cloudtop": "-1.5", "scattering": "1.5", "outsample": "sample.dat",
                                  "detailext": "detail_ext.dat:3001,3015.5", "detailtau": "detail_tau.dat:3029.9",
                                  "detailcia": "detail_cia.dat:3000,3030"}),
+    # radius resampling (makesample.c:144-300, 409-549): layers every 400 km instead of the
+    # atmosphere file's own sampling, T / p / abundances / partition functions splined onto them
+    "resample_radius": dict(nlines=2000, wnlow=2500, wnhigh=2530, nlayers=25, solution="eclipse", seed=71,
+                            extra={"raddelt": "400"}),
+    "resample_transit": dict(nlines=2000, wnlow=2500, wnhigh=2530, nlayers=25, solution="transit", seed=72, ncia=2,
+                             extra={"raddelt": "350", "radlow": "93500"}),
     "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
                        solution="transit", seed=17, ncia=2),
 }
