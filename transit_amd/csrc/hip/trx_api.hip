@@ -88,7 +88,7 @@ struct trx_handle {
   std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
   bool walk_temp_ok = true;         // this run's layers are all warmer than kWalkMinTemp
   struct Plan { bool built = false; DevBuf blo, bhi, off; int64_t records = 0; };
-  Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
+  Plan plan[4];                                             // NB = 2, 4, 8 bins per frame (slot 3 spare)
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw; };
   std::vector<Cia> cia;
@@ -752,7 +752,9 @@ int walk_frame_bins(const trx_handle *h, const int32_t *psmax, int r)
 {
   if (!h->walk_ok || !h->walk_temp_ok) return 0;
   const long long rc = layer_psmax(h, psmax, r) / h->osamp;
-  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : rc <= 7 ? 16 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
+  // (a 16-bin frame was measured too: per wide layer it costs more than the two-kernel form at
+  // any layer count -- 1.4 ms against ~0.4 ms for the 9 such layers of configs[2])
+  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
 }
 
 // plan of the line ranges for a frame of nb bins (built once per handle and frame size)
@@ -823,8 +825,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   if (nw > 0) {
     if (nb == 2) launch_walk<2>(A, M.prof, nw, st);
     else if (nb == 4) launch_walk<4>(A, M.prof, nw, st);
-    else if (nb == 8) launch_walk<8>(A, M.prof, nw, st);
-    else launch_walk<16>(A, M.prof, nw, st);
+    else launch_walk<8>(A, M.prof, nw, st);
   }
   if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
   hipStream_t sc = st_comb ? st_comb : st;

@@ -4,7 +4,7 @@
 // dense contraction, hence no MFMA.  Wavefront = 64 lanes.
 //
 //   k_voigt_bins / k_voigt_bins_wave  Voigt-profile table      (opacity.c:219-277, voigt.c)
-//   (the line sweep of layers whose profiles reach <= 7 cells is trx_walk.hip.h: k_line_walk)
+//   (the line sweep of layers whose profiles reach <= 3 cells is trx_walk.hip.h: k_line_walk)
 //   k_group_sweep                     two-kernel form, wider profiles: passes 1+2a, co-added
 //                                     group strength and Doppler index (extinction.c:399-483)
 //   k_sticky_index                    sticky Doppler index, all layers of a run up front
