@@ -81,8 +81,9 @@ struct trx_handle {
   void *comm = nullptr; int nranks = 1, rank = 0;          // RCCL communicator: only trx_gather uses it
   bool windowed() const { return lo > 0 || hi < nwn; }    // a shard sweeps only the lines that can reach it
   // candidates for the layer maximum (k_cand_*): indices into the line arrays; -1 = use every line
-  DevBuf d_cand; int64_t ncand = -1;
-  DevBuf d_kmax;                                            // [layer][nmx] strongest single line of the run
+  DevBuf d_cand, d_candrec; int64_t ncand = -1;             // candidate line indices / their packed line data
+  DevBuf d_kmax;                                            // [2][layer] (runs alternate; k_layer_max) / [layer][nmx] (per-molecule sweeps)
+  int kmax_parity = 0, kmax_nr = 0; bool kmax_clean = false;   // clean: the half the next run will use is zero
   // the walk (k_line_walk): one record per line, line ranges of ngw groups, plans per profile reach
   DevBuf d_walk, d_wbase, d_part[2];   // partial records: consecutive steps alternate
   std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
@@ -444,9 +445,13 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   // (32-bit byte offsets into the widened table: 8*tab_n + 64*osamp must stay below 2^32)
   h->walk_ok = s->osamp < (1 << 21) && h->tab_n < ((int64_t)1 << 28) && !gfirst.empty();
   if (h->walk_ok) {
+    // Groups per range: ~2 rounds of resident waves (the hardware balances the rounds).  Taken from
+    // the WHOLE list, not from what reaches this shard: the range size is part of the order of the
+    // sums, and a shard's spectrum must be the same bits as the unsharded one.  (Shorter ranges for
+    // small shards were measured: 1/8 of the demo 0.267 -> 0.259 ms with 32, slower with 16.)
     int ngw = 32;
     if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
-    else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;     // ~2 rounds of resident waves: the hardware balances them
+    else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;
     h->ngw = ngw;
     h->h_wbase.assign(s->niso + 1, 0);
     for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
@@ -501,7 +506,13 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     HIPCHK(h, hipMemcpyAsync(&nc, d_n.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
-    if (nc > 0 && nc <= cap) h->ncand = nc;
+    if (nc > 0 && nc <= cap) {
+      h->ncand = nc;
+      if ((rc = ensure(h, h->d_candrec, sizeof(CandLine) * (size_t)nc))) return rc;
+      hipLaunchKernelGGL(k_cand_pack, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, nc, h->d_cand.as<int32_t>(),
+                         L.wavn, L.elow, L.gf, L.iso, L.inrange, h->d_candrec.as<CandLine>());
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
   }
   h->stats.ncandidates = h->ncand;
   T.lap("candidates");
@@ -788,12 +799,32 @@ void launch_walk(const WalkArgs &A, bool prof, unsigned nwaves, hipStream_t st)
   else      hipLaunchKernelGGL((k_line_walk<NB, false>), grid, block, 0, st, A);
 }
 
+// A combine whose launch has been put off (the host queues the NEXT step's walk first, so that the
+// walks sit back to back on their queue whatever else this step still has to queue).
+struct PendingCombine {
+  bool valid = false;
+  CombineArgs C{}; hipStream_t sc = nullptr, st_walk = nullptr; hipEvent_t ev_walk = nullptr, ev_done = nullptr; bool cross = false;
+};
+
+int launch_combine(trx_handle *h, PendingCombine &pc, Spans *sp)
+{
+  if (!pc.valid) return TRX_OK;
+  pc.valid = false;
+  if (pc.cross) HIPCHK(h, hipStreamWaitEvent(pc.sc, pc.ev_walk, 0));
+  if (sp && sp->begin(Spans::kAccum, pc.sc)) return fail(h, TRX_E_HIP, "event");
+  hipLaunchKernelGGL(k_walk_combine, dim3((unsigned)((h->nsh + kCombineBins - 1) / kCombineBins)), dim3(64 * kCombineBins), 0, pc.sc, pc.C);
+  if (sp && sp->end(pc.sc)) return fail(h, TRX_E_HIP, "event");
+  if (pc.cross && pc.ev_done) HIPCHK(h, hipEventRecord(pc.ev_done, pc.sc));
+  return TRX_OK;
+}
+
 // The walk: layers r_top .. r_top-nc+1 (nc <= 64) in one kernel on M.st, then the combine of its
 // partial sums on st_comb (the stream the optical depth runs on; null: M.st).  Consecutive steps
 // alternate between two record buffers, so that the next step's walk does not wait for this
 // step's combine.
 int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, int r_top, int nc, const SweepMode &M, Spans *sp,
-               int parity, hipStream_t st_comb, hipEvent_t ev_walk, hipEvent_t ev_reuse = nullptr, hipEvent_t ev_done = nullptr)
+               int parity, hipStream_t st_comb, hipEvent_t ev_walk, hipEvent_t ev_reuse = nullptr, hipEvent_t ev_done = nullptr,
+               PendingCombine *defer = nullptr /* non-null: the combine is handed back instead of launched */)
 {
   hipStream_t st = M.st ? M.st : h->stream;
   WalkPlan P{}; trx_handle::Plan *pl = nullptr;
@@ -821,27 +852,43 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.table = h->tab; A.zero_index = h->tab_n;
   A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
-  const unsigned nw = (unsigned)h->nwaves;
+  // a shard launches only the ranges that can reach it: per isotope block the groups whose cells
+  // lie within Rc + 1 cells of [lo, hi) are one run of consecutive ranges (cnt_ge look-up)
+  unsigned nw = (unsigned)h->nwaves;
+  A.nseg = 0;
+  if (h->windowed() && h->niso <= kWalkSegs && nw > 0) {
+    const int Rc = nb / 2 - 1;
+    const long long klo = std::max<long long>(0, h->lo - Rc - 1), khi = std::min<long long>(h->nwn - 1, h->hi - 1 + Rc);
+    int cum = 0, ns = 0;
+    for (int b = 0; b < h->niso; b++) {
+      const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
+      if (gb0 == gb1) continue;
+      const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
+      const int ga = cg[khi + 1], gz = cg[klo];                 // groups of the block (descending cells) with cell in [klo, khi]
+      if (gz <= ga) continue;
+      const int wa = h->h_wbase[b] + ga / h->ngw, wz = h->h_wbase[b] + (gz + h->ngw - 1) / h->ngw;
+      A.seg_w0[ns] = wa; A.seg_cum[ns] = cum; cum += wz - wa; ns++;
+    }
+    A.seg_cum[ns] = cum; A.nseg = ns;
+    nw = (unsigned)cum;
+    if (ns == 0) { A.nseg = 1; A.seg_w0[0] = 0; A.seg_cum[0] = 0; A.seg_cum[1] = 0; }     // nothing reaches: no wave does anything
+  }
   if (nw > 0) {
     if (nb == 2) launch_walk<2>(A, M.prof, nw, st);
     else if (nb == 4) launch_walk<4>(A, M.prof, nw, st);
     else launch_walk<8>(A, M.prof, nw, st);
   }
   if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
-  hipStream_t sc = st_comb ? st_comb : st;
-  if (st_comb && ev_walk) {
-    HIPCHK(h, hipEventRecord(ev_walk, st));
-    HIPCHK(h, hipStreamWaitEvent(st_comb, ev_walk, 0));
-  }
-  if (sp && sp->begin(Spans::kAccum, sc)) return fail(h, TRX_E_HIP, "event");
-  CombineArgs C{};
+  PendingCombine pc;
+  pc.valid = true; pc.sc = st_comb ? st_comb : st; pc.st_walk = st; pc.cross = st_comb != nullptr && ev_walk != nullptr;
+  pc.ev_walk = ev_walk; pc.ev_done = ev_done;
+  if (pc.cross) HIPCHK(h, hipEventRecord(ev_walk, st));
+  CombineArgs &C = pc.C;
   C.P = P; C.niso = h->niso; C.gblock = h->d_gblock.as<int32_t>(); C.lo = h->lo; C.nsh = h->nsh; C.r_top = r_top; C.nc = nc;
   C.nmx = M.nmx; C.iso_mx = M.d_iso_mx; C.part = part.as<double>(); C.e = M.d_e;
   C.flags = h->d_flags.as<int>(); C.last = A.last; C.eager = M.eager;
-  hipLaunchKernelGGL(k_walk_combine, dim3((unsigned)((h->nsh + kCombineBins - 1) / kCombineBins)), dim3(64 * kCombineBins), 0, sc, C);
-  if (sp && sp->end(sc)) return fail(h, TRX_E_HIP, "event");
-  if (st_comb && ev_done) HIPCHK(h, hipEventRecord(ev_done, sc));
-  return TRX_OK;
+  if (defer) { *defer = pc; return TRX_OK; }
+  return launch_combine(h, pc, sp);
 }
 
 // The two-kernel form (profiles wider than the walk's largest frame): strengths, accumulation.
@@ -926,13 +973,15 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
 
 // Strongest single line and sticky Doppler index of ALL nv layers (states) at once: both depend
 // on the inputs only, not on how far the rays get, so they leave the per-step chain.
+// kmax: [nv][nmx], zero on entry.  init: the run's small buffers, initialised by an extra row of
+// blocks of the first launch (null: none); *init_done tells whether that happened.
 int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_npre, int nv, const double *temp_k,
-                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st, bool zeroed)
+                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st, double *kmax,
+                            const RunInit *init = nullptr, bool *init_done = nullptr)
 {
   int rc;
-  if ((rc = ensure(h, h->d_kmax, sizeof(double) * (size_t)nv * nmx)) || (rc = ensure(h, h->d_sticky, sizeof(int) * (size_t)nv * std::max(h->niso, 1))))
-    return rc;
-  if (!zeroed) HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * (size_t)nv * nmx, st));
+  if (init_done) *init_done = false;
+  if ((rc = ensure(h, h->d_sticky, sizeof(int) * (size_t)nv * std::max(h->niso, 1)))) return rc;
   if (h->ngroups == 0) return TRX_OK;
   // the pruning argument needs c*nu/T well above the rounding of 1 - exp(-c*nu/T) (trx_walk.hip.h)
   bool pruned = h->ncand > 0;
@@ -941,14 +990,18 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
   for (int r0 = 0; r0 < nv; r0 += 32768) {
     const int nr = std::min(32768, nv - r0);
     LayerDev Yr = Y; Yr.negc_over_t += r0; Yr.strength_f += (size_t)r0 * h->niso;
-    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines)), (unsigned)((nr + kLayerMaxGroup - 1) / kLayerMaxGroup)), dim3(64), 0, st,
-                       h->L, Yr, h->niso, nr, pruned ? h->d_cand.as<int32_t>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
-                       (unsigned long long *)(h->d_kmax.as<double>() + (size_t)r0 * nmx));
+    const unsigned ny = (unsigned)((nr + kLayerMaxGroup - 1) / kLayerMaxGroup);
+    const bool with_init = init && r0 == 0;
+    RunInit R{}; R.nsh = -1;
+    if (with_init) { R = *init; *init_done = true; }
+    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines)), ny + (with_init ? 1u : 0u)), dim3(64), 0, st,
+                       h->L, Yr, h->niso, nr, pruned ? h->d_candrec.as<CandLine>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
+                       (unsigned long long *)(kmax + (size_t)r0 * nmx), R, with_init ? (int)ny : -1);
   }
   for (int r0 = 0; r0 < nv; r0 += 4096) {               // one wave per (layer, isotope)
     const int nr = std::min(4096, nv - r0);
     hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nr * h->niso)), dim3(64), 0, st,
-                       h->L, Y, h->niso, r0 + nr - 1, nr, h->d_kmax.as<double>(), nmx, d_iso_mx, ethresh, h->d_adop.as<double>(), h->ndop,
+                       h->L, Y, h->niso, r0 + nr - 1, nr, kmax, nmx, d_iso_mx, ethresh, h->d_adop.as<double>(), h->ndop,
                        h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), 1);
   }
   HIPCHK(h, hipGetLastError());
@@ -1405,16 +1458,24 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st_sweep));
   if (dbg || eager)
     HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st_sweep));
-  if ((rc = ensure(h, h->d_kmax, sizeof(double) * (size_t)nr))) return rc;
+  // the layer maxima of consecutive runs alternate between two arrays: the run's start-up pass
+  // (which rides along with k_layer_max) zeroes the NEXT run's
   {
-    RunInit R{};
-    R.last = h->d_last.as<int>(); R.nsh = nsh; R.acc = h->d_acc.as<double>();
-    R.counters = h->d_counters.as<unsigned long long>(); R.ncounters = 3 * nr;
-    R.kmax = h->d_kmax.as<double>(); R.nkmax = nr;
-    R.status = h->d_status.as<int>(); R.flags = h->d_flags.as<int>(); R.rays = (int)std::min<int64_t>(nsh, 0x7fffffff);
-    const long long nt = std::max<long long>(nsh, 3LL * nr);
-    hipLaunchKernelGGL(k_run_init, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st_sweep, R);
+    const size_t had = h->d_kmax.bytes;
+    if ((rc = ensure(h, h->d_kmax, sizeof(double) * 2 * (size_t)nr))) return rc;
+    if (h->d_kmax.bytes != had || !h->kmax_clean || h->kmax_nr != nr) {
+      HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * 2 * (size_t)nr, st_sweep));
+      h->kmax_parity = 0; h->kmax_nr = nr;
+    }
+    h->kmax_clean = false;               // until this run has got through (an error return leaves the halves in doubt)
   }
+  double *kmax_run = h->d_kmax.as<double>() + (size_t)h->kmax_parity * nr;
+  RunInit R{};
+  R.last = h->d_last.as<int>(); R.nsh = nsh; R.acc = h->d_acc.as<double>();
+  R.counters = h->d_counters.as<unsigned long long>(); R.ncounters = 3 * nr;
+  R.kmax = h->d_kmax.as<double>() + (size_t)(h->kmax_parity ^ 1) * nr; R.nkmax = nr;
+  R.status = h->d_status.as<int>(); R.flags = h->d_flags.as<int>(); R.rays = (int)std::min<int64_t>(nsh, 0x7fffffff);
+  h->kmax_parity ^= 1;
   lap("init");
 
   const double *df = h->d_in.as<double>();
@@ -1457,8 +1518,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
   if (pipelined) HIPCHK(h, hipStreamWaitEvent(st_early, h->ev_inputs, 0));
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
+  bool init_done = false;
   if (!h->has_grid &&
-      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, true))) return rc;
+      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, kmax_run, &R, &init_done))) return rc;
+  if (!init_done) {                      // no line kernel to ride along with (opacity-grid mode, no in-range line)
+    const long long nt = std::max<long long>(nsh, 3LL * nr);
+    hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((nt + 255) / 256, 4096)), dim3(256), 0, st_sweep, R);
+  }
   lap("kmax");
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
@@ -1490,6 +1556,52 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
   std::vector<unsigned long long> counters(3 * (size_t)nr);
   double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
+  struct SideWork { bool active = false, first = false; int r_top = 0, nc = 0, swept = 0; hipStream_t st_tau = nullptr; PendingCombine pc; };
+  SideWork pending;
+  auto run_side = [&](SideWork &S) -> int {
+    int rc = launch_combine(h, S.pc, prof ? &spans : nullptr);
+    if (rc) return rc;
+    if (S.first) {
+      if ((rc = queue_cia())) return rc;
+      lap("cia");
+      HIPCHK(h, hipStreamWaitEvent(S.st_tau, h->ev_cia, 0));
+    }
+    if (S.st_tau == st) { if ((rc = join_early())) return rc; }       // the optical depths of the earlier steps
+    else early_dirty = true;
+    if (prof && spans.begin(Spans::kTau, S.st_tau)) return fail(h, TRX_E_HIP, "event");
+    for (int done = 0; done < S.nc; ) {          // optical depth in sub-steps of at most tau_cap layers
+      int nt = std::min(tau_cap, S.nc - done);
+      if (S.swept == 0 && done == 0) nt = std::min(S.nc, std::max(nt, 3));
+      TauArgs T{};
+      T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
+      T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
+      T.r_top = S.r_top - done; T.nc = nt; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
+      T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
+      T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
+      T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
+      T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
+      T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
+      T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
+      T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
+      T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
+      T.pw = d_pw; T.acc = h->d_acc.as<double>();
+      T.hrs = d_pw + 4 * (size_t)nr; T.hr0 = T.hrs + nr; T.status = h->d_status.as<int>();
+      if (o->solution == TRX_SOL_ECLIPSE) {
+        // small shards: one wave per block spreads the (latency-bound) chains over more CUs
+        const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
+        const dim3 grid((unsigned)std::min<int64_t>((nsh + (small ? 63 : 255)) / (small ? 64 : 256), kTauMaxBlocks)), block(small ? 64 : 256);
+        if (small && extras)       hipLaunchKernelGGL((k_optical_depth_vertical<true, true>), grid, block, 0, S.st_tau, T);
+        else if (small)            hipLaunchKernelGGL((k_optical_depth_vertical<true, false>), grid, block, 0, S.st_tau, T);
+        else if (extras)           hipLaunchKernelGGL((k_optical_depth_vertical<false, true>), grid, block, 0, S.st_tau, T);
+        else                       hipLaunchKernelGGL((k_optical_depth_vertical<false, false>), grid, block, 0, S.st_tau, T);
+      } else
+        hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
+                           dim3(256), 0, S.st_tau, T);
+      done += nt;
+    }
+    if (prof && spans.end(S.st_tau)) return fail(h, TRX_E_HIP, "event");
+    return TRX_OK;
+  };
   for (;;) {
   for (; r_top >= 0; ) {
     // Step plan.  Layers still to go: down to the previous spectrum's depth when it is known
@@ -1536,6 +1648,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     // combine and optical depth stay on the walk's queue
     const bool last_step = r_top - nc < 0 || (stop_at_hint && nr - 1 - (r_top - nc) >= h->hint_layers);
     hipStream_t st_tau = (pipelined && !last_step) ? st_early : st;
+    SideWork S;
+    S.first = nchunks == 0; S.r_top = r_top; S.nc = nc; S.swept = swept; S.st_tau = st_tau;
     if (h->has_grid) {
       if (prof && spans.begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
       GridArgs Gd{};
@@ -1551,12 +1665,12 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       bool walked = false;
       M.eager = eager; M.prof = count; M.ethresh = o->ethresh;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
-      M.d_e = h->d_e.as<double>(); M.d_kmax = h->d_kmax.as<double>(); M.d_sticky = h->d_sticky.as<int>();
+      M.d_e = h->d_e.as<double>(); M.d_kmax = kmax_run; M.d_sticky = h->d_sticky.as<int>();
       M.st = st_sweep;
       if (h->ngroups > 0) {
         if (nb) {
           rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, st_tau != st ? st_tau : nullptr, h->ev_ac[nchunks],
-                          nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()]);
+                          nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()], &S.pc);
           nwalks++;
         }
         else    rc = sweep_chunk(h, Y, d_wcut, psmax, r_top, nc, sg_layers, M, prof ? &spans : nullptr);
@@ -1569,51 +1683,22 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       }
     }
     lap("sweep");
-    if (nchunks == 0) {
-      if ((rc = queue_cia())) return rc;
-      lap("cia");
-      HIPCHK(h, hipStreamWaitEvent(st_tau, h->ev_cia, 0));
-    }
-    if (st_tau == st) { if ((rc = join_early())) return rc; }       // the optical depths of the earlier steps
-    else early_dirty = true;
-    if (prof && spans.begin(Spans::kTau, st_tau)) return fail(h, TRX_E_HIP, "event");
-    for (int done = 0; done < nc; ) {          // optical depth in sub-steps of at most tau_cap layers
-      int nt = std::min(tau_cap, nc - done);
-      if (swept == 0 && done == 0) nt = std::min(nc, std::max(nt, 3));
-      TauArgs T{};
-      T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
-      T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
-      T.r_top = r_top - done; T.nc = nt; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
-      T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
-      T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
-      T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
-      T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
-      T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
-      T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
-      T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
-      T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
-      T.pw = d_pw; T.acc = h->d_acc.as<double>();
-      T.hrs = d_pw + 4 * (size_t)nr; T.hr0 = T.hrs + nr; T.status = h->d_status.as<int>();
-      if (o->solution == TRX_SOL_ECLIPSE) {
-        // small shards: one wave per block spreads the (latency-bound) chains over more CUs
-        const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
-        const dim3 grid((unsigned)std::min<int64_t>((nsh + (small ? 63 : 255)) / (small ? 64 : 256), kTauMaxBlocks)), block(small ? 64 : 256);
-        if (small && extras)       hipLaunchKernelGGL((k_optical_depth_vertical<true, true>), grid, block, 0, st_tau, T);
-        else if (small)            hipLaunchKernelGGL((k_optical_depth_vertical<true, false>), grid, block, 0, st_tau, T);
-        else if (extras)           hipLaunchKernelGGL((k_optical_depth_vertical<false, true>), grid, block, 0, st_tau, T);
-        else                       hipLaunchKernelGGL((k_optical_depth_vertical<false, false>), grid, block, 0, st_tau, T);
-      } else
-        hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
-                           dim3(256), 0, st_tau, T);
-      done += nt;
-    }
-    if (prof && spans.end(st_tau)) return fail(h, TRX_E_HIP, "event");
+    // The rest of the step -- its combine, the CIA kernels ahead of the first optical depth, the
+    // optical depth itself -- goes to the side queue for every step but the plan's last, and is
+    // QUEUED only after the next step's walk: the walks then sit back to back on the main queue
+    // however long the host takes over the rest (small shards are host-bound otherwise).
+    if (pending.active) { if ((rc = run_side(pending))) return rc; pending.active = false; }
+    S.active = true;
+    if (st_tau != st) pending = S;
+    else if ((rc = run_side(S))) return rc;
     lap("tau");
     r_top -= nc; nchunks++;
     // the previous spectrum stopped here: compute the spectrum now and look at the outcome
     // on the host (which this call waits for anyway) instead of queueing gated no-op steps
     if (stop_at_hint && nr - 1 - r_top >= h->hint_layers) break;
   }
+
+  if (pending.active) { if ((rc = run_side(pending))) return rc; pending.active = false; }
 
   // ---- spectrum ---------------------------------------------------------------
   if ((rc = join_early())) return rc;
@@ -1660,6 +1745,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
 
   drain.armed = false;                     // everything was joined into the main stream and waited for
+  h->kmax_clean = true;
   trx_stats &S = h->stats;
   S.layers_swept = flags_host[2];
   h->hint_layers = flags_host[4];
@@ -1758,7 +1844,11 @@ int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double
   HIPCHK(h, hipMemsetAsync(h->d_pm.p, 0, sizeof(double) * (size_t)nv * nslot * nsh, st));
   LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
   layer_dev(h->d_pm_f64.as<double>(), h->d_pm_i32.as<int32_t>(), LH, nv, Y, d_wcut, d_npre);
-  if ((rc = layer_maxima_and_sticky(h, Y, d_npre, nv, temp, nslot, h->d_iso_mx.as<int32_t>(), ethresh, st, false))) return rc;
+  // (its own maxima array: [state][slot]; the runs' two halves are left dirty, trx_run re-zeroes them)
+  if ((rc = ensure(h, h->d_kmax, sizeof(double) * (size_t)nv * nslot))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->d_kmax.p, 0, sizeof(double) * (size_t)nv * nslot, st));
+  h->kmax_clean = false;
+  if ((rc = layer_maxima_and_sticky(h, Y, d_npre, nv, temp, nslot, h->d_iso_mx.as<int32_t>(), ethresh, st, h->d_kmax.as<double>()))) return rc;
   for (int r_top = nv - 1; r_top >= 0 && h->ngroups > 0; ) {
     int nb = walk_frame_bins(h, LH.psmax, r_top);
     int nc = 1;

@@ -109,6 +109,52 @@ void k_cand_select(long long n, const double *__restrict__ wavn, const double *_
   }
 }
 
+// Start of a run: every small per-run buffer in ONE pass (a dozen memsets cost more than the
+// spectrum's arithmetic at demo size) -- and that pass rides along with k_layer_max as one extra
+// row of blocks, so that it is not a launch of its own on the critical path.  kmax here is the
+// array of the NEXT run (two alternate): this run's was zeroed a run ago.
+struct RunInit {
+  int *last; long long nsh;            // -1: ray still descending   (nsh < 0: nothing to initialise)
+  double *acc;                         // [2][nsh] running Simpson sums of the vertical rays
+  unsigned long long *counters; int ncounters;
+  double *kmax; int nkmax;
+  int *status, *flags; int rays;
+};
+
+__device__ __forceinline__ void run_init_elements(const RunInit &R, long long t0, long long stride)
+{
+  const long long n = max(max(R.nsh, (long long)R.ncounters), max((long long)R.nkmax, 8LL));
+  for (long long t = t0; t < n; t += stride) {
+    if (t < R.nsh) { R.last[t] = -1; R.acc[t] = 0.0; R.acc[R.nsh + t] = 0.0; }
+    if (t < R.ncounters) R.counters[t] = 0ull;
+    if (t < R.nkmax) R.kmax[t] = 0.0;
+    if (t < 4) R.status[t] = 0;
+    if (t < 8) R.flags[t] = t == 0 ? R.rays : 0;
+  }
+}
+
+__global__ __launch_bounds__(256)
+void k_run_init(RunInit R)
+{
+  run_init_elements(R, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+}
+
+// the candidates' line data in one place: k_layer_max then needs one load round trip, not three
+// (index -> range flag -> four arrays)
+struct alignas(32) CandLine { double gf, elow, wavn; int32_t iso, pad; };
+
+__global__ __launch_bounds__(256)
+void k_cand_pack(int n, const int32_t *__restrict__ cand, const double *__restrict__ wavn, const double *__restrict__ elow,
+                 const double *__restrict__ gf, const int16_t *__restrict__ iso, const uint8_t *__restrict__ inr, CandLine *__restrict__ out)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int ln = cand[t];
+  CandLine c{0.0, 0.0, 0.0, 0, 0};
+  if (inr[ln]) { c.gf = gf[ln]; c.elow = elow[ln]; c.wavn = wavn[ln]; c.iso = iso[ln]; }
+  out[t] = c;
+}
+
 // Strongest single line of every layer.  One wavefront per 256 candidates (four per lane) and
 // kLayerMaxGroup layers: the lines are read once, the lanes keep running maxima per layer and the
 // wave reduces them once at the end.  cand == null: all lines.  kmax is [layer][nmx] bit
@@ -117,10 +163,14 @@ constexpr int kLayerMaxGroup = 16;
 constexpr int kLayerMaxLines = 4;
 
 __global__ __launch_bounds__(64)
-void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const int32_t *__restrict__ cand, long long ncand,
+void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__restrict__ cand, long long ncand,
                  const double *__restrict__ e2tab, int nmx, const int32_t *__restrict__ iso_mx,
-                 unsigned long long *__restrict__ kmax_bits)
+                 unsigned long long *__restrict__ kmax_bits, RunInit R, int init_row)
 {
+  if ((int)blockIdx.y == init_row) {     // the extra row of blocks: the run's small buffers
+    run_init_elements(R, (long long)blockIdx.x * 64 + threadIdx.x, (long long)gridDim.x * 64);
+    return;
+  }
   __shared__ double s_e2[64];
   s_e2[threadIdx.x] = e2tab[threadIdx.x];
   __builtin_amdgcn_wave_barrier();
@@ -130,8 +180,8 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const int32_t *__rest
     const long long t = ((long long)blockIdx.x * kLayerMaxLines + u) * 64 + threadIdx.x;
     gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
     if (t < ncand) {
-      const long long ln = cand ? cand[t] : t;
-      if (L.inrange[ln]) { gf[u] = L.gf[ln]; elow[u] = L.elow[ln]; wavn[u] = L.wavn[ln]; iso[u] = L.iso[ln]; }
+      if (cand) { const CandLine c = cand[t]; gf[u] = c.gf; elow[u] = c.elow; wavn[u] = c.wavn; iso[u] = c.iso; }
+      else if (L.inrange[t]) { gf[u] = L.gf[t]; elow[u] = L.elow[t]; wavn[u] = L.wavn[t]; iso[u] = L.iso[t]; }
     }
   }
   const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
@@ -154,27 +204,6 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const int32_t *__rest
       if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(m));
     }
   }
-}
-
-// Start of a run: every small per-run buffer in ONE launch (a dozen memsets cost more than the
-// spectrum's arithmetic at demo size).
-struct RunInit {
-  int *last; long long nsh;            // -1: ray still descending
-  double *acc;                         // [2][nsh] running Simpson sums of the vertical rays
-  unsigned long long *counters; int ncounters;
-  double *kmax; int nkmax;
-  int *status, *flags; int rays;
-};
-
-__global__ __launch_bounds__(256)
-void k_run_init(RunInit R)
-{
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t < R.nsh) { R.last[t] = -1; R.acc[t] = 0.0; R.acc[R.nsh + t] = 0.0; }
-  if (t < R.ncounters) R.counters[t] = 0ull;
-  if (t < R.nkmax) R.kmax[t] = 0.0;
-  if (t < 4) R.status[t] = 0;
-  if (t < 8) R.flags[t] = t == 0 ? R.rays : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -247,6 +276,7 @@ void k_wave_plan(WalkPlan P, int niso, const int32_t *__restrict__ gblock, const
 struct alignas(32) WalkLine { double wavn, elow, gf; int32_t meta, cell; };
 
 constexpr int kWalkLayers = 64;      // layers per step = lanes
+constexpr int kWalkSegs = 16;        // isotope blocks whose reaching ranges a launch can address separately
 // exp(ct*wavn) along a wavenumber-sorted range: with a base point t0 = fl(ct*w0), c0 = -t0 and
 // E0 = exp(t0), x = fma(ct, wavn, c0) is the EXACT difference ct*wavn - t0 (one rounding) and
 // exp(ct*wavn) = E0 * P5(x) to 5e-18 while 0 <= x <= 2^-8.  Base points are a property of the
@@ -314,6 +344,9 @@ struct WalkArgs {
   double *part;                     // [records][64]
   unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
   const int *flags; const int *last; int eager;
+  // the ranges that can reach the shard: per isotope block one run of consecutive ranges
+  // (nseg = 0: every range is launched).  Wave L of the grid walks range seg_w0[s] + L - seg_cum[s].
+  int nseg; int seg_w0[kWalkSegs]; int seg_cum[kWalkSegs + 1];
 };
 
 __device__ __forceinline__ double exp_small(double x)
@@ -336,7 +369,13 @@ void k_line_walk(WalkArgs A)
   constexpr int Rc = NB / 2 - 1;
   if (!A.eager && A.flags[0] == 0) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int w = blockIdx.x * kWalkWaves + wv;            // wave-uniform
+  int w = blockIdx.x * kWalkWaves + wv;                  // wave-uniform
+  if (A.nseg > 0) {                                       // only the ranges that can reach the shard were launched
+    if (w >= A.seg_cum[A.nseg]) return;
+    int sgm = 0;
+    while (sgm + 1 < A.nseg && w >= A.seg_cum[sgm + 1]) sgm++;
+    w = A.seg_w0[sgm] + (w - A.seg_cum[sgm]);
+  }
   if (w >= A.P.nwaves) return;
   const int lane = threadIdx.x & 63;
   const int blo = A.P.blo[w], bhi = A.P.bhi[w];
