@@ -91,7 +91,7 @@ struct trx_handle {
   struct Plan { bool built = false; DevBuf blo, bhi, off; int64_t records = 0; };
   Plan plan[4];                                             // NB = 2, 4, 8 bins per frame (slot 3 spare)
   // CIA (host copies)
-  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw; };
+  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw, ruw, rh; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw, d_ruw, d_rh; };
   std::vector<Cia> cia;
   DevBuf d_cia_ws;
   // per-run workspaces (grown on demand)
@@ -567,7 +567,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     for (int j = 0; j < lj; j++) if (a->temp[j] > lx2) lj = j;
     if (fi >= li || fj >= lj) continue;
     CiaDev C{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>(),
-             c.d_zt.as<double>(), c.d_uw.as<double>()};
+             c.d_zt.as<double>(), c.d_uw.as<double>(), c.d_ruw.as<double>(), c.d_rh.as<double>()};
     double *mid = h->d_cia_ws.as<double>(), *z2 = mid + nwmax * nr, *v = z2 + nwmax * nr;
     hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)C.nwave * nr + 255) / 256)), dim3(256), 0, cst, C, nr, d_tlay, fj, lj, mid);
     hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, cst, C, nr, fj, lj, mid, z2, v);
@@ -1178,6 +1178,10 @@ int trx_create(const trx_static *s, trx_handle **out)
       std::vector<double> zdummy(nw), ydummy(nw, 0.0);
       t.uw.assign(nw, 0.0);
       spline_second_derivs(zdummy.data(), t.wn.data(), ydummy.data(), (long)nw, t.uw.data(), v.data());
+      t.ruw.assign(nw, 0.0);                 // reciprocal pivots: the per-layer sweeps multiply instead of dividing
+      for (size_t i = 0; i < (size_t)nw; i++) if (t.uw[i] != 0.0) t.ruw[i] = 1.0 / t.uw[i];
+      t.rh.assign(nw, 0.0);                  // reciprocal spacings 1/(wn[i+1]-wn[i])
+      for (size_t i = 0; i + 1 < (size_t)nw; i++) t.rh[i] = 1.0 / (t.wn[i + 1] - t.wn[i]);
     }
     h->cia.push_back(std::move(t));
   }
@@ -1194,7 +1198,7 @@ int trx_create(const trx_static *s, trx_handle **out)
   }
   for (auto &c : h->cia)
     if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs)) ||
-        (rc = upload(h, c.d_zt, c.zt)) || (rc = upload(h, c.d_uw, c.uw))) return bail(rc);
+        (rc = upload(h, c.d_zt, c.zt)) || (rc = upload(h, c.d_uw, c.uw)) || (rc = upload(h, c.d_ruw, c.ruw)) || (rc = upload(h, c.d_rh, c.rh))) return bail(rc);
   // the handle does not survive a failed create, so its error text cannot be asked for later:
   // without a message callback it goes to stderr
   auto say = [&]() { if (!log_sink().fn) std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); };

@@ -834,7 +834,7 @@ void k_grid_extinction(GridArgs G)
 // The table-only halves of both splines are computed once at trx_create
 // (zt = second derivatives along T of every table row, uw = the tridiagonal
 // pivots u[] of the wavenumber spline, which depend on the wn grid alone).
-struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs, *zt, *uw; };
+struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs, *zt, *uw, *ruw, *rh; };
 
 // one lane per (table row, layer): the T spline evaluated at the layer temperature.
 // mid is [nwave][nr] so that the next kernel walks it with unit stride per lane.
@@ -849,11 +849,17 @@ void k_cia_rows(CiaDev C, int nr, const double *__restrict__ tlay, int fj, int l
   mid[idx] = spline_eval_pt(C.zt + (long long)i * C.ntemp, C.ntemp, C.temp, C.cs + (long long)i * C.ntemp, tlay[j]);
 }
 
-// one lane per layer: second derivatives of the wavenumber spline -- the
-// sequential tridiagonal sweep of spline_second_derivs (trx_numerics.h) with the
-// pivots read from uw and next step's operands loaded one step ahead, so that a
-// step costs its dependent mul-div-sub chain and not a memory round trip.
-// z2/v are [nwave][nr].
+// one lane per layer: second derivatives of the wavenumber spline -- the sequential
+// tridiagonal sweep of spline_second_derivs (trx_numerics.h), pivots from the table.
+// With one wave per 64 layers nothing hides a memory round trip, and a load one step
+// ahead of its use still waited ~400 cycles per step (and for the step's store: loads and
+// stores return in order on this part).  So the sweeps run in chunks of kCiaChunk steps:
+// all of a chunk's operands are requested together, the chain then runs out of registers,
+// and the chunk's results are stored together.  The divisions by table constants (pivots,
+// spacings) are multiplications by reciprocals made at create: the chain is mul-fma
+// (e_cs agrees with the oracle to 1e-13).  z2/v are [nwave][nr].
+constexpr int kCiaChunk = 16;
+
 __global__ __launch_bounds__(64)
 void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ mid,
                   double *__restrict__ z2, double *__restrict__ v)
@@ -862,7 +868,7 @@ void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ m
   if (j >= lj) return;
   latency_critical();
   const long n = C.nwave;
-  const double *__restrict__ x = C.wn, *__restrict__ uw = C.uw;
+  const double *__restrict__ x = C.wn, *__restrict__ ru = C.ruw, *__restrict__ rh = C.rh;
   const double *y = mid + j; double *z = z2 + j, *vv = v + j;
   double vp = 0;
   if (n > 2) {
@@ -872,29 +878,43 @@ void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ m
     vv[1L*nr] = vp;
   }
   if (n > 3) {
-    double xi = x[2], yi = y[2L*nr];
-    double him = xi - x[1], bim = (yi - y[1L*nr]) / him;
-    double xn = x[3], yn = y[3L*nr], up = uw[1];
-    for (long i = 2; i < n - 1; i++) {
-      const long ip = (i + 2 < n) ? i + 2 : n - 1;          // operands of the next step
-      const double xnn = x[ip], ynn = y[ip*nr], un = uw[i];
-      const double hi = xn - xi, bi = (yn - yi) / hi;
-      const double vn = 6*(bi - bim) - vp*him/up;
-      vv[i*nr] = vn;
-      vp = vn; up = un; him = hi; bim = bi; xi = xn; yi = yn; xn = xnn; yn = ynn;
+    // forward: v[i] = 6 (b[i] - b[i-1]) - v[i-1] h[i-1] / u[i-1],  b[i] = (y[i+1] - y[i]) / h[i]
+    double yi = y[2L*nr], bim = (yi - y[1L*nr]) / (x[2] - x[1]);
+    for (long base = 2; base < n - 1; base += kCiaChunk) {
+      double yb[kCiaChunk], vo[kCiaChunk];
+#pragma unroll
+      for (int k = 0; k < kCiaChunk; k++) { const long i = base + k + 1; yb[k] = y[(i < n ? i : n - 1) * nr]; }     // y[i+1] of step i
+#pragma unroll
+      for (int k = 0; k < kCiaChunk; k++) {
+        const long i = base + k;
+        if (i < n - 1) {
+          const double bi = (yb[k] - yi) * rh[i];
+          const double vn = 6*(bi - bim) - vp * (x[i] - x[i-1]) * ru[i-1];
+          vo[k] = vn; vp = vn; bim = bi; yi = yb[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kCiaChunk; k++) if (base + k < n - 1) vv[(base + k) * nr] = vo[k];
     }
   }
   z[0] = 0; z[(n-1)*nr] = 0;
   if (n > 2) {
-    double zn = 0, xn = x[n-1];
-    double xi = x[n-2], vi = vv[(n-2)*nr], ui = uw[n-2];
-    for (long i = n - 2; i > 0; i--) {
-      const long im = (i > 1) ? i - 1 : 1;
-      const double xm = x[im], vm = vv[im*nr], um = uw[im];
-      const double hi = xn - xi;
-      const double zi = (vi - hi*zn) / ui;
-      z[i*nr] = zi;
-      zn = zi; xn = xi; xi = xm; vi = vm; ui = um;
+    // backward: z[i] = (v[i] - h[i] z[i+1]) / u[i]
+    double zn = 0;
+    for (long top = n - 2; top > 0; top -= kCiaChunk) {
+      double vb[kCiaChunk], zo[kCiaChunk];
+#pragma unroll
+      for (int k = 0; k < kCiaChunk; k++) { const long i = top - k; vb[k] = vv[(i > 0 ? i : 1) * nr]; }
+#pragma unroll
+      for (int k = 0; k < kCiaChunk; k++) {
+        const long i = top - k;
+        if (i > 0) {
+          const double zi = (vb[k] - (x[i+1] - x[i]) * zn) * ru[i];
+          zo[k] = zi; zn = zi;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kCiaChunk; k++) if (top - k > 0) z[(top - k) * nr] = zo[k];
     }
   }
 }
