@@ -432,14 +432,14 @@ void k_line_walk(WalkArgs A)
 
   auto flush = [&](int k, double v) {                      // bin of slot k leaves the frame
     const int j = jc - Rc + k;
-    if (j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = v;
+    if (valid && j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = v;     // (idle lanes: nobody reads their entries)
   };
 
   // bins of the interval that no frame position covers (a jump over empty or skipped cells, the
   // tail below the last evaluated group) still get their record: zeros
   auto fill_zero = [&](int ja, int jb) {                   // bins ja..jb inclusive
     ja = max(ja, blo); jb = min(jb, bhi);
-    for (int j = ja; j <= jb; j++) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = 0.0;
+    if (valid) for (int j = ja; j <= jb; j++) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = 0.0;
   };
 
   double pk = 0.0;                   // strength of the group so far (0 between groups)
@@ -639,7 +639,7 @@ void k_walk_combine(CombineArgs C)
       for (int u = 0; u < 4; u++) {
         const int ww = min(w + u, wz - 1);
         const long long rec = C.P.off[ww] + (j - C.P.blo[ww]);
-        v[u] = (w + u < wz) ? C.part[rec * kWalkLayers + lane] : 0.0;
+        v[u] = (w + u < wz && lane < C.nc) ? C.part[rec * kWalkLayers + lane] : 0.0;     // (a step's idle lanes are never written)
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) if (w + u < wz) sum += v[u];
