@@ -89,7 +89,7 @@ struct trx_handle {
   std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
   bool walk_temp_ok = true;         // this run's layers are all warmer than kWalkMinTemp
   struct Plan { bool built = false; DevBuf blo, bhi, off; int64_t records = 0; };
-  Plan plan[4];                                             // NB = 2, 4, 8 bins per frame (slot 3 spare)
+  Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw, ruw, rh; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw, d_ruw, d_rh; };
   std::vector<Cia> cia;
@@ -763,9 +763,13 @@ int walk_frame_bins(const trx_handle *h, const int32_t *psmax, int r)
 {
   if (!h->walk_ok || !h->walk_temp_ok) return 0;
   const long long rc = layer_psmax(h, psmax, r) / h->osamp;
-  // (a 16-bin frame was measured too: per wide layer it costs more than the two-kernel form at
-  // any layer count -- 1.4 ms against ~0.4 ms for the 9 such layers of configs[2])
-  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
+  // The 16-bin frame (profiles reaching 4-7 cells) pays only where lines are sparse: its cost goes
+  // with the number of LINES, the two-kernel form's with bins and tiles.  At hundreds of lines
+  // per bin (configs[1], [2]) it is dearer per wide layer than the two-kernel form at any layer
+  // count (1.4 ms against ~0.4 ms for the 9 such layers of configs[2]); at one line per bin
+  // (configs[4]) it is the cheaper one (0.220 s against 0.245 s).  A property of the handle.
+  const bool frame16 = h->ngroups < 16 * h->nwn;
+  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : (rc <= 7 && frame16) ? 16 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
 }
 
 // plan of the line ranges for a frame of nb bins (built once per handle and frame size)
@@ -876,7 +880,8 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   if (nw > 0) {
     if (nb == 2) launch_walk<2>(A, M.prof, nw, st);
     else if (nb == 4) launch_walk<4>(A, M.prof, nw, st);
-    else launch_walk<8>(A, M.prof, nw, st);
+    else if (nb == 8) launch_walk<8>(A, M.prof, nw, st);
+    else launch_walk<16>(A, M.prof, nw, st);
   }
   if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
   PendingCombine pc;
@@ -1523,12 +1528,18 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (pipelined) HIPCHK(h, hipStreamWaitEvent(st_early, h->ev_inputs, 0));
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
   bool init_done = false;
-  if (!h->has_grid &&
-      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, kmax_run, &R, &init_done))) return rc;
-  if (!init_done) {                      // no line kernel to ride along with (opacity-grid mode, no in-range line)
-    const long long nt = std::max<long long>(nsh, 3LL * nr);
-    hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((nt + 255) / 256, 4096)), dim3(256), 0, st_sweep, R);
+  // (the start-up pass rides along with k_layer_max only where it is small next to it: a few
+  // thousand threads striding over 10^7 rays took 20 ms at configs[4])
+  const bool ride_along = nsh <= 65536;
+  if (!ride_along) {
+    hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
+    init_done = true;
   }
+  bool rode = false;
+  if (!h->has_grid &&
+      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, kmax_run, ride_along ? &R : nullptr, &rode))) return rc;
+  if (!init_done && !rode)               // no line kernel to ride along with (opacity-grid mode, no in-range line)
+    hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
   lap("kmax");
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
@@ -1653,6 +1664,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     const bool last_step = r_top - nc < 0 || (stop_at_hint && nr - 1 - (r_top - nc) >= h->hint_layers);
     hipStream_t st_tau = (pipelined && !last_step) ? st_early : st;
     SideWork S;
+    bool step_walked = false;
     S.first = nchunks == 0; S.r_top = r_top; S.nc = nc; S.swept = swept; S.st_tau = st_tau;
     if (h->has_grid) {
       if (prof && spans.begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
@@ -1680,6 +1692,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         else    rc = sweep_chunk(h, Y, d_wcut, psmax, r_top, nc, sg_layers, M, prof ? &spans : nullptr);
         if (rc) return rc;
         walked = nb != 0;
+        step_walked = walked;
       }
       if (st_tau != st && !walked) {     // the optical depth of this step follows its extinction
         HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], st));
@@ -1693,7 +1706,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     // however long the host takes over the rest (small shards are host-bound otherwise).
     if (pending.active) { if ((rc = run_side(pending))) return rc; pending.active = false; }
     S.active = true;
-    if (st_tau != st) pending = S;
+    // (walk steps only: with the two-kernel form's long steps the later queueing of an optical
+    // depth measurably delays the stop information the next step's tile skipping reads --
+    // configs[4] 0.223 -> 0.246 s)
+    if (st_tau != st && step_walked) pending = S;
     else if ((rc = run_side(S))) return rc;
     lap("tau");
     r_top -= nc; nchunks++;

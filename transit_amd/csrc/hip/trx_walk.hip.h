@@ -287,7 +287,7 @@ constexpr int kWalkSegs = 16;        // isotope blocks whose reaching ranges a l
 constexpr double kRebaseSpan = 0.03125;     // cm-1
 constexpr double kWalkMinTemp = 1.4387752 * kRebaseSpan * 256.0 * 1.05;
 
-constexpr int kWalkMaxFrame = 8;     // bins of the widest frame (k_line_walk<8>)
+constexpr int kWalkMaxFrame = 16;    // bins of the widest frame (k_line_walk<16>)
 
 // trx_create builds the records on the device from the line and group arrays it has just uploaded
 __global__ __launch_bounds__(256)
