@@ -411,3 +411,18 @@ def test_sixty_four_isotopes_and_one_too_many(tmp_path):
     with pytest.raises(EngineError) as ei:
         Engine(Q.static)
     assert ei.value.code == -6
+
+
+def test_large_shard_emission_kernel_against_oracle(tmp_path):
+    """A 70 001-point grid with few layers: the small-shard variants of the optical-depth and
+    start-up kernels switch off above 65 536 wavenumbers; spectrum and per-angle intensities
+    against the CPU restatement."""
+    d = str(tmp_path / "wide")
+    synth.make_case(d, nlines=60, wnlow=2500, wnhigh=2507, wndelt=1e-4, wnosamp=1, nlayers=8, solution="eclipse", seed=5,
+                    toomuch=10.0, nwidth=2.0)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    assert P.nwn > 65536
+    got, ref = _both(P.static, P)
+    assert np.array_equal(got["last"], ref["last"])
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9
+    assert rel_err(got["intens"], ref["intens"]) < 1e-9

@@ -1734,7 +1734,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       E.cosang[i] = std::cos(o->angles_deg[i] * kDeg);
       E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
     }
-    E.intens = h->d_intens.as<double>(); E.flux = d_out;
+    E.intens = h->d_intens.as<double>(); E.flux = d_out; E.e2tab = h->d_e2tab.as<double>();
     hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + kEmisWaves - 1) / kEmisWaves)), dim3(64 * kEmisWaves), 0, st, E);
   } else {
     ModArgs M{};

@@ -1274,7 +1274,15 @@ struct EmisArgs {
   double cosang[kMaxAngles], area[kMaxAngles];
   double *intens;                    // [nang][nsh]
   double *flux;                      // [nsh]
+  const double *e2tab;               // [64] 2^(j/64)
 };
+
+// B = num / (e^x - 1) = num e^-x / (1 - e^-x),  x = h nu / k T > 0, with the kernels' own exponential
+__device__ __forceinline__ double planck_from(double num, double x, const double *e2tab)
+{
+  const double em = exp_neg(-x, e2tab);
+  return num * em / (1.0 - em);
+}
 
 // eclipse.c:118-160 (eclipse_intens) + eclipse.c:243-287 (flux).
 // One wavefront per wavenumber, lanes = heights: every lane evaluates the Planck function and
@@ -1288,6 +1296,9 @@ __global__ __launch_bounds__(64 * kEmisWaves)
 void k_emission(EmisArgs E)
 {
   latency_critical();
+  __shared__ double s_e2[64];                 // 2^(j/64) for exp_neg (the kernels' own exponential, ~1.5 ulp)
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = E.e2tab[threadIdx.x];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const long long w = (long long)blockIdx.x * kEmisWaves + (threadIdx.x >> 6);     // wave-uniform
   if (w >= E.nsh) return;
@@ -1305,7 +1316,7 @@ void k_emission(EmisArgs E)
     double B = 0.0, tv = 0.0;
     if (have) {
       tv = E.tau[(long long)i * E.nsh + w];
-      B = pl_num / (exp(pl_exp / (kKb * E.temp[E.nr - 1 - i])) - 1.0);
+      B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
     }
     double Bp = __shfl_up(B, 1, 64);
     if (lane == 0) Bp = B_c;
@@ -1313,7 +1324,7 @@ void k_emission(EmisArgs E)
 #pragma unroll
     for (int a = 0; a < kMaxAngles; a++) {
       if (a < E.nang) {
-        const double dt = have ? exp(-tv / E.cosang[a]) : 0.0;
+        const double dt = have ? exp_neg(-tv / E.cosang[a], s_e2) : 0.0;
         double dtp = __shfl_up(dt, 1, 64);
         if (lane == 0) dtp = dt_c[a];
         const double term = (have && i > 0) ? (dt - dtp) * (B + Bp) : 0.0;
