@@ -338,10 +338,10 @@ def main():
         nbins = hi - lo
         # Bytes the dominant kernel's data flow must move per launch.  The walk reads one 32-byte
         # record per line, 4 bytes per accumulated bin (table) and writes its partial records
-        # (512 B each); the combine reads those and writes e.  Two-kernel form: see DESIGN.md.
+        # (8 B per layer of the step); the combine reads those and writes e.  Two-kernel form: see DESIGN.md.
         if walked:
-            alg = {line_k: 32.0 * L * launches + 4.0 * stats["sum_bins"] + 512.0 * stats["walk_records"],
-                   acc_k: 512.0 * stats["walk_records"] + 8.0 * R * nbins}
+            alg = {line_k: 32.0 * L * launches + 4.0 * stats["sum_bins"] + 8.0 * stats["walk_record_lanes"],
+                   acc_k: 8.0 * stats["walk_record_lanes"] + 8.0 * R * nbins}
         else:
             G = stats["ngroups"]
             alg = {line_k: 27.0 * L * launches + 9.0 * G * R, acc_k: 13.0 * G * R + 4.0 * stats["sum_bins"] + 8.0 * R * nbins}

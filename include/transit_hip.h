@@ -221,7 +221,9 @@ typedef struct {
                              dominated, trx_walk.hip.h); -1: every line is looked at */
   int64_t walk_steps;     /* steps of the last run taken by the one-kernel line walk (the
                              rest, sweep_launches - walk_steps, took the two-kernel form)  */
-  int64_t walk_records;   /* partial-sum records (64 doubles each) those steps wrote      */
+  int64_t walk_records;   /* partial-sum records (64 lane slots each) those steps wrote   */
+  int64_t walk_record_lanes; /* lane slots of them actually written and read: sum over steps of
+                             records x layers of the step (8 bytes each)                 */
 } trx_stats;
 
 typedef struct trx_handle trx_handle;

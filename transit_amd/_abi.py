@@ -84,7 +84,7 @@ class TrxStats(C.Structure):
         ("ms_k_sweep", C.c_double), ("ms_k_sticky", C.c_double), ("ms_k_accum", C.c_double),
         ("sweep_launches", C.c_int64),
         ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_host_total", C.c_double),
-        ("ms_spectrum", C.c_double), ("ncandidates", C.c_int64), ("walk_steps", C.c_int64), ("walk_records", C.c_int64),
+        ("ms_spectrum", C.c_double), ("ncandidates", C.c_int64), ("walk_steps", C.c_int64), ("walk_records", C.c_int64), ("walk_record_lanes", C.c_int64),
     ]
 
     def as_dict(self):

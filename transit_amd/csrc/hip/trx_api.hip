@@ -835,7 +835,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   int rc = walk_plan(h, nb, st, P, pl);
   if (rc) return rc;
   DevBuf &part = h->d_part[parity & 1];
-  h->stats.walk_steps++; h->stats.walk_records += pl->records;
+  h->stats.walk_steps++; h->stats.walk_records += pl->records; h->stats.walk_record_lanes += pl->records * nc;
   const size_t pbytes = sizeof(double) * kWalkLayers * (size_t)std::max<int64_t>(pl->records, 1);
   if (part.bytes < pbytes) {
     HIPCHK(h, hipStreamSynchronize(st));                 // an earlier step may still be using the old buffer
@@ -1559,7 +1559,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   HIPCHK(h, hipEventCreate(&ev.a)); HIPCHK(h, hipEventCreate(&ev.b));
   HIPCHK(h, hipEventRecord(ev.a, st));
 
-  h->stats.walk_steps = 0; h->stats.walk_records = 0;
+  h->stats.walk_steps = 0; h->stats.walk_records = 0; h->stats.walk_record_lanes = 0;
   if (!h->has_grid && log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
     std::string ln = "run: walk frame (bins) per layer, top first; 0 = two-kernel form:";
     for (int r = nr - 1; r >= 0; r--) ln += " " + std::to_string(walk_frame_bins(h, psmax, r));
