@@ -553,8 +553,12 @@ static void layer_extinction(trxo_handle *h, double ethresh, double *kout, doubl
     neval++;
   }
   h->stats.nadd = nadd;
+  /* (layers may be swept by several threads: trxo_run with opts.eager, see there) */
+#pragma omp atomic
   h->stats.nskip += nskip;
+#pragma omp atomic
   h->stats.neval += neval;
+#pragma omp atomic
   h->stats.sum_bins += nbins;
   free(alphal); free(alphad); free(idop); free(ilor); free(kmaxv);
 #undef OWN
@@ -925,7 +929,24 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
     comp[(L)] = 1; } while (0)
 
   if (!comp[nr-1]) SWEEP(nr-1);                            /* tau.c:158-177 */
-  if (o->eager) for (long L = nr - 2; L >= 0; L--) SWEEP(L);
+  /* eager: every layer, independent of each other -- the one place where this restatement uses
+   * more than one core (OMP_NUM_THREADS; bench.py's all-core CPU figure).  Each thread has its
+   * own density / partition-function scratch; a layer's sums are what one thread computes. */
+  if (o->eager) {
+#pragma omp parallel
+    {
+      double *dens_t = malloc(sizeof(double) * (nmol > 0 ? nmol : 1)), *zp_t = malloc(sizeof(double) * (niso > 0 ? niso : 1));
+#pragma omp for schedule(dynamic, 1)
+      for (long L = nr - 2; L >= 0; L--) {
+        for (int m_ = 0; m_ < nmol; m_++) dens_t[m_] = a->density[m_*nr + L];
+        for (int i_ = 0; i_ < niso; i_++) zp_t[i_] = a->zpart[i_*nr + L];
+        if (s->ogrid) grid_extinction(h, a, L, e + (size_t)L*nwn);
+        else layer_extinction(h, o->ethresh, e + (size_t)L*nwn, a->temp[L], dens_t, zp_t, 1, NULL);
+        comp[L] = 1;
+      }
+      free(dens_t); free(zp_t);
+    }
+  }
 
   /* mean mass density and H2 number density for the cloud models,
    * tau.c:193-214.  (The reference accumulates mean_dens into an
