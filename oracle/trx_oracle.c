@@ -1,7 +1,8 @@
 /* trx_oracle.c -- TEST INFRASTRUCTURE ONLY (see trx_oracle.h).
  *
- * One-thread CPU restatement of the reference's spectrum path in its exact
- * discretisation.  Every function names the reference lines it follows
+ * CPU restatement of the reference's spectrum path in its exact discretisation; one thread,
+ * except that the eager sweep of all layers (trx_opts.eager) runs its independent layers
+ * under OpenMP -- bench.py's all-core CPU figure.  Every function names the reference lines it follows
  * (paths relative to the reference tree).  Written from the algorithm, not
  * from the text: data layout, naming and control flow are this project's.
  *

@@ -1,6 +1,6 @@
 /* trx_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
- * CPU restatement (plain C, one thread) of the reference's spectrum path, used
+ * CPU restatement (plain C; one thread but for the OpenMP'd eager layer sweep) of the reference's spectrum path, used
  * as the parity checker by tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py.  It is never linked into, imported by, or
  * called from the product (transit_amd/): the product fails loudly when its
