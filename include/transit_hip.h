@@ -202,13 +202,13 @@ typedef struct {
   int64_t nadd;           /* co-added lines per layer (layer independent)      */
   int64_t layers_swept;
   int64_t neval;          /* evaluated groups, summed over swept layers (these three
-                             counters are collected by profiled runs only)      */
+                             counters are collected by counting runs only: profile 2) */
   int64_t nskip;          /* groups below ethresh*kmax, summed over layers     */
   int64_t sum_bins;       /* accumulated (group,layer,bin) triples             */
   int64_t table_floats;   /* Voigt table size                                  */
   double  ms_create_table;/* device time of the Voigt-table build              */
   double  ms_run_total;   /* device time of the last run, first to last kernel */
-  double  ms_sweep;       /* line-sweep kernels (pass 1 + pass 2 + accumulate) */
+  double  ms_sweep;       /* line-sweep kernels (profile >= 1; as ms_k_* and ms_tau) */
   double  ms_k_sweep;      /* sum over launches of the line kernel (k_line_walk, or k_group_sweep where profiles are wide) */
   double  ms_k_sticky;     /* unused (the sticky Doppler index is computed once per run)  */
   double  ms_k_accum;     /* sum over launches of k_walk_combine / k_accumulate  */
