@@ -1061,7 +1061,7 @@ __device__ __forceinline__ void tau_publish(const TauArgs &T, int nstill, int de
 //           once the chain is known; weights are wave-uniform loads, er reads are
 //           coalesced along the wavenumber axis;
 //   phase 3 (one lane per wavenumber): toomuch cut in height order (tau.c:277-287).
-constexpr int kTauH = 16;                 // heights per block (>= layers per chunk)
+constexpr int kTauH = 32;                 // heights per block (>= layers per chunk)
 constexpr int kTauW = 256 / kTauH;        // wavenumbers per block
 
 __global__ __launch_bounds__(256)
@@ -1081,36 +1081,37 @@ void k_optical_depth(TauArgs T)
   const long long w = tile * kTauW + wi;
   const bool ok = w < T.nsh;
 
-  if (hc == 0) {
-    const bool alive = ok && T.last[w] < 0;
-    s_alive[wi] = alive;
-    if (alive) {
-      const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
-      for (int c = 0; c < T.nc; c++) {
-        const int r = T.r_top - c;
-        const long long k = (long long)r * T.nsh + w;
-        T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
-      }
-      // extinction at the closest-approach radius of every height (slantpath.c:55-58).  The
-      // bracket's lowest layer rs is the height's own layer, or -- when the impact parameter came
-      // out an ulp below the layer radius (TauArgs.hrs) -- the layer under it.  That one may lie
-      // below this step: the reference, sweeping lazily, has no line extinction there yet either
-      // (tau.c:231-232 with an unswept row), and its weight in the parabola is ~1e-14.
-      for (int c = 0; c < T.nc; c++) {
-        const int k = T.r_top - c;
-        const int rs = (int)T.hrs[k];
-        if (rs < 0) { s_y0[c][wi] = 0.0; continue; }
-        const int n = nr - rs;
-        const double r0 = T.hr0[k];
-        const double *y = T.er + (long long)rs * T.nsh + w;
-        const double ylow = rs >= r_low ? y[0]
-                                        : scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[(long long)rs * T.nsh + w];
-        double y0;
-        if (n == 2) y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], ylow, y[T.nsh], r0);
-        else        y0 = parab3(T.rad[rs], T.rad[rs+1], ylow, y[T.nsh], y[2*T.nsh], r0);
-        s_y0[c][wi] = y0;
-      }
+  // phase 1a: every (wavenumber, height) lane adds up the total extinction of ITS layer of the
+  // chunk (tau.c:231-232) -- it used to be one lane per wavenumber going down the chunk
+  const bool alive = ok && T.last[w] < 0;
+  if (hc == 0) s_alive[wi] = alive;
+  const double wcgs = (T.wn_i + (double)(T.lo + (ok ? w : 0)) * T.wn_d) * T.wn_fct;
+  if (alive && hc < T.nc) {
+    const int r = T.r_top - hc;
+    const long long k = (long long)r * T.nsh + w;
+    T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
+  }
+  __syncthreads();                                       // (the block's own global writes: visible to it after the barrier)
+  // phase 1b: extinction at the closest-approach radius of this lane's height (slantpath.c:55-58).
+  // The bracket's lowest layer rs is the height's own layer, or -- when the impact parameter came
+  // out an ulp below the layer radius (TauArgs.hrs) -- the layer under it.  That one may lie
+  // below this step: the reference, sweeping lazily, has no line extinction there yet either
+  // (tau.c:231-232 with an unswept row), and its weight in the parabola is ~1e-14.
+  if (alive && hc < T.nc) {
+    const int c = hc;
+    const int k = T.r_top - c;
+    const int rs = (int)T.hrs[k];
+    double y0 = 0.0;
+    if (rs >= 0) {
+      const int n = nr - rs;
+      const double r0 = T.hr0[k];
+      const double *y = T.er + (long long)rs * T.nsh + w;
+      const double ylow = rs >= r_low ? y[0]
+                                      : scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[(long long)rs * T.nsh + w];
+      if (n == 2) y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], ylow, y[T.nsh], r0);
+      else        y0 = parab3(T.rad[rs], T.rad[rs+1], ylow, y[T.nsh], y[2*T.nsh], r0);
     }
+    s_y0[c][wi] = y0;
   }
   __syncthreads();
 
