@@ -1361,20 +1361,28 @@ struct ModArgs {
   int *status;                       // set to 1 when modlevel -1 cannot be evaluated
 };
 
-// slantpath.c:351-436 (modulation1) and :447-473 (modulationm1)
-__global__ __launch_bounds__(256)
+// slantpath.c:351-436 (modulation1) and :447-473 (modulationm1).
+// One wavefront per wavenumber, lanes = Simpson interval pairs of the ray's radial integral:
+// every lane evaluates the three integrand points of its pair (exp(-tau) * b), the pairs are
+// added over the wave in a fixed butterfly.  (One lane per wavenumber looping over ~35 pairs of
+// three exponentials each was 40 us of latency at the end of every transmission spectrum.)
+constexpr int kModWaves = 4;
+
+__global__ __launch_bounds__(64 * kModWaves)
 void k_modulation(ModArgs M)
 {
   latency_critical();
-  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * kModWaves + (threadIdx.x >> 6);      // wave-uniform
   if (w >= M.nsh) return;
   const int nr = M.nr;
-  int last = M.last[w];
+  const int last = __builtin_amdgcn_readfirstlane(M.last[w]);
   // a ray that is still descending (only possible in the provisional spectrum of a run that
   // stopped at the previous run's depth and will go on): nothing to integrate yet
-  if (last < 0) { M.out[w] = 0.0; return; }
+  if (last < 0) { if (lane == 0) M.out[w] = 0.0; return; }
   const double *tw = M.tau + w;                           // tw[i*nsh] = tau[i][w]
   if (M.modlevel == -1) {
+    if (lane != 0) return;
     const double tl = tw[(long long)last * M.nsh];
     if (tl < M.toomuch) { M.out[w] = -1; *M.status = 1; return; }
     int ini = last + 1 - 2; if (ini < 0) ini = 0;
@@ -1385,12 +1393,12 @@ void k_modulation(ModArgs M)
     M.out[w] = r * r / (M.srad * M.srad);
     return;
   }
-  const double tlast = tw[(long long)last * M.nsh];
+  const double tlast = readlane_f64(tw[(long long)last * M.nsh], 0);
   const double maxtau = tlast > M.toomuch ? tlast : M.toomuch;
   // integrand on ascending radius: index q = 0..cnt-1 maps to height i = cnt-1-q
   int lastp = last + 1; if (lastp > nr - 1) lastp = nr - 1;
   const int cnt = lastp + 1;                               // points, including the zero pad
-  if (cnt < 3) { M.out[w] = nan(""); *M.status = 2; return; }
+  if (cnt < 3) { if (lane == 0) { M.out[w] = nan(""); *M.status = 2; } return; }
   const double *g = M.gw + (long long)cnt * M.gstride;
   auto val = [&](int q) -> double {
     const int i = cnt - 1 - q;
@@ -1398,12 +1406,18 @@ void k_modulation(ModArgs M)
     const double b = M.ip[i] * M.ip_fct;
     return exp(-tw[(long long)i * M.nsh]) * b;
   };
-  const int even = (cnt % 2 == 0);
+  const int even = (cnt % 2 == 0), npair = (cnt - 1) / 2;
   double acc = 0.0;
-  for (int i = 0; i < (cnt - 1) / 2; i++) {
-    const int j = 2*i + even;
-    acc += (val(j) * g[4*i] + val(j+1) * g[4*i+1] + val(j+2) * g[4*i+2]) * g[4*i+3];
+  for (int i0 = 0; i0 < npair; i0 += 64) {
+    const int i = i0 + lane;
+    double term = 0.0;
+    if (i < npair) {
+      const int j = 2*i + even;
+      term = (val(j) * g[4*i] + val(j+1) * g[4*i+1] + val(j+2) * g[4*i+2]) * g[4*i+3];
+    }
+    acc += wave_sum(term);
   }
+  if (lane != 0) return;
   double res = acc / 6.0;
   if (even) res += M.gh0[cnt] * (val(0) + val(1)) / 2;
   const double rtop = M.ip[0] * M.ip_fct;
