@@ -88,7 +88,7 @@ struct trx_handle {
   DevBuf d_walk, d_wbase, d_part[2];   // partial records: consecutive steps alternate
   std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
   bool walk_temp_ok = true;         // this run's layers are all warmer than kWalkMinTemp
-  struct Plan { bool built = false; DevBuf blo, bhi, off; int64_t records = 0; };
+  struct Plan { bool built = false; DevBuf blo, bhi, off, binw; int64_t records = 0; };
   Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw, ruw, rh; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw, d_ruw, d_rh; };
@@ -784,9 +784,16 @@ int walk_plan(trx_handle *h, int nb, hipStream_t st, WalkPlan &P, trx_handle::Pl
   }
   P.nwaves = h->nwaves; P.ngw = h->ngw; P.wbase = h->d_wbase.as<int32_t>();
   P.blo = pl->blo.as<int32_t>(); P.bhi = pl->bhi.as<int32_t>(); P.off = pl->off.as<int64_t>();
+  // (the per-bin range table: 8 bytes per bin and isotope; above 2^24 entries the combine searches instead)
+  const long long nbinw = (long long)h->nsh * h->niso;
+  const bool with_binw = nbinw > 0 && nbinw <= (1LL << 24);
+  if (!pl->built && with_binw && (rc = ensure(h, pl->binw, 8 * (size_t)nbinw))) return rc;
+  P.binw = with_binw ? pl->binw.as<int32_t>() : nullptr;
   if (!pl->built) {
     hipLaunchKernelGGL(k_wave_plan, dim3(1), dim3(256), 0, st, P, h->niso, h->d_gblock.as<int32_t>(), h->d_gidiv.as<int32_t>(),
                        nb / 2 - 1, (long long)h->lo, (long long)h->hi);
+    if (with_binw)
+      hipLaunchKernelGGL(k_bin_ranges, dim3((unsigned)((nbinw + 255) / 256)), dim3(256), 0, st, P, h->niso, (long long)h->lo, (long long)h->nsh);
     int64_t total = 0;
     HIPCHK(h, hipMemcpyAsync(&total, P.off + h->nwaves, sizeof total, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));                 // once per handle and frame size

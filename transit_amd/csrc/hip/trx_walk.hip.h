@@ -221,6 +221,8 @@ struct WalkPlan {
   const int32_t *wbase;             // [niso + 1] first range of every isotope block
   int32_t *blo, *bhi;               // [nwaves] (bhi < blo: the range cannot reach the shard)
   int64_t *off;                     // [nwaves + 1]
+  int32_t *binw;                    // [niso][bins of the shard][2]: first and one-past-last range of the
+                                    // block that touches the bin (null: the combine searches blo/bhi itself)
 };
 
 __device__ __forceinline__ int walk_block_of(const int32_t *wbase, int niso, int w)
@@ -263,6 +265,31 @@ void k_wave_plan(WalkPlan P, int niso, const int32_t *__restrict__ gblock, const
     if (threadIdx.x == 255) s_carry += s_scan[255];
     __syncthreads();
   }
+}
+
+// The ranges of an isotope block that touch a bin, for the combine: blo and bhi descend with the
+// range index, so they are one run [wa, wz).  Found once per plan here -- the combine used to do
+// these two bisections itself, ~28 dependent loads at the head of every wave.
+__device__ __forceinline__ void ranges_of_bin(const WalkPlan &P, int b, long long j, int &wa, int &wz)
+{
+  const int w0 = P.wbase[b], w1 = P.wbase[b + 1];
+  int a = w0, z = w1;                      // first w with blo[w] <= j
+  while (a < z) { const int m = (a + z) >> 1; if (P.blo[m] <= j) z = m; else a = m + 1; }
+  wa = a;
+  z = w1;                                  // first w >= wa with bhi[w] < j
+  while (a < z) { const int m = (a + z) >> 1; if (P.bhi[m] < j) z = m; else a = m + 1; }
+  wz = a;
+}
+
+__global__ __launch_bounds__(256)
+void k_bin_ranges(WalkPlan P, int niso, long long lo, long long nsh)
+{
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nsh * niso) return;
+  const int b = (int)(t / nsh); const long long j = lo + t % nsh;
+  int wa = 0, wz = 0;
+  if (P.wbase[b] != P.wbase[b + 1]) ranges_of_bin(P, b, j, wa, wz);
+  P.binw[2 * t] = wa; P.binw[2 * t + 1] = wz;
 }
 
 // ---------------------------------------------------------------------------
@@ -625,14 +652,10 @@ void k_walk_combine(CombineArgs C)
       cur_mx = mx; sum = 0.0;
     }
     if (!have) continue;
-    const int w0 = C.P.wbase[b], w1 = C.P.wbase[b + 1];
-    // ranges of the block that touch bin j: bhi and blo descend with w
-    int a = w0, z = w1;                      // first w with blo[w] <= j
-    while (a < z) { const int m = (a + z) >> 1; if (C.P.blo[m] <= j) z = m; else a = m + 1; }
-    const int wa = a;
-    z = w1;                                  // first w >= wa with bhi[w] < j
-    while (a < z) { const int m = (a + z) >> 1; if (C.P.bhi[m] < j) z = m; else a = m + 1; }
-    const int wz = a;
+    // ranges of the block that touch bin j
+    int wa, wz;
+    if (C.P.binw) { const long long t = (long long)b * C.nsh + (j - C.lo); wa = C.P.binw[2 * t]; wz = C.P.binw[2 * t + 1]; }
+    else ranges_of_bin(C.P, b, j, wa, wz);
     for (int w = wa; w < wz; w += 4) {
       double v[4];
 #pragma unroll
