@@ -98,6 +98,27 @@ def measured_traffic(kernel):
     return None, None
 
 
+def measured_valu(kernel):
+    """SQ_INSTS_VALU per launch of `kernel` (weighted over its production instantiations) from the
+    committed SQ pass that matches this tree's kernel sources, or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            if json.load(open(f)).get("kernel_sources") != kernel_source_hash():
+                continue
+            d = json.load(open(f.replace("pmc_traffic", "sq_mix")))
+            tot = n = 0.0
+            for name, k in d["kernels"].items():
+                if kernel in name and ", true>" not in name:
+                    tot += float(k["SQ_INSTS_VALU_avg_launch"]) * k["launches"]
+                    n += k["launches"]
+            if n:
+                return tot / n
+        except Exception:
+            continue
+    return None
+
+
 def make_workload(args, tag, nlines, verb=2, wnhigh=None, unique=True):
     from transit_amd import synth
     d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%s" % (
@@ -389,6 +410,10 @@ def main():
         # per-(wn, layer) arrays, the outputs).  Rank 0's share x world for the job.
         b_alg_run = world * (52.0 * L * R + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
         b_min_run = world * (52.0 * L + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
+        # the roof this kernel is actually near: vector-instruction issue.  A wave64 instruction holds
+        # its SIMD's 16 lanes for 4 clocks; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock.
+        valu = measured_valu(dom) if (world == 1 and args.lines == 1_000_000) else None
+        valu_frac = (valu * 4.0 / (kern[dom] / launches * 1e-3 * 1024 * 2.4e9)) if (valu and kern[dom] > 0) else None
         tr_pair, traffic_file = measured_traffic(dom) if (world == 1 and args.lines == 1_000_000) else (None, None)
         traffic, traffic_raw = tr_pair if tr_pair else (None, None)
         out = {
@@ -430,6 +455,7 @@ def main():
                          "bmin_frac": b_min_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "balg_frac": b_alg_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
+                         "valu_issue_frac": valu_frac,
                          "launches": launches,
                          "note": "achieved = bytes the dominant kernel's data flow must move (32 B per line record, 4 B "
                                  "per accumulated bin, its partial records) / its measured time (HIP events on its own "
