@@ -104,7 +104,7 @@ struct trx_handle {
   // what the host reads back after a run, in ONE device block and one pinned host block:
   // flags (8 ints, byte 0), status (4 ints, byte 64), counters (3 per layer, byte 128)
   DevBuf d_small; DevView d_flags, d_status, d_counters; void *h_small = nullptr; size_t h_small_bytes = 0;
-  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_intens, d_spec, d_acc;
+  DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_intens, d_spec, d_acc, d_geom;
   // opacity grid (optional)
   bool has_grid = false; long og_nmol = 0, og_ntemp = 0, og_nlayer = 0, og_nwave = 0;
   std::vector<double> og_temp; std::vector<int32_t> og_molidx; DevBuf d_og_o, d_og_layer, d_og_itemp, d_iso_mx, d_pm, d_kmaxpm;
@@ -1348,14 +1348,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const bool vertical = o->solution == TRX_SOL_ECLIPSE;
   const int gstride = vertical ? 4 : 4 * (nr / 2 + 1);
   const size_t mw_doubles = vertical ? 0 : (size_t)(nr + 1) * gstride;
-  std::vector<double> geom((size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr, 0.0);
-  double *gw = &geom[0], *gh0 = gw + (size_t)(nr + 1) * gstride;
-  double *mw = gh0 + (nr + 1), *mh0 = mw + mw_doubles;
-  double *pw = mh0 + (nr + 1);            // pair weights by starting layer (vertical rays)
-  double *hrs = pw + 4 * (size_t)nr, *hr0 = hrs + nr;     // slant rays: bracket layer and closest approach per height
+  const size_t n_geom_all = (size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr;
+  std::vector<double> geom(vertical ? n_geom_all : 1, 0.0);       // (transit: device-built, see below)
   {
-    std::vector<double> sx(nr + 1), rr(nr + 1);
-    if (o->solution == TRX_SOL_ECLIPSE) {
+    std::vector<double> sx(nr + 1);
+    if (vertical) {
+      double *gw = &geom[0], *gh0 = gw + (size_t)(nr + 1) * gstride;
+      double *pw = gh0 + (nr + 1) + mw_doubles + (nr + 1);    // pair weights by starting layer (vertical rays)
       // only the two-point ray (start layer nr-2) integrates with tabulated weights (eclipse.c:68-80);
       // all others run on the pair weights below
       const int rs = nr - 2;
@@ -1365,28 +1364,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       simpson_weights(sx.data(), 3, gw + (size_t)rs * gstride, gh0 + rs);
       for (int k = 0; k + 2 < nr; k++) { double h0; simpson_weights(a->radius + k, 3, pw + 4 * (size_t)k, &h0); }
     } else {
-      // impact parameter of every height as the reference's object code computes it
-      // (tau.c:274 under -ffast-math: the reciprocal of rfct is hoisted out of the loop)
-      const double fct = a->rad_fct, recip = 1.0 / fct;
-      for (int k = 0; k < nr; k++) {
-        const double b = (a->radius[k] * fct) * recip;
-        const int rs = bracket_ie(a->radius, 0, nr - 1, b);          // slantpath.c:36
-        hr0[k] = b;
-        if (rs == -5 || rs == -2) { hrs[k] = -1; continue; }         // :37-38
-        if (rs < 0) { hrs[k] = -3; continue; }                       // :39-44
-        hrs[k] = rs;
-        int n = nr - rs;
-        rr[0] = b;
-        for (int i = 1; i < n; i++) rr[i] = a->radius[rs + i];
-        if (n == 2) { rr[2] = rr[1]; rr[1] = (rr[0] + rr[2]) / 2.0; n = 3; }   // :62-74
-        sx[0] = 0.0;
-        for (int i = 1; i < n; i++) sx[i] = std::sqrt(rr[i] * rr[i] - b * b);  // :82-84
-        simpson_weights(sx.data(), n, gw + (size_t)k * gstride, gh0 + k);
-      }
-      for (int cnt = 3; cnt <= nr; cnt++) {                          // slantpath.c:399-408, per point count
-        for (int q = 0; q < cnt; q++) sx[q] = a->radius[nr - 1 - (cnt - 1 - q)] * a->rad_fct;
-        simpson_weights(sx.data(), cnt, mw + (size_t)cnt * gstride, mh0 + cnt);
-      }
+      // transit geometry: built on the device (k_slant_geometry), nothing to prepare or ship here
     }
   }
   std::vector<double> ipv(nr);
@@ -1499,7 +1477,9 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   layer_dev(df, (const int32_t *)(df + off_i32), LH, nr, Y, d_wcut, d_npre);
   const double *d_press = df + LH.extra_off, *d_tempk = d_press + nr, *d_mdens = d_tempk + nr, *d_nH = d_mdens + nr,
                *d_scatpol = d_nH + nr, *d_rad = d_scatpol + nr;
-  const double *d_gw = df + off_geom, *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
+  // (ray geometry: part of the input block in eclipse geometry, a device-built buffer of its own in transit geometry)
+  if (!vertical && (rc = ensure(h, h->d_geom, sizeof(double) * n_geom_all))) return rc;
+  const double *d_gw = vertical ? df + off_geom : h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + mw_doubles, *d_pw = d_mh0 + (nr + 1);
   const double *d_ipv = df + off_ip, *d_ciadens = df + off_cd;
   (void)nli;
@@ -1553,6 +1533,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // after that step's kernels, which are what the GPU is waiting for.
   auto queue_cia = [&]() -> int {
     const auto t0 = std::chrono::steady_clock::now();
+    if (!vertical) {        // the slant rays' geometry, ahead of the CIA kernels: both are waited for by the first optical depth
+      SlantGeomArgs G{};
+      G.rad = d_rad; G.nr = nr; G.fct = a->rad_fct; G.gstride = gstride;
+      G.gw = const_cast<double *>(d_gw); G.gh0 = const_cast<double *>(d_gh0); G.mw = const_cast<double *>(d_mw); G.mh0 = const_cast<double *>(d_mh0);
+      G.hrs = const_cast<double *>(d_pw) + 4 * (size_t)nr; G.hr0 = G.hrs + nr;
+      hipLaunchKernelGGL(k_slant_geometry, dim3((unsigned)(nr + nr - 2)), dim3(64), 0, h->stream2, G);
+    }
     const int rcc = cia_device(h, a, o, d_tempk, d_ciadens, h->stream2);
     if (rcc) return rcc;
     if (hipEventRecord(h->ev_cia, h->stream2) != hipSuccess) return fail(h, TRX_E_HIP, "event");

@@ -1051,6 +1051,65 @@ __device__ __forceinline__ void tau_publish(const TauArgs &T, int nstill, int de
   }
 }
 
+// Ray geometry of the transit solution on the device: per height the impact parameter as the
+// reference's object code forms it (tau.c:274), its bracket layer (slantpath.c:36-44), the
+// Simpson weights of its point set (slantpath.c:62-95; numerical.c:390-425), and per point count
+// the weights of the modulation integral (slantpath.c:399-408).  O(nlayer^2) numbers that depend
+// on the radii alone: the host used to build them (~25 us) and ship them (330 KB) every run.
+// Same operations in the same order as that host code (IEEE sqrt and division, no contraction):
+// the same bits.  One block per height / point count, one lane per Simpson pair.
+struct SlantGeomArgs {
+  const double *rad; int nr; double fct;
+  double *gw, *gh0, *hrs, *hr0;       // per height k: weights [k][gstride], first interval, bracket layer, closest approach
+  double *mw, *mh0;                   // per point count cnt: weights [cnt][gstride], first interval
+  int gstride;
+};
+
+__device__ __forceinline__ void simpson_pair(double xa, double xb, double xc, double *row)
+{
+  const double ha = xb - xa, hb = xc - xb;
+  const double hsum = ha + hb, hratio = hb / ha, hfactor = hsum * hsum / (ha * hb);
+  row[0] = 2.0 - hratio; row[1] = hfactor; row[2] = 2.0 - 1.0 / hratio; row[3] = hsum;
+}
+
+__global__ __launch_bounds__(64)
+void k_slant_geometry(SlantGeomArgs G)
+{
+  const int nr = G.nr, lane = threadIdx.x;
+  if ((int)blockIdx.x < nr) {                              // ---- height k
+    const int k = blockIdx.x;
+    const double recip = 1.0 / G.fct;
+    const double b = (G.rad[k] * G.fct) * recip;
+    const int rs = bracket_ie(G.rad, 0, nr - 1, b);        // slantpath.c:36
+    if (lane == 0) { G.hr0[k] = b; G.hrs[k] = (rs == -5 || rs == -2) ? -1.0 : (rs < 0 ? -3.0 : (double)rs); }
+    if (rs < 0) return;
+    int n = nr - rs;
+    // point i of the set: rr[0] = b, rr[i] = rad[rs + i]; two points become three (slantpath.c:62-74)
+    auto rr = [&](int i) -> double {
+      if (n == 2) return i == 0 ? b : (i == 2 ? G.rad[rs + 1] : (b + G.rad[rs + 1]) / 2.0);
+      return i == 0 ? b : G.rad[rs + i];
+    };
+    const int np = n == 2 ? 3 : n;
+    auto sx = [&](int i) -> double { if (i == 0) return 0.0; const double r = rr(i); return sqrt(r * r - b * b); };   // :82-84
+    if (lane == 0) G.gh0[k] = sx(1) - sx(0);
+    const int even = (np % 2 == 0);
+    for (int i = lane; i < (np - 1) / 2; i += 64) {
+      const int j = 2 * i + even;
+      simpson_pair(sx(j), sx(j + 1), sx(j + 2), G.gw + (long long)k * G.gstride + 4 * i);
+    }
+  } else {                                                 // ---- point count cnt of the modulation integral
+    const int cnt = (int)blockIdx.x - nr + 3;
+    if (cnt > nr) return;
+    auto x = [&](int q) -> double { return G.rad[nr - 1 - (cnt - 1 - q)] * G.fct; };
+    if (lane == 0) G.mh0[cnt] = x(1) - x(0);
+    const int even = (cnt % 2 == 0);
+    for (int i = lane; i < (cnt - 1) / 2; i += 64) {
+      const int j = 2 * i + even;
+      simpson_pair(x(j), x(j + 1), x(j + 2), G.mw + (long long)cnt * G.gstride + 4 * i);
+    }
+  }
+}
+
 // Heights are visited top-down, a chunk of layers per launch (tau.c:235-290).
 // A 256-thread block owns 256/kTauH wavenumbers x kTauH heights:
 //   phase 1 (one lane per wavenumber): total extinction of the chunk's layers
