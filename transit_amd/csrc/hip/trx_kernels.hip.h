@@ -15,6 +15,8 @@
 //                                     phase-major table (k_table_phase_major)
 //   k_grid_extinction                 opacity-grid mode          (extinction.c:535-581)
 //   k_cia_rows/_layers/_eval          CIA extinction            (crosssec.c:272-428)
+//   k_slant_geometry                  transit rays: impact parameters, bracket layers, Simpson weights
+//                                                               (tau.c:274, slantpath.c:36-95, 399-408)
 //   k_optical_depth(_vertical)        total extinction + ray quadrature + toomuch cut
 //                                                               (tau.c:216-305, eclipse.c:29-105,
 //                                                                slantpath.c:19-108)
