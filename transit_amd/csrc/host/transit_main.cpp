@@ -44,6 +44,10 @@ struct Rank {
 
 int main(int argc, char **argv)
 {
+  // three busy queues per handle; next to an RCCL communicator the runtime's default of 4 hardware
+  // queues per device makes two of them share one.  Read by the HIP
+  // runtime when it initialises, which nothing has made it do yet.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   char err[512] = {0};
   trh_problem *P = nullptr;
   const double t_start = now_s();

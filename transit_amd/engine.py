@@ -146,6 +146,9 @@ def _one_hip_runtime():
     binds to it by soname, whichever import order the caller uses.  torch itself is not imported."""
     import importlib.util
     import sys
+    # three busy queues per handle: see INTEGRATION.md section 4 (only effective while the HIP
+    # runtime has not initialised yet; multi-GPU launchers should export it themselves)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "torch" in sys.modules:
         return                                   # torch's runtime is mapped already
     try:
