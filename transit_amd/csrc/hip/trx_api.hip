@@ -1153,9 +1153,37 @@ int trx_create(const trx_static *s, trx_handle **out)
   auto bail = [&](int code) { trx_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return bail(TRX_E_NODEVICE);
   {
+    // Three streams that really overlap: the runtime hands out hardware queues round-robin, and with
+    // other streams in the process (an RCCL communicator, the caller's own) two of ours can land on
+    // ONE queue -- the CIA kernels then ran after the walks instead of under them, +0.11 ms per
+    // spectrum.  So every new stream is probed against the ones it must overlap and replaced (the
+    // next creation gets the next queue) until it does; after 12 tries it is taken as it is.
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
-    if (hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking) != hipSuccess) return bail(TRX_E_HIP);
+    DevBuf probe;
+    if ((rc = ensure(h, probe, 64))) return bail(rc);
+    int *d_flag = probe.as<int>(), *d_saw = d_flag + 8;
+    auto overlaps = [&](hipStream_t a, hipStream_t b) -> bool {
+      int saw = 0;
+      if (hipMemsetAsync(d_flag, 0, 64, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return true;
+      hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, (volatile int *)d_flag, d_saw);
+      hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, (volatile int *)d_flag);
+      if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+      if (hipMemcpy(&saw, d_saw, sizeof saw, hipMemcpyDeviceToHost) != hipSuccess) return true;
+      return saw != 0;
+    };
+    auto concurrent_stream = [&](hipStream_t *out, hipStream_t with1, hipStream_t with2) -> int {
+      std::vector<hipStream_t> rejected;
+      int code = TRX_OK;
+      for (int attempt = 0; attempt < 12; attempt++) {
+        hipStream_t s2 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { code = TRX_E_HIP; break; }
+        if (attempt == 11 || (overlaps(with1, s2) && (!with2 || overlaps(with2, s2)))) { *out = s2; break; }
+        rejected.push_back(s2);                  // kept alive until the end: destroying it would free its slot for the next try
+      }
+      for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+      return code;
+    };
+    if ((rc = concurrent_stream(&h->stream4, h->stream, nullptr)) || (rc = concurrent_stream(&h->stream2, h->stream, h->stream4))) return bail(rc);
   }
   if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming) != hipSuccess ||

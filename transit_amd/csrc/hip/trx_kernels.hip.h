@@ -32,6 +32,22 @@
 namespace trx {
 
 // ---------------------------------------------------------------------------
+// do two streams run concurrently?
+// ---------------------------------------------------------------------------
+// The HIP runtime maps a process's streams onto a few hardware queues per device; two streams
+// on one queue run their kernels one after the other, whatever the program intended.  trx_create
+// probes: k_probe_wait on one stream waits (bounded: ~0.5 ms of the 100 MHz wall clock) for a flag
+// that k_probe_set on the other stream raises.  If the waiter saw the flag, the two overlap.
+__global__ void k_probe_wait(volatile int *flag, int *saw)
+{
+  const unsigned long long t0 = wall_clock64();
+  int v = 0;
+  while ((v = *flag) == 0 && wall_clock64() - t0 < 50000ull) __builtin_amdgcn_s_sleep(8);
+  *saw = v;
+}
+__global__ void k_probe_set(volatile int *flag) { *flag = 1; }
+
+// ---------------------------------------------------------------------------
 // wavefront helpers (64 lanes, fixed butterfly order => deterministic sums)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
