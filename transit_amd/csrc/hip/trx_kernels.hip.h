@@ -577,7 +577,7 @@ void k_accumulate(AccumArgs A)
         for (int t = 0; t < kTileBins; t++) pv[t] = prof[ok[t] ? d0 + (long long)t * A.osamp : 0];
 #pragma unroll
         for (int t = 0; t < kTileBins; t++)
-          if (ok[t]) { acc[t] += sg_k * (double)pv[t]; nb++; }
+          if (ok[t]) { acc[t] = __builtin_fma(sg_k, (double)pv[t], acc[t]); nb++; }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -642,11 +642,11 @@ __device__ __forceinline__ void wide_apply(double (&acc)[kWideM], double sg, con
   const int ta = tt & 0xFFFF, tb = tt >> 16;
   if (ta == 0 && tb == kWideT - 1) {                         // wave-uniform: the profile covers the tile
 #pragma unroll
-    for (int m = 0; m < kWideM; m++) acc[m] += sg * (double)q.v[m];
+    for (int m = 0; m < kWideM; m++) acc[m] = __builtin_fma(sg, (double)q.v[m], acc[m]);     // (fused, as in the walk)
   } else {
 #pragma unroll
     for (int m = 0; m < kWideM; m++)
-      if (t0 + m >= ta && t0 + m <= tb) acc[m] += sg * (double)q.v[m];
+      if (t0 + m >= ta && t0 + m <= tb) acc[m] = __builtin_fma(sg, (double)q.v[m], acc[m]);
   }
 }
 
