@@ -1272,7 +1272,18 @@ void k_optical_depth_vertical(TauArgs T)
   latency_critical();
   __shared__ double s_out[STAGED ? 2 * kMaxChunk * 64 : 1];
   __shared__ double s_in[STAGED ? (kMaxChunk + 1) * 64 : 1];
+  // the chunk's radii and pair weights, staged once: read per layer from global memory (the same
+  // for every lane, but fetched as vector loads) they put a memory round trip -- ~1 us next to a
+  // running walk -- into every step of the chain
+  __shared__ double s_rad[kMaxChunk + 3];                  // s_rad[j] = rad[r_top + 1 - j]
+  __shared__ double s_pw[4 * kMaxChunk];                   // s_pw[4c + q] = pw[4 (r_top - c) + q]
   const int nr = T.nr;
+  for (int j = threadIdx.x; j < T.nc + 3; j += blockDim.x) {
+    const int r = T.r_top + 1 - j;
+    s_rad[j] = (r >= 0 && r < nr) ? T.rad[r] : 0.0;
+  }
+  for (int j = threadIdx.x; j < 4 * T.nc; j += blockDim.x) s_pw[j] = T.pw[4 * (T.r_top - (j >> 2)) + (j & 3)];
+  __syncthreads();
   int nstill = 0, deep = 0;
   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
   if (T.last[w] < 0) {
@@ -1311,14 +1322,14 @@ void k_optical_depth_vertical(TauArgs T)
         tv = 0.0;                                           // eclipse.c:45-46
       } else if (n == 2) {                                  // eclipse.c:65, 68-80 (value not kept)
         // needs the layer below: it belongs to this chunk (the first chunk has >= 3 layers)
-        const double yp = parab3(T.rad[rs-1], T.rad[rs], ybelow, yraw, y1, T.rad[rs]);
+        const double yp = parab3(s_rad[c + 2], s_rad[c + 1], ybelow, yraw, y1, s_rad[c + 1]);
         const double *g = T.gw + (long long)rs * T.gstride;
         tv = T.rad_fct * (((yp * g[0] + ((y1 + yp) / 2.0) * g[1] + y1 * g[2]) * g[3]) / 6.0);
       } else {
-        y0 = parab3(T.rad[rs], T.rad[rs+1], yraw, y1, y2, T.rad[rs]);      // kept: eclipse.c:66
-        const double *p = T.pw + 4 * rs;
+        y0 = parab3(s_rad[c + 1], s_rad[c], yraw, y1, y2, s_rad[c + 1]);      // kept: eclipse.c:66
+        const double *p = s_pw + 4 * c;
         const double a0 = (y0 * p[0] + y1 * p[1] + y2 * p[2]) * p[3] + a2;
-        double res = (n & 1) ? a0 / 6.0 : a1 / 6.0 + (T.rad[rs+1] - T.rad[rs]) * (y0 + y1) / 2;
+        double res = (n & 1) ? a0 / 6.0 : a1 / 6.0 + (s_rad[c] - s_rad[c + 1]) * (y0 + y1) / 2;
         tv = T.rad_fct * res;
         a2 = a1; a1 = a0;
       }
