@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "trx_device.h"
 #include "../trx_numerics.h"
 
@@ -1276,13 +1277,27 @@ void k_optical_depth_vertical(TauArgs T)
   // for every lane, but fetched as vector loads) they put a memory round trip -- ~1 us next to a
   // running walk -- into every step of the chain
   __shared__ double s_rad[kMaxChunk + 3];                  // s_rad[j] = rad[r_top + 1 - j]
-  __shared__ double s_pw[4 * kMaxChunk];                   // s_pw[4c + q] = pw[4 (r_top - c) + q]
+  // per layer c of the chunk (ray bottom rs = r_top - c), everything the chain needs that does not
+  // depend on the wavenumber: {step, t0, twice_sq (parab3_nodes), pair weights p0..p3, rad[rs]}
+  __shared__ double s_lay[(kMaxChunk + 1) * 8];
   const int nr = T.nr;
   for (int j = threadIdx.x; j < T.nc + 3; j += blockDim.x) {
     const int r = T.r_top + 1 - j;
     s_rad[j] = (r >= 0 && r < nr) ? T.rad[r] : 0.0;
   }
-  for (int j = threadIdx.x; j < 4 * T.nc; j += blockDim.x) s_pw[j] = T.pw[4 * (T.r_top - (j >> 2)) + (j & 3)];
+  for (int c = threadIdx.x; c <= T.nc; c += blockDim.x) {
+    const int rs = T.r_top - c;
+    double *L = s_lay + 8 * c;
+    for (int q = 0; q < 8; q++) L[q] = 0.0;
+    if (c < T.nc && rs >= 0) {
+      if (rs + 1 < nr) {                                   // (the 3+ point rays: nodes rad[rs], rad[rs+1])
+        const double step = T.rad[rs + 1] - T.rad[rs];
+        L[0] = step; L[1] = T.rad[rs] / step; L[2] = 2.0 * step * step;
+      }
+      for (int q = 0; q < 4; q++) L[3 + q] = T.pw[4 * rs + q];
+      L[7] = T.rad[rs];
+    }
+  }
   __syncthreads();
   int nstill = 0, deep = 0;
   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
@@ -1310,41 +1325,74 @@ void k_optical_depth_vertical(TauArgs T)
       // total extinction of the layers ahead is requested six steps before it is used
       q0 = total_ext(0); q1 = total_ext(1); q2 = total_ext(2); q3 = total_ext(3); q4 = total_ext(4); q5 = total_ext(5);
     }
-    int done = 0;
-    for (int c = 0; c < T.nc; c++) {
-      const int rs = T.r_top - c, ri = nr - 1 - rs, n = nr - rs;
-      const long long k = (long long)rs * T.nsh + w;
-      double yraw, ybelow;
-      if (STAGED) { yraw = s_in[c * 64 + threadIdx.x]; ybelow = s_in[(c + 1) * 64 + threadIdx.x]; }
-      else { yraw = q0; ybelow = q1; q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6); }
-      double tv, y0 = yraw;
-      if (n == 1) {
+    // One layer of the chain.  SHORT: the 1- and 2-point rays of the top two layers may occur.
+    // The two Simpson forms are selected, not branched on, so that consecutive layers make one
+    // straight piece of code.
+    auto layer = [&](auto short_rays, int c, double yraw, double ybelow, double &y0, double &tv) {
+      const int rs = T.r_top - c, n = nr - rs;
+      const double *L = s_lay + 8 * c;
+      y0 = yraw;
+      if (decltype(short_rays)::value && n == 1) {
         tv = 0.0;                                           // eclipse.c:45-46
-      } else if (n == 2) {                                  // eclipse.c:65, 68-80 (value not kept)
+      } else if (decltype(short_rays)::value && n == 2) {   // eclipse.c:65, 68-80 (value not kept)
         // needs the layer below: it belongs to this chunk (the first chunk has >= 3 layers)
         const double yp = parab3(s_rad[c + 2], s_rad[c + 1], ybelow, yraw, y1, s_rad[c + 1]);
         const double *g = T.gw + (long long)rs * T.gstride;
         tv = T.rad_fct * (((yp * g[0] + ((y1 + yp) / 2.0) * g[1] + y1 * g[2]) * g[3]) / 6.0);
       } else {
-        y0 = parab3(s_rad[c + 1], s_rad[c], yraw, y1, y2, s_rad[c + 1]);      // kept: eclipse.c:66
-        const double *p = s_pw + 4 * c;
-        const double a0 = (y0 * p[0] + y1 * p[1] + y2 * p[2]) * p[3] + a2;
-        double res = (n & 1) ? a0 / 6.0 : a1 / 6.0 + (s_rad[c] - s_rad[c + 1]) * (y0 + y1) / 2;
-        tv = T.rad_fct * res;
+        y0 = parab3_nodes(L[0], L[1], L[2], yraw, y1, y2, L[7]);          // kept: eclipse.c:66
+        const double a0 = (y0 * L[3] + y1 * L[4] + y2 * L[5]) * L[6] + a2;
+        const bool odd = n & 1;
+        const double sixth = (odd ? a0 : a1) / 6.0;
+        const double with_first = sixth + L[0] * (y0 + y1) / 2;
+        tv = T.rad_fct * (odd ? sixth : with_first);
         a2 = a1; a1 = a0;
       }
-      if (STAGED) { s_out[(2 * c) * 64 + threadIdx.x] = y0; s_out[(2 * c + 1) * 64 + threadIdx.x] = tv; }
-      else { T.er[k] = y0; T.tau[(long long)ri * T.nsh + w] = tv; }
       y2 = y1; y1 = y0;
-      done = c + 1;
-      if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
-    }
-    if (STAGED)
-      for (int c = 0; c < done; c++) {
-        const int rs = T.r_top - c;
-        T.er[(long long)rs * T.nsh + w] = s_out[(2 * c) * 64 + threadIdx.x];
-        T.tau[(long long)(nr - 1 - rs) * T.nsh + w] = s_out[(2 * c + 1) * 64 + threadIdx.x];
+    };
+    int done = 0;
+    if constexpr (STAGED) {
+      // A ray ends at the first layer whose optical depth passes toomuch (tau.c:277-287, 299-304),
+      // but a test per layer would put that layer's whole Simpson sum and division between one
+      // parabola and the next.  Results go to LDS whether the ray is still alive or not (only the
+      // first `done` are copied out), so the test can wait: once per four layers, the four
+      // Simpson sums overlapping the parabola chain.
+      bool alive = true;
+      int hit = -1;
+      auto one = [&](auto short_rays, int c) {
+        double y0, tv;
+        layer(short_rays, c, s_in[c * 64 + threadIdx.x], s_in[(c + 1) * 64 + threadIdx.x], y0, tv);
+        s_out[(2 * c) * 64 + threadIdx.x] = y0; s_out[(2 * c + 1) * 64 + threadIdx.x] = tv;
+        const int ri = nr - 1 - (T.r_top - c);
+        const bool ends = alive & ((tv > T.toomuch) | (ri == nr - 1));    // (no short cuts: no branches)
+        done = alive ? c + 1 : done;
+        hit = ends ? ri : hit;
+        alive = alive & !ends;
+      };
+      int c = 0;
+      for (; alive && c < T.nc && nr - (T.r_top - c) < 3; c++) one(std::true_type(), c);
+      for (; alive && c + 4 <= T.nc; c += 4) {
+        one(std::false_type(), c); one(std::false_type(), c + 1);
+        one(std::false_type(), c + 2); one(std::false_type(), c + 3);
       }
+      for (; alive && c < T.nc; c++) one(std::false_type(), c);
+      if (!alive) { T.last[w] = hit; still = false; }
+      for (int d = 0; d < done; d++) {
+        const int rs = T.r_top - d;
+        T.er[(long long)rs * T.nsh + w] = s_out[(2 * d) * 64 + threadIdx.x];
+        T.tau[(long long)(nr - 1 - rs) * T.nsh + w] = s_out[(2 * d + 1) * 64 + threadIdx.x];
+      }
+    } else {
+      for (int c = 0; c < T.nc; c++) {
+        const int rs = T.r_top - c, ri = nr - 1 - rs;
+        const double yraw = q0, ybelow = q1;
+        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6);
+        double y0, tv;
+        layer(std::true_type(), c, yraw, ybelow, y0, tv);
+        T.er[(long long)rs * T.nsh + w] = y0; T.tau[(long long)ri * T.nsh + w] = tv;
+        if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
+      }
+    }
     T.acc[w] = a1; T.acc[T.nsh + w] = a2;
     nstill += still;
   }

@@ -77,6 +77,18 @@ TRX_HD double parab3(double node0, double node1, double v0, double v1, double v2
   return at * at * quad + at * lin + cst;
 }
 
+// The same with the node-only terms handed in (they are the same for every wavenumber of a layer:
+// a kernel computes them once per layer, off its per-ray dependency chain).  step = node1 - node0,
+// t0 = node0 / step, twice_sq = 2.0 * step * step: the very expressions of parab3, so the same bits.
+TRX_HD double parab3_nodes(double step, double t0, double twice_sq, double v0, double v1, double v2, double at)
+{
+  const double bend = v0 + v2 - 2*v1;
+  const double quad = bend / twice_sq;
+  const double lin  = (v2 - v1 - (t0 + 1.5) * bend) / step;
+  const double cst  = v0 + t0 * (v2 - 4*v1 + 3*v0 + t0 * bend) / 2.0;
+  return at * at * quad + at * lin + cst;
+}
+
 // pu/src/spline.c:12-48 + 186-206 (tri / spline_init).  Scratch arrays u, v of
 // length n are supplied by the caller (no allocation: usable in a kernel).
 // Strided access so that a kernel can keep column-major scratch.
