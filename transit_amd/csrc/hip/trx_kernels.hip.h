@@ -1278,8 +1278,10 @@ void k_optical_depth_vertical(TauArgs T)
   // running walk -- into every step of the chain
   __shared__ double s_rad[kMaxChunk + 3];                  // s_rad[j] = rad[r_top + 1 - j]
   // per layer c of the chunk (ray bottom rs = r_top - c), everything the chain needs that does not
-  // depend on the wavenumber: {step, t0, twice_sq (parab3_nodes), pair weights p0..p3, rad[rs]}
-  __shared__ double s_lay[(kMaxChunk + 1) * 8];
+  // depend on the wavenumber: {step, t0, twice_sq (parab3_nodes), pair weights p0..p3, rad[rs],
+  // 1/step, 1/twice_sq (parab3_recip)}
+  constexpr int kLay = 10;
+  __shared__ double s_lay[(kMaxChunk + 1) * kLay];
   const int nr = T.nr;
   for (int j = threadIdx.x; j < T.nc + 3; j += blockDim.x) {
     const int r = T.r_top + 1 - j;
@@ -1287,12 +1289,13 @@ void k_optical_depth_vertical(TauArgs T)
   }
   for (int c = threadIdx.x; c <= T.nc; c += blockDim.x) {
     const int rs = T.r_top - c;
-    double *L = s_lay + 8 * c;
-    for (int q = 0; q < 8; q++) L[q] = 0.0;
+    double *L = s_lay + kLay * c;
+    for (int q = 0; q < kLay; q++) L[q] = 0.0;
     if (c < T.nc && rs >= 0) {
       if (rs + 1 < nr) {                                   // (the 3+ point rays: nodes rad[rs], rad[rs+1])
         const double step = T.rad[rs + 1] - T.rad[rs];
         L[0] = step; L[1] = T.rad[rs] / step; L[2] = 2.0 * step * step;
+        L[8] = 1.0 / step; L[9] = 1.0 / L[2];
       }
       for (int q = 0; q < 4; q++) L[3 + q] = T.pw[4 * rs + q];
       L[7] = T.rad[rs];
@@ -1330,7 +1333,7 @@ void k_optical_depth_vertical(TauArgs T)
     // straight piece of code.
     auto layer = [&](auto short_rays, int c, double yraw, double ybelow, double &y0, double &tv) {
       const int rs = T.r_top - c, n = nr - rs;
-      const double *L = s_lay + 8 * c;
+      const double *L = s_lay + kLay * c;
       y0 = yraw;
       if (decltype(short_rays)::value && n == 1) {
         tv = 0.0;                                           // eclipse.c:45-46
@@ -1340,10 +1343,12 @@ void k_optical_depth_vertical(TauArgs T)
         const double *g = T.gw + (long long)rs * T.gstride;
         tv = T.rad_fct * (((yp * g[0] + ((y1 + yp) / 2.0) * g[1] + y1 * g[2]) * g[3]) / 6.0);
       } else {
-        y0 = parab3_nodes(L[0], L[1], L[2], yraw, y1, y2, L[7]);          // kept: eclipse.c:66
+        // (the three divisions of a layer as residual-corrected products, trx_numerics.h: the
+        // chain is one wave issuing ~6 clocks per instruction, a division is 13 of them)
+        y0 = parab3_recip(L[0], L[8], L[1], L[2], L[9], yraw, y1, y2, L[7]);   // kept: eclipse.c:66
         const double a0 = (y0 * L[3] + y1 * L[4] + y2 * L[5]) * L[6] + a2;
         const bool odd = n & 1;
-        const double sixth = (odd ? a0 : a1) / 6.0;
+        const double sixth = quotient_rn(odd ? a0 : a1, 6.0, 1.0 / 6.0);
         const double with_first = sixth + L[0] * (y0 + y1) / 2;
         tv = T.rad_fct * (odd ? sixth : with_first);
         a2 = a1; a1 = a0;
@@ -1358,16 +1363,13 @@ void k_optical_depth_vertical(TauArgs T)
       // first `done` are copied out), so the test can wait: once per four layers, the four
       // Simpson sums overlapping the parabola chain.
       bool alive = true;
-      int hit = -1;
       auto one = [&](auto short_rays, int c) {
         double y0, tv;
         layer(short_rays, c, s_in[c * 64 + threadIdx.x], s_in[(c + 1) * 64 + threadIdx.x], y0, tv);
         s_out[(2 * c) * 64 + threadIdx.x] = y0; s_out[(2 * c + 1) * 64 + threadIdx.x] = tv;
         const int ri = nr - 1 - (T.r_top - c);
-        const bool ends = alive & ((tv > T.toomuch) | (ri == nr - 1));    // (no short cuts: no branches)
-        done = alive ? c + 1 : done;
-        hit = ends ? ri : hit;
-        alive = alive & !ends;
+        done += alive;                                                    // (no short cuts: no branches)
+        alive = alive & !((tv > T.toomuch) | (ri == nr - 1));
       };
       int c = 0;
       for (; alive && c < T.nc && nr - (T.r_top - c) < 3; c++) one(std::true_type(), c);
@@ -1376,7 +1378,7 @@ void k_optical_depth_vertical(TauArgs T)
         one(std::false_type(), c + 2); one(std::false_type(), c + 3);
       }
       for (; alive && c < T.nc; c++) one(std::false_type(), c);
-      if (!alive) { T.last[w] = hit; still = false; }
+      if (!alive) { T.last[w] = nr - 1 - (T.r_top - (done - 1)); still = false; }
       for (int d = 0; d < done; d++) {
         const int rs = T.r_top - d;
         T.er[(long long)rs * T.nsh + w] = s_out[(2 * d) * 64 + threadIdx.x];

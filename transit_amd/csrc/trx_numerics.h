@@ -89,6 +89,36 @@ TRX_HD double parab3_nodes(double step, double t0, double twice_sq, double v0, d
   return at * at * quad + at * lin + cst;
 }
 
+// x / d, correctly rounded, for a divisor whose reciprocal rd = 1.0 / d (itself a correctly
+// rounded division) is known beforehand: two residual corrections of x * rd, five dependent
+// multiply-adds instead of the ~13 instructions (one of them the slow reciprocal) of a division.
+// After the first correction the quotient is within one unit of the last place; a residual
+// x - q d taken exactly (fused) and applied with the correctly rounded reciprocal then lands on
+// the rounded quotient itself (Markstein, IBM J. Res. Dev. 34, 1990, theorem 8.5; the exceptional
+// divisors of that theorem are those whose reciprocal is not correctly rounded, excluded here).
+// Holds while no intermediate leaves the normal range: |x| between ~1e-290 and ~1e290 or zero
+// (an optical depth or extinction outside of it has no physical meaning; it comes out within a
+// few units of the last denormal place instead).  tests/test_numerics.py checks 10^7 operands
+// against the division, with the divisors the kernels use.
+TRX_HD double quotient_rn(double x, double d, double rd)
+{
+  const double q0 = x * rd;
+  const double q1 = __builtin_fma(__builtin_fma(-q0, d, x), rd, q0);
+  return __builtin_fma(__builtin_fma(-q1, d, x), rd, q1);
+}
+
+// parab3_nodes with the two divisors' reciprocals handed in as well (r_step = 1.0 / step,
+// r_twice_sq = 1.0 / twice_sq): the same bits again, without a division on the chain.
+TRX_HD double parab3_recip(double step, double r_step, double t0, double twice_sq, double r_twice_sq,
+                           double v0, double v1, double v2, double at)
+{
+  const double bend = v0 + v2 - 2*v1;
+  const double quad = quotient_rn(bend, twice_sq, r_twice_sq);
+  const double lin  = quotient_rn(v2 - v1 - (t0 + 1.5) * bend, step, r_step);
+  const double cst  = v0 + t0 * (v2 - 4*v1 + 3*v0 + t0 * bend) / 2.0;
+  return at * at * quad + at * lin + cst;
+}
+
 // pu/src/spline.c:12-48 + 186-206 (tri / spline_init).  Scratch arrays u, v of
 // length n are supplied by the caller (no allocation: usable in a kernel).
 // Strided access so that a kernel can keep column-major scratch.
