@@ -72,6 +72,8 @@ struct trx_handle {
   // both tables carry kTabPad zero floats in front and behind: k_accumulate_wide reads whole
   // 4-float lane segments around a profile row and masks what lies outside the row
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
+  // the walk's copy: phase-major rows with kWalkPad zeros behind each, one WalkProfile per table entry
+  DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
   DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge, d_cntsub;
@@ -330,10 +332,45 @@ int build_table(trx_handle *h, const trx_static *s)
     for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
       const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
       hipLaunchKernelGGL(k_table_phase_major, dim3(32, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
-                         d_joffT.as<long long>() + j0, h->tab, h->d_tabT.as<float>() + kTabPad, s->osamp);
+                         d_joffT.as<long long>() + j0, h->tab, h->d_tabT.as<float>() + kTabPad, s->osamp, 0);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->tabT = h->d_tabT.as<float>() + kTabPad; h->poffT = h->d_poffT.as<long long>();
+  }
+  // The walk's copy (trx_walk.hip.h): phase-major rows, each followed by kWalkPad zeros -- the
+  // bins of a frame are CONSECUTIVE entries of one row, and what a narrow profile does not reach
+  // is zero by position (the pad behind a row is also the pad in front of the next).  One
+  // descriptor per table entry.  32-bit byte offsets: the walk is off when the copy passes 4 GB.
+  {
+    std::vector<long long> joffW(jobs.size());
+    long long totW = 0;
+    for (size_t j = 0; j < jobs.size(); j++) { joffW[j] = totW; totW += (long long)s->osamp * ((jobs[j].nv - 1) / s->osamp + 1 + kWalkPad); }
+    h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32);
+    if (h->tabw_ok) {
+      std::vector<WalkProfile> desc((size_t)s->ndop * s->nlor);
+      size_t j = 0;
+      for (int i = 0; i < s->ndop; i++)
+        for (int k = 0; k < s->nlor; k++) {
+          const size_t e = (size_t)i * s->nlor + k;
+          if (h->adop[i] * 10.0 < h->alor[k] && i != 0) { desc[e] = desc[e - s->nlor]; continue; }
+          const long long ps = h->psize[e], K = (2 * ps) / s->osamp + 1;
+          desc[e].centre4 = (uint32_t)(4 * (joffW[j++] + ps / s->osamp));
+          desc[e].rowb = (int32_t)(4 * (K + kWalkPad));
+          desc[e].psr = (int32_t)(ps % s->osamp);
+          desc[e].ps = (int32_t)ps;
+        }
+      DevBuf d_joffW;
+      if ((rc = upload(h, d_joffW, joffW)) || (rc = upload(h, h->d_walkprof, desc))) return rc;
+      if ((rc = ensure(h, h->d_tabW, sizeof(float) * ((size_t)totW + 2 * kTabPad)))) return rc;
+      HIPCHK(h, hipMemsetAsync(h->d_tabW.p, 0, sizeof(float) * ((size_t)totW + 2 * kTabPad), h->stream));
+      for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
+        const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
+        hipLaunchKernelGGL(k_table_phase_major, dim3(32, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
+                           d_joffW.as<long long>() + j0, h->tab, h->d_tabW.as<float>() + kTabPad, s->osamp, kWalkPad);
+      }
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      h->tabW = h->d_tabW.as<float>() + kTabPad;
+    }
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -443,7 +480,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
   // ranges of ngw consecutive groups per isotope block
   // (32-bit byte offsets into the widened table: 8*tab_n + 64*osamp must stay below 2^32)
-  h->walk_ok = s->osamp < (1 << 21) && h->tab_n < ((int64_t)1 << 28) && !gfirst.empty();
+  h->walk_ok = h->tabw_ok && s->osamp < (1 << 21) && h->tab_n < ((int64_t)1 << 28) && !gfirst.empty();
   if (h->walk_ok) {
     // Groups per range: ~2 rounds of resident waves (the hardware balances the rounds).  Taken from
     // the WHOLE list, not from what reaches this shard: the range size is part of the order of the
@@ -861,6 +898,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.dthr = h->d_dopthr.as<double>(); A.e2tab = h->d_e2tab.as<double>();
   A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
   A.table = h->tab; A.zero_index = h->tab_n;
+  A.tabw = h->tabW; A.walkprof = h->d_walkprof.as<WalkProfile>();
   A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
   // a shard launches only the ranges that can reach it: per isotope block the groups whose cells

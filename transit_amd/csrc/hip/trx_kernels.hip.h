@@ -794,10 +794,11 @@ void k_accumulate_wide(WideArgs W)
   }
 }
 
-// phase-major copy of one profile: tabT[offT + ph*K + k] = tab[off + osamp*k + ph]
+// phase-major copy of one profile: tabT[offT + ph*(K + pad) + k] = tab[off + osamp*k + ph], each row
+// followed by `pad` zeros (pad = 0: the wide-profile kernel's copy; kWalkPad: the walk's)
 __global__ __launch_bounds__(256)
 void k_table_phase_major(const ProfileJob *jobs, const long long *joffT, const float *__restrict__ tab,
-                         float *__restrict__ tabT, int of)
+                         float *__restrict__ tabT, int of, int pad)
 {
   const ProfileJob J = jobs[blockIdx.y];
   const long long offT = joffT[blockIdx.y];
@@ -807,7 +808,7 @@ void k_table_phase_major(const ProfileJob *jobs, const long long *joffT, const f
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int ph = (int)(t / K), k = (int)(t - (long long)ph * K);
     const long long q = (long long)of * k + ph;
-    tabT[offT + t] = (q < npt) ? tab[J.off + q] : 0.f;
+    tabT[offT + (long long)ph * (K + pad) + k] = (q < npt) ? tab[J.off + q] : 0.f;
   }
 }
 

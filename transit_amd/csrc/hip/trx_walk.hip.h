@@ -316,6 +316,21 @@ constexpr double kWalkMinTemp = 1.4387752 * kRebaseSpan * 256.0 * 1.05;
 
 constexpr int kWalkMaxFrame = 16;    // bins of the widest frame (k_line_walk<16>)
 
+// The walk's copy of the Voigt table ("tabW", built by trx_create): per profile `osamp` rows, row
+// `ph` holding the entries q = osamp*kk + ph, kk = 0..K-1, followed by kWalkPad zeros.  The bins of a
+// frame sit a whole cell apart: they are CONSECUTIVE entries of one row, one or two wide loads per
+// lane instead of a load per bin, and where a profile does not reach the entries are zero by
+// position (a row's pad is also the pad in front of the next row; kTabPad zeros around the whole).
+constexpr int kWalkPad = kWalkMaxFrame / 2;
+struct alignas(16) WalkProfile {
+  uint32_t centre4;                  // byte offset of (row 0, kk = ps / osamp)
+  int32_t rowb;                      // bytes per row, 4*(K + kWalkPad)
+  int32_t psr;                       // ps % osamp
+  int32_t ps;                        // half-width in table samples
+};
+// frames of at least this many bins read tabW (the narrower ones: a load per bin from the table itself)
+constexpr int kWalkRowsFrom = 4;
+
 // trx_create builds the records on the device from the line and group arrays it has just uploaded
 __global__ __launch_bounds__(256)
 void k_walk_records(long long n, const double *__restrict__ wavn, const double *__restrict__ elow, const double *__restrict__ gf,
@@ -368,6 +383,7 @@ struct WalkArgs {
   const int32_t *psize; const long long *poff;
   long long zero_index;             // index (in `table`) where kWalkMaxFrame*osamp zeros begin
   const float *table;               // the Voigt table, followed by kWalkMaxFrame cells of zeros (k_table_padded)
+  const float *tabw; const WalkProfile *walkprof;   // the walk's row copy and its descriptors [ndop][nlor]
   double *part;                     // [records][64]
   unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
   const int *flags; const int *last; int eager;
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(64 * kWalkWaves)
 void k_line_walk(WalkArgs A)
 {
   constexpr int Rc = NB / 2 - 1;
+  constexpr bool ROWS = !PROF && NB >= kWalkRowsFrom;     // (counting runs keep the per-bin form: they count per bin)
   if (!A.eager && A.flags[0] == 0) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int w = blockIdx.x * kWalkWaves + wv;                  // wave-uniform
@@ -450,6 +467,8 @@ void k_line_walk(WalkArgs A)
   int ps_cur = A.psize[lo_i * A.nlor + il];
   unsigned vo_cur = 4u * (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);   // byte offset of the profile centre
   const unsigned vo_st8 = 4u * vo_st;
+  WalkProfile wp_cur{}, wp_st{};
+  if (ROWS) { wp_cur = A.walkprof[lo_i * A.nlor + il]; wp_st = A.walkprof[idst * A.nlor + il]; }
 
   double acc[NB];
 #pragma unroll
@@ -498,6 +517,7 @@ void k_line_walk(WalkArgs A)
   for (int k = 0; k < NB; k++) tab_k[k] = (const char *)A.table + 4LL * (k - Rc - 1) * A.osamp;
   const unsigned vzero = 4u * (unsigned)(A.zero_index + (long long)(Rc + 1) * A.osamp);
   const unsigned cell8 = 4u * (unsigned)A.osamp;
+  const char *tabw_base = (const char *)A.tabw - 4 * (Rc + 1);     // (slot 0 of a row segment; the copy has a front pad)
 
   // line records through the scalar cache: the address is wave-uniform and the data constant
   typedef const __attribute__((address_space(4))) double *ScalarF64;
@@ -549,6 +569,7 @@ void k_line_walk(WalkArgs A)
               lo_i--; thr_lo = s_thr[lo_i];
               ps_cur = A.psize[lo_i * A.nlor + il];
               vo_cur = 4u * (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);
+              if (ROWS) wp_cur = A.walkprof[lo_i * A.nlor + il];
             }
           } while (__any(v < thr_lo));
         }
@@ -577,17 +598,33 @@ void k_line_walk(WalkArgs A)
         }
         // ---- bins: slot k is bin jc - Rc + k at fine distance d = (k - Rc)*osamp - imod from the line
         // (a bin outside the shard may be accumulated too: it never leaves the frame, see flush)
-        kk_p = kk;
         pend = true;
-        const int ps_act = act ? ps : -1;                       // a lane that sits out reaches no slot
-        const unsigned vbase = vo8 + cell8 - 4u * (unsigned)imod;
+        if (ROWS) {
+          // one row of the lane's profile holds all the frame's bins: row ph = (ps - imod) mod osamp,
+          // entry kk = (ps - imod) div osamp for the centre slot -- from the profile's ps = psq*osamp + psr
+          // without a division: psr >= imod ? (psr - imod, psq) : (psr - imod + osamp, psq - 1).
+          // A lane that sits out adds 0 * (whatever it reads).
+          kk_p = act ? kk : 0.0;
+          const unsigned c4 = own ? wp_cur.centre4 : wp_st.centre4;
+          const int rb = own ? wp_cur.rowb : wp_st.rowb;
+          const int d = (own ? wp_cur.psr : wp_st.psr) - imod, sgn = d >> 31;          // sgn = -1: borrowed a cell
+          const unsigned at = c4 + (unsigned)((d + (sgn & A.osamp)) * rb) + (unsigned)((sgn + 1) << 2);
+          struct alignas(4) Row { float v[NB]; } row;
+          __builtin_memcpy(&row, tabw_base + at, sizeof row);       // 4-byte aligned wide loads
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-          // |d| with the sign known per slot: d <= 0 up to the centre slot, > 0 beyond (imod < osamp)
-          const int dist = k <= Rc ? (Rc - k) * A.osamp + imod : (k - Rc) * A.osamp - imod;      // wave-uniform
-          const bool ok = dist <= ps_act;
-          pv_p[k] = *(const float *)(tab_k[k] + (ok ? vbase : vzero));
-          if (PROF && ok && cell - Rc + k >= lo32 && cell - Rc + k < hi32) nb++;
+          for (int k = 0; k < NB; k++) pv_p[k] = row.v[k];
+        } else {
+          kk_p = kk;
+          const int ps_act = act ? ps : -1;                       // a lane that sits out reaches no slot
+          const unsigned vbase = vo8 + cell8 - 4u * (unsigned)imod;
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            // |d| with the sign known per slot: d <= 0 up to the centre slot, > 0 beyond (imod < osamp)
+            const int dist = k <= Rc ? (Rc - k) * A.osamp + imod : (k - Rc) * A.osamp - imod;      // wave-uniform
+            const bool ok = dist <= ps_act;
+            pv_p[k] = *(const float *)(tab_k[k] + (ok ? vbase : vzero));
+            if (PROF && ok && cell - Rc + k >= lo32 && cell - Rc + k < hi32) nb++;
+          }
         }
       }
     }
