@@ -370,6 +370,25 @@ def main():
         t0 = time.time(); e2 = Engine(st); extras["ms_create_total"] = 1e3 * (time.time() - t0)
         t0 = time.time(); e2.run(P.atm, opts); extras["ms_first_spectrum_cold"] = 1e3 * (time.time() - t0)
         e2.close()
+        if not args.no_extras:
+            # several handles computing spectra at the same time (retrieval chains sharing a GPU): one
+            # spectrum's launch gaps and latency chains are another one's room.  Not the headline:
+            # BASELINE's metric is one spectrum at a time.
+            import threading
+            engs = [Engine(st) for _ in range(3)]
+            def _loop(e, n):
+                for _ in range(n):
+                    e.run(P.atm, opts)
+            for e in engs:
+                _loop(e, 5)
+            n3 = max(20, args.steps // 2)
+            th = [threading.Thread(target=_loop, args=(e, n3)) for e in engs]
+            t0 = time.time()
+            for t in th: t.start()
+            for t in th: t.join()
+            extras["ms_per_spectrum_3_handles_at_once"] = 1e3 * (time.time() - t0) / (3 * n3)
+            for e in engs:
+                e.close()
         exe = os.path.join(ROOT, "transit_amd", "lib", "transit_hip")
         if os.path.exists(exe):          # the one-shot command, fresh process, same input files
             t0 = time.time()
