@@ -185,13 +185,19 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__res
     }
   }
   const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
+  // the wave's layer scalars in LDS, one round trip for all of them (read per layer from global
+  // memory they were a dependent round trip per layer of this one-wave chain)
+  __shared__ double s_ct[kLayerMaxGroup], s_f[kLayerMaxGroup * kMaxIso];
+  for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64) s_f[t] = Y.strength_f[r0 * niso + t];
+  if ((int)threadIdx.x < r1 - r0) s_ct[threadIdx.x] = Y.negc_over_t[r0 + threadIdx.x];
+  __builtin_amdgcn_wave_barrier();
   for (int r = r0; r < r1; r++) {
-    const double ct = Y.negc_over_t[r];
+    const double ct = s_ct[r - r0];
     double best = 0.0;
 #pragma unroll
     for (int u = 0; u < kLayerMaxLines; u++) {
       const double s = gf[u] * exp_neg(ct * elow[u], s_e2) * (1 - exp_neg(ct * wavn[u], s_e2));
-      const double k = s * Y.strength_f[r * niso + iso[u]];
+      const double k = s * s_f[(r - r0) * niso + iso[u]];
       if (nmx == 1) best = fmax(best, k);
       else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
         unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso[u]]];
@@ -693,16 +699,28 @@ void k_walk_combine(CombineArgs C)
     int wa, wz;
     if (C.P.binw) { const long long t = (long long)b * C.nsh + (j - C.lo); wa = C.P.binw[2 * t]; wz = C.P.binw[2 * t + 1]; }
     else ranges_of_bin(C.P, b, j, wa, wz);
-    for (int w = wa; w < wz; w += 4) {
-      double v[4];
+    // The record indices of all ranges touching the bin in ONE round trip (lane u: range w0 + u), then
+    // the records eight loads at a time -- added in range order all the same.  (One range after the
+    // other, each record waited for its range's off/blo: ~20 dependent round trips per bin at the
+    // demo size, where ~45 ranges touch a bin of the 8-bin frame.)
+    wa = __builtin_amdgcn_readfirstlane(wa); wz = __builtin_amdgcn_readfirstlane(wz);     // (one bin per wave)
+    for (int w0 = wa; w0 < wz; w0 += 64) {
+      const int n = min(64, wz - w0);
+      long long myrec = 0;
+      if (lane < n) myrec = C.P.off[w0 + lane] + (j - C.P.blo[w0 + lane]);
+      const int rec_lo = (int)(myrec & 0xffffffffLL), rec_hi = (int)(myrec >> 32);
+      for (int u0 = 0; u0 < n; u0 += 8) {
+        double v[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int ww = min(w + u, wz - 1);
-        const long long rec = C.P.off[ww] + (j - C.P.blo[ww]);
-        v[u] = (w + u < wz && lane < C.nc) ? C.part[rec * kWalkLayers + lane] : 0.0;     // (a step's idle lanes are never written)
+        for (int u = 0; u < 8; u++) {
+          const int uu = min(u0 + u, n - 1);                       // wave-uniform
+          const long long rec = ((long long)__builtin_amdgcn_readlane(rec_hi, uu) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane(rec_lo, uu);
+          v[u] = (u0 + u < n && lane < C.nc) ? C.part[rec * kWalkLayers + lane] : 0.0;     // (a step's idle lanes are never written)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (u0 + u < n) sum += v[u];
       }
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (w + u < wz) sum += v[u];
     }
   }
   if (cur_mx >= 0) store(cur_mx);
