@@ -585,8 +585,23 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
   for (int i = 0; i < nr; i++)
     if (a->temp[i] < tmin || a->temp[i] > tmax) return fail(h, TRX_E_RANGE, "layer temperature outside the CIA tables");
   int rc;
-  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 3 * nwmax * (size_t)nr))) return rc;
+  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 3 * nwmax * (size_t)nr * std::min<size_t>(kCiaBatch, h->cia.size())))) return rc;
   auto wn_at = [&](long long i) { return o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d); };
+  CiaBatch B{};
+  auto flush = [&]() {
+    if (B.n == 0) return;
+    int nwave = 0, fj0 = nr, lj1 = 0; long long fi0 = nsh, li1 = 0;
+    for (int t = 0; t < B.n; t++) {
+      nwave = std::max(nwave, B.J[t].C.nwave);
+      fj0 = std::min(fj0, B.J[t].fj); lj1 = std::max(lj1, B.J[t].lj);
+      fi0 = std::min(fi0, B.J[t].fi); li1 = std::max(li1, B.J[t].li);
+    }
+    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr, d_tlay);
+    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj1 - fj0 + 63) / 64), (unsigned)B.n), dim3(64), 0, cst, B, nr);
+    hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)(lj1 - fj0)), dim3(256), 0, cst,
+                       B, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi0, li1, fj0, h->d_ecs.as<double>());
+    B.n = 0;
+  };
   for (size_t n = 0; n < h->cia.size(); n++) {
     auto &c = h->cia[n];
     const long long nt1 = nsh; const int nt2 = nr;
@@ -603,15 +618,15 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     while (a->temp[fj] < fx2) fj++;
     for (int j = 0; j < lj; j++) if (a->temp[j] > lx2) lj = j;
     if (fi >= li || fj >= lj) continue;
-    CiaDev C{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>(),
-             c.d_zt.as<double>(), c.d_uw.as<double>(), c.d_ruw.as<double>(), c.d_rh.as<double>()};
-    double *mid = h->d_cia_ws.as<double>(), *z2 = mid + nwmax * nr, *v = z2 + nwmax * nr;
-    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)C.nwave * nr + 255) / 256)), dim3(256), 0, cst, C, nr, d_tlay, fj, lj, mid);
-    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj - fj + 63) / 64)), dim3(64), 0, cst, C, nr, fj, lj, mid, z2, v);
-    hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li - fi + 255) / 256), (unsigned)(lj - fj)), dim3(256), 0, cst,
-                       C, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi, li, fj, mid, z2,
-                       d_dens + n * nr, h->d_ecs.as<double>());
+    CiaJob &J = B.J[B.n];
+    J.C = CiaDev{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>(),
+                 c.d_zt.as<double>(), c.d_uw.as<double>(), c.d_ruw.as<double>(), c.d_rh.as<double>()};
+    J.fj = fj; J.lj = lj; J.fi = fi; J.li = li;
+    J.mid = h->d_cia_ws.as<double>() + 3 * nwmax * (size_t)nr * (size_t)B.n; J.z2 = J.mid + nwmax * nr; J.v = J.z2 + nwmax * nr;
+    J.dens = d_dens + n * nr;
+    if (++B.n == kCiaBatch) flush();
   }
+  flush();
   HIPCHK(h, hipGetLastError());
   return TRX_OK;
 }

@@ -858,10 +858,23 @@ struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs, *zt, *uw, *ruw, 
 
 // one lane per (table row, layer): the T spline evaluated at the layer temperature.
 // mid is [nwave][nr] so that the next kernel walks it with unit stride per lane.
+// The tables of a run are independent until their values are added: up to kCiaBatch of them go
+// through each kernel side by side (blockIdx.y = table), and k_cia_eval adds them in table order.
+constexpr int kCiaBatch = 4;
+struct CiaJob {
+  CiaDev C;
+  int fj, lj; long long fi, li;      // layers / wavenumbers inside the table (crosssec.c:376-393)
+  double *mid, *z2, *v;              // [nwave][nr] each
+  const double *dens;                // [nr] density product
+};
+struct CiaBatch { int n; CiaJob J[kCiaBatch]; };
+
 __global__ __launch_bounds__(256)
-void k_cia_rows(CiaDev C, int nr, const double *__restrict__ tlay, int fj, int lj,
-                double *__restrict__ mid)
+void k_cia_rows(CiaBatch B, int nr, const double *__restrict__ tlay)
 {
+  const CiaDev &C = B.J[blockIdx.y].C;
+  const int fj = B.J[blockIdx.y].fj, lj = B.J[blockIdx.y].lj;
+  double *__restrict__ mid = B.J[blockIdx.y].mid;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)C.nwave * nr) return;
   const int i = (int)(idx / nr), j = (int)(idx - (long long)i * nr);
@@ -881,9 +894,12 @@ void k_cia_rows(CiaDev C, int nr, const double *__restrict__ tlay, int fj, int l
 constexpr int kCiaChunk = 16;
 
 __global__ __launch_bounds__(64)
-void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ mid,
-                  double *__restrict__ z2, double *__restrict__ v)
+void k_cia_layers(CiaBatch B, int nr)
 {
+  const CiaDev &C = B.J[blockIdx.y].C;
+  const int fj = B.J[blockIdx.y].fj, lj = B.J[blockIdx.y].lj;
+  const double *__restrict__ mid = B.J[blockIdx.y].mid;
+  double *__restrict__ z2 = B.J[blockIdx.y].z2, *__restrict__ v = B.J[blockIdx.y].v;
   const int j = fj + blockIdx.x * 64 + threadIdx.x;
   if (j >= lj) return;
   latency_critical();
@@ -939,18 +955,25 @@ void k_cia_layers(CiaDev C, int nr, int fj, int lj, const double *__restrict__ m
   }
 }
 
-// one lane per (wavenumber, layer): evaluate, scale by the density product, add
+// one lane per (wavenumber, layer): evaluate every table of the batch, scale by its density
+// product, add in table order (grid: the union of the tables' wavenumber and layer ranges)
 __global__ __launch_bounds__(256)
-void k_cia_eval(CiaDev C, int nr, long long nsh, long long lo, double wn_i, double wn_d, double wn_fct,
-                long long fi, long long li, int fj, const double *__restrict__ mid,
-                const double *__restrict__ z2, const double *__restrict__ dens, double *__restrict__ ecs)
+void k_cia_eval(CiaBatch B, int nr, long long nsh, long long lo, double wn_i, double wn_d, double wn_fct,
+                long long fi0, long long li1, int fj0, double *__restrict__ ecs)
 {
-  const long long w = fi + (long long)blockIdx.x * 256 + threadIdx.x;
-  const int j = fj + blockIdx.y;
-  if (w >= li) return;
+  const long long w = fi0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  const int j = fj0 + blockIdx.y;
+  if (w >= li1) return;
   const double xo = wn_fct * (wn_i + (double)(lo + w) * wn_d);
-  const double val = spline_eval_pt(z2 + j, C.nwave, C.wn, mid + j, xo, nr, 1, nr);
-  if (val > 0) ecs[(long long)j * nsh + w] += val * dens[j];
+  double sum = ecs[(long long)j * nsh + w];
+  bool any = false;
+  for (int t = 0; t < B.n; t++) {
+    const CiaJob &J = B.J[t];
+    if (w < J.fi || w >= J.li || j < J.fj || j >= J.lj) continue;
+    const double val = spline_eval_pt(J.z2 + j, J.C.nwave, J.C.wn, J.mid + j, xo, nr, 1, nr);
+    if (val > 0) { sum += val * J.dens[j]; any = true; }
+  }
+  if (any) ecs[(long long)j * nsh + w] = sum;
 }
 
 // ---------------------------------------------------------------------------
