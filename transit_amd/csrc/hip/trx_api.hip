@@ -1684,8 +1684,11 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         else if (small)            hipLaunchKernelGGL((k_optical_depth_vertical<true, false>), grid, block, 0, S.st_tau, T);
         else if (extras)           hipLaunchKernelGGL((k_optical_depth_vertical<false, true>), grid, block, 0, S.st_tau, T);
         else                       hipLaunchKernelGGL((k_optical_depth_vertical<false, false>), grid, block, 0, S.st_tau, T);
-      } else
-        hipLaunchKernelGGL(k_optical_depth, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
+      } else if (o->scat_flag != 0 || o->cloud_flag != 0)
+        hipLaunchKernelGGL(k_optical_depth<true>, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
+                           dim3(256), 0, S.st_tau, T);
+      else
+        hipLaunchKernelGGL(k_optical_depth<false>, dim3((unsigned)std::min<int64_t>((nsh + kTauW - 1) / kTauW, kTauMaxBlocks)),
                            dim3(256), 0, S.st_tau, T);
       done += nt;
     }

@@ -1165,8 +1165,10 @@ void k_slant_geometry(SlantGeomArgs G)
 //   phase 3 (one lane per wavenumber): toomuch cut in height order (tau.c:277-287).
 constexpr int kTauH = 32;                 // heights per block (>= layers per chunk)
 constexpr int kTauW = 256 / kTauH;        // wavenumbers per block
+constexpr int kTauStageRows = 256;        // rows of a tile kept in LDS (deeper atmospheres read global memory)
 
-__global__ __launch_bounds__(256)
+template <bool EXTRAS>                    // EXTRAS: a scattering or cloud model is switched on (their out-of-line
+__global__ __launch_bounds__(256)         // bodies take TauArgs by reference: a copy in scratch memory per lane)
 void k_optical_depth(TauArgs T)
 {
   if (!T.eager && T.flags[0] == 0) return;
@@ -1174,6 +1176,10 @@ void k_optical_depth(TauArgs T)
   __shared__ double s_y0[kTauH][kTauW];
   __shared__ double s_tv[kTauH][kTauW];
   __shared__ int s_alive[kTauW];
+  // the tile's total extinction from the step's lowest layer up, fetched once per block: every
+  // height of the tile integrates over (nearly) the same rows
+  __shared__ double s_y[kTauStageRows][kTauW];
+  const bool staged = T.nr - (T.r_top - T.nc + 1) <= kTauStageRows;
   const int wi = threadIdx.x % kTauW, hc = threadIdx.x / kTauW;
   const int nr = T.nr;
   const int r_low = T.r_top - T.nc + 1;                  // lowest layer whose extinction exists so far
@@ -1191,9 +1197,19 @@ void k_optical_depth(TauArgs T)
   if (alive && hc < T.nc) {
     const int r = T.r_top - hc;
     const long long k = (long long)r * T.nsh + w;
-    T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
+    if (EXTRAS) T.er[k] = T.e[k] + scat_term(T, r, wcgs) + cloud_term(T, r, wcgs) + T.ecs[k];
+    else        T.er[k] = T.e[k] + T.ecs[k];
   }
   __syncthreads();                                       // (the block's own global writes: visible to it after the barrier)
+  if (staged) {
+    const int rows = nr - r_low;
+    for (int t = threadIdx.x; t < rows * kTauW; t += 256) {
+      const int row = t / kTauW, col = t % kTauW;
+      const long long ww = tile * kTauW + col;
+      s_y[row][col] = ww < T.nsh ? T.er[(long long)(r_low + row) * T.nsh + ww] : 0.0;
+    }
+    __syncthreads();
+  }
   // phase 1b: extinction at the closest-approach radius of this lane's height (slantpath.c:55-58).
   // The bracket's lowest layer rs is the height's own layer, or -- when the impact parameter came
   // out an ulp below the layer radius (TauArgs.hrs) -- the layer under it.  That one may lie
@@ -1208,8 +1224,10 @@ void k_optical_depth(TauArgs T)
       const int n = nr - rs;
       const double r0 = T.hr0[k];
       const double *y = T.er + (long long)rs * T.nsh + w;
-      const double ylow = rs >= r_low ? y[0]
-                                      : scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[(long long)rs * T.nsh + w];
+      double ylow;
+      if (rs >= r_low) ylow = y[0];
+      else if (EXTRAS) ylow = scat_term(T, rs, wcgs) + cloud_term(T, rs, wcgs) + T.ecs[(long long)rs * T.nsh + w];
+      else             ylow = T.ecs[(long long)rs * T.nsh + w];
       if (n == 2) y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], ylow, y[T.nsh], r0);
       else        y0 = parab3(T.rad[rs], T.rad[rs+1], ylow, y[T.nsh], y[2*T.nsh], r0);
     }
@@ -1240,11 +1258,32 @@ void k_optical_depth(TauArgs T)
         const int even = (n % 2 == 0);
         double acc = 0.0;
         const int npair = (n - 1) / 2;
-        for (int i = 0; i < npair; i++) {
-          const int j = 2*i + even;
-          const double ya = (j == 0) ? y0 : y[(long long)j * T.nsh];
-          const double yb = y[(long long)(j+1) * T.nsh], yc = y[(long long)(j+2) * T.nsh];
-          acc += (ya * g[4*i] + yb * g[4*i+1] + yc * g[4*i+2]) * g[4*i+3];
+        // four interval pairs per trip: their nine points and sixteen weights are requested together
+        // (pair by pair, every trip waited for its own loads -- ~30 round trips for a deep ray), the
+        // sum keeps the pairs' order
+        double gn[16];                                     // the NEXT trip's weights, requested a trip ahead
+#pragma unroll
+        for (int q = 0; q < 16; q++) gn[q] = g[4 * min(q / 4, npair - 1) + (q & 3)];
+        for (int i0 = 0; i0 < npair; i0 += 4) {
+          const int jb = 2 * i0 + even;
+          double yv[9], gg[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) gg[q] = gn[q];
+          if (i0 + 4 < npair) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) gn[q] = g[4 * min(i0 + 4 + q / 4, npair - 1) + (q & 3)];
+          }
+          if (staged) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) yv[q] = s_y[max(rs + min(jb + q, n - 1) - r_low, 0)][wi];     // (row rs itself: only as yv[0], replaced below)
+          } else {
+#pragma unroll
+            for (int q = 0; q < 9; q++) yv[q] = y[(long long)min(jb + q, n - 1) * T.nsh];
+          }
+          if (jb == 0) yv[0] = y0;
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (i0 + u < npair) acc += (yv[2*u] * gg[4*u] + yv[2*u+1] * gg[4*u+1] + yv[2*u+2] * gg[4*u+2]) * gg[4*u+3];
         }
         res = acc / 6.0;
         if (even) res += T.gh0[k] * (y0 + y[T.nsh]) / 2;
