@@ -105,6 +105,7 @@ struct trx_handle {
   DevBuf d_pm_f64, d_pm_i32;         // the same scalars of a per-molecule sweep (trx_sweep_permol)
   // what the host reads back after a run, in ONE device block and one pinned host block:
   // flags (8 ints, byte 0), status (4 ints, byte 64), counters (3 per layer, byte 128)
+  DevBuf d_xf;                        // scattering / cloud wavenumber factors [2][nsh] + 3 constants
   DevBuf d_small; DevView d_flags, d_status, d_counters; void *h_small = nullptr; size_t h_small_bytes = 0;
   DevBuf d_e, d_ecs, d_er, d_tau, d_last, d_intens, d_spec, d_acc, d_geom;
   // opacity grid (optional)
@@ -1612,8 +1613,28 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right
   // after that step's kernels, which are what the GPU is waiting for.
+  // scattering / cloud models: the parameters of tau.c:193-214, extinction.c:587-693, and the per-ray
+  // wavenumber factors the optical-depth kernels multiply the layer parts with (k_extras_factors)
+  const bool extras_on = o->scat_flag != 0 || o->cloud_flag != 0;
+  if (extras_on && (rc = ensure(h, h->d_xf, sizeof(double) * (2 * (size_t)nsh + 8)))) return rc;
+  auto model_args = [&](TauArgs &T) {
+    T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
+    T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
+    T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
+    T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
+    T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
+    T.mdens = d_mdens; T.nH = d_nH;
+    if (extras_on) { T.xf_scat = h->d_xf.as<double>(); T.xf_cloud = T.xf_scat + nsh; T.xf_const = T.xf_cloud + nsh; }
+  };
   auto queue_cia = [&]() -> int {
     const auto t0 = std::chrono::steady_clock::now();
+    if (extras_on) {        // (ahead of the first optical depth like everything on this queue)
+      TauArgs X{};
+      X.nr = nr; X.nsh = nsh; X.lo = h->lo; X.wn_i = h->wn_i; X.wn_d = h->wn_d; X.wn_fct = o->wn_fct;
+      model_args(X);
+      hipLaunchKernelGGL(k_extras_factors, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, h->stream2, X,
+                         h->d_xf.as<double>(), h->d_xf.as<double>() + nsh, h->d_xf.as<double>() + 2 * nsh);
+    }
     if (!vertical) {        // the slant rays' geometry, ahead of the CIA kernels: both are waited for by the first optical depth
       SlantGeomArgs G{};
       G.rad = d_rad; G.nr = nr; G.fct = a->rad_fct; G.gstride = gstride;
@@ -1668,12 +1689,8 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       T.r_top = S.r_top - done; T.nc = nt; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
       T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
       T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
-      T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
-      T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
-      T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
-      T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
-      T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
-      T.mdens = d_mdens; T.nH = d_nH; T.flags = h->d_flags.as<int>(); T.eager = eager;
+      model_args(T);
+      T.flags = h->d_flags.as<int>(); T.eager = eager;
       T.pw = d_pw; T.acc = h->d_acc.as<double>();
       T.hrs = d_pw + 4 * (size_t)nr; T.hr0 = T.hrs + nr; T.status = h->d_status.as<int>();
       if (o->solution == TRX_SOL_ECLIPSE) {
@@ -1893,12 +1910,7 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if ((rc = ensure(h, d_x, sizeof(double) * 2 * (size_t)nr * nsh))) return rc;
       TauArgs T{};
       T.nr = nr; T.nsh = nsh; T.lo = h->lo; T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct;
-      T.scat_flag = o->scat_flag; T.cloud_flag = o->cloud_flag; T.nmol = nmol;
-      T.scat_pref = std::pow(10.0, o->scat_logext) * kE0H2;
-      T.press = d_press; T.temp = d_tempk; T.scat_pol = d_scatpol;
-      T.cloud_top = o->cloud_top; T.cloud_bot = o->cloud_bot; T.cloud_ext = o->cloud_ext; T.cloud_gamma = o->cloud_gamma;
-      T.cloud_Q = o->cloud_Q; T.cloud_r = o->cloud_r; T.cloud_sig = o->cloud_sig; T.cloud_refwn = o->cloud_refwn;
-      T.mdens = d_mdens; T.nH = d_nH;
+      model_args(T);
       double *xs = d_x.as<double>(), *xc = xs + (size_t)nr * nsh;
       hipLaunchKernelGGL(k_extras_dump, dim3((unsigned)((nsh + 255) / 256), (unsigned)nr), dim3(256), 0, st, T, xs, xc);
       HIPCHK(h, hipStreamSynchronize(st));
