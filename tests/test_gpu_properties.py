@@ -374,6 +374,29 @@ def test_two_handles_on_two_threads():
             assert np.array_equal(o, refs[k])
 
 
+def test_wide_frames_without_the_row_copy_give_the_same_bits(tmp_path, monkeypatch):
+    """Frames of 4+ bins read a row copy of the Voigt table (k_line_walk, `tabW`); when that copy
+    would pass 4 GB a handle has none and those frames run their per-bin form.  Same spectrum, bit
+    for bit, and the same extinction in every layer (the deep layers are the wide frames)."""
+    d = str(tmp_path / "case")
+    synth.make_case(d, nlines=30000, wnlow=2500, wnhigh=2600, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=77)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    outs = []
+    for no_copy in (False, True):
+        if no_copy:
+            monkeypatch.setenv("TRX_NO_ROW_COPY", "1")
+        eng = Engine(P.static)
+        P.opts.eager = 1                                    # every layer, also below where the rays stop
+        outs.append(eng.run(P.atm, P.opts, debug=("e",)))
+        P.opts.eager = 0
+        assert eng.stats()["walk_steps"] > 0
+        eng.close()
+    assert np.array_equal(outs[0]["spectrum"], outs[1]["spectrum"])
+    assert np.array_equal(outs[0]["e"], outs[1]["e"])
+    assert np.count_nonzero(outs[0]["e"][0]) > 0           # the bottom layer (widest profiles) was swept by something
+
+
 @pytest.mark.parametrize("grid", [dict(ndop=256, nlor=7), dict(ndop=2, nlor=2), dict(ndop=17, nlor=120, dmin=5e-4, dmax=0.5, lmin=1e-3, lmax=2.0)])
 def test_other_voigt_grids_against_oracle(tmp_path, grid):
     """--ndop/--nlor/--dmin/... (argum.c:220-237): the largest Doppler grid the kernels stage in

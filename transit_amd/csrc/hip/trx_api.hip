@@ -341,12 +341,12 @@ int build_table(trx_handle *h, const trx_static *s)
   // The walk's copy (trx_walk.hip.h): phase-major rows, each followed by kWalkPad zeros -- the
   // bins of a frame are CONSECUTIVE entries of one row, and what a narrow profile does not reach
   // is zero by position (the pad behind a row is also the pad in front of the next).  One
-  // descriptor per table entry.  32-bit byte offsets: the walk is off when the copy passes 4 GB.
+  // descriptor per table entry.  32-bit byte offsets: no copy when it would pass 4 GB (walk_chunk).
   {
     std::vector<long long> joffW(jobs.size());
     long long totW = 0;
     for (size_t j = 0; j < jobs.size(); j++) { joffW[j] = totW; totW += (long long)s->osamp * ((jobs[j].nv - 1) / s->osamp + 1 + kWalkPad); }
-    h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32);
+    h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !std::getenv("TRX_NO_ROW_COPY");      // (the variable: tests of the fallback)
     if (h->tabw_ok) {
       std::vector<WalkProfile> desc((size_t)s->ndop * s->nlor);
       size_t j = 0;
@@ -481,7 +481,7 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
   // ranges of ngw consecutive groups per isotope block
   // (32-bit byte offsets into the widened table: 8*tab_n + 64*osamp must stay below 2^32)
-  h->walk_ok = h->tabw_ok && s->osamp < (1 << 21) && h->tab_n < ((int64_t)1 << 28) && !gfirst.empty();
+  h->walk_ok = s->osamp < (1 << 21) && h->tab_n < ((int64_t)1 << 28) && !gfirst.empty();
   if (h->walk_ok) {
     // Groups per range: ~2 rounds of resident waves (the hardware balances the rounds).  Taken from
     // the WHOLE list, not from what reaches this shard: the range size is part of the order of the
@@ -939,10 +939,13 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     if (ns == 0) { A.nseg = 1; A.seg_w0[0] = 0; A.seg_cum[0] = 0; A.seg_cum[1] = 0; }     // nothing reaches: no wave does anything
   }
   if (nw > 0) {
-    if (nb == 2) launch_walk<2>(A, M.prof, nw, st);
-    else if (nb == 4) launch_walk<4>(A, M.prof, nw, st);
-    else if (nb == 8) launch_walk<8>(A, M.prof, nw, st);
-    else launch_walk<16>(A, M.prof, nw, st);
+    // (no row copy -- it would have passed 4 GB: the wide frames run their per-bin form, which is
+    // the counting instantiation with the counters switched off)
+    const bool per_bin = M.prof || (nb >= kWalkRowsFrom && A.tabw == nullptr);
+    if (nb == 2) launch_walk<2>(A, per_bin, nw, st);
+    else if (nb == 4) launch_walk<4>(A, per_bin, nw, st);
+    else if (nb == 8) launch_walk<8>(A, per_bin, nw, st);
+    else launch_walk<16>(A, per_bin, nw, st);
   }
   if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");
   PendingCombine pc;

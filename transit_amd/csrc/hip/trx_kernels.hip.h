@@ -1245,7 +1245,6 @@ void k_optical_depth(TauArgs T)
   // chunk (tau.c:231-232) -- it used to be one lane per wavenumber going down the chunk
   const bool alive = ok && T.last[w] < 0;
   if (hc == 0) s_alive[wi] = alive;
-  const double wcgs = (T.wn_i + (double)(T.lo + (ok ? w : 0)) * T.wn_d) * T.wn_fct;
   if (alive && hc < T.nc) {
     const int r = T.r_top - hc;
     const long long k = (long long)r * T.nsh + w;
@@ -1421,7 +1420,6 @@ void k_optical_depth_vertical(TauArgs T)
   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
   if (T.last[w] < 0) {
     bool still = true;
-    const double wcgs = (T.wn_i + (double)(T.lo + w) * T.wn_d) * T.wn_fct;
     double a1 = T.acc[w], a2 = T.acc[T.nsh + w];          // A(rs+1), A(rs+2) on entry of a step
     // y1, y2: (edited) extinction of the two layers above the current bottom
     double y1 = 0, y2 = 0;
