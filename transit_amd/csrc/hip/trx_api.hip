@@ -860,6 +860,10 @@ void launch_walk(const WalkArgs &A, bool prof, unsigned nwaves, hipStream_t st)
 {
   const dim3 grid((nwaves + kWalkWaves - 1) / kWalkWaves), block(64 * kWalkWaves);
   if (prof) hipLaunchKernelGGL((k_line_walk<NB, true>), grid, block, 0, st, A);
+  else if constexpr (NB >= 8) {      // steps of at most 32 layers: two lanes per layer (trx_walk.hip.h)
+    if (A.nc <= 32) hipLaunchKernelGGL((k_line_walk<NB, false, 2>), grid, block, 0, st, A);
+    else            hipLaunchKernelGGL((k_line_walk<NB, false>), grid, block, 0, st, A);
+  }
   else      hipLaunchKernelGGL((k_line_walk<NB, false>), grid, block, 0, st, A);
 }
 

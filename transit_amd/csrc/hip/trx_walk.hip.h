@@ -411,12 +411,19 @@ __device__ __forceinline__ double exp_small(double x)
 
 constexpr int kWalkWaves = 4;        // independent waves per workgroup (a CU holds few workgroups)
 
-template <int NB, bool PROF>
+// LPL = 2 (steps of at most 32 layers, row form): TWO lanes per layer, each with half of the frame --
+// lane = 32*half + layer.  The frame's row segment is then fetched by ONE load instruction per
+// group instead of two (the wide frames are bound by their table loads: a further 16-byte load per
+// lane and group costs 35 us of 153 even when it hits the same cache line); the strength
+// arithmetic is done twice, on lanes that would be idle.
+template <int NB, bool PROF, int LPL = 1>
 __global__ __launch_bounds__(64 * kWalkWaves)
 void k_line_walk(WalkArgs A)
 {
   constexpr int Rc = NB / 2 - 1;
+  constexpr int NS = NB / LPL;                             // slots (bins of the frame) per lane
   constexpr bool ROWS = !PROF && NB >= kWalkRowsFrom;     // (counting runs keep the per-bin form: they count per bin)
+  static_assert(LPL == 1 || (LPL == 2 && ROWS && NS >= 4), "lane pairs: row form, frames of 8+ bins");
   if (!A.eager && A.flags[0] == 0) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int w = blockIdx.x * kWalkWaves + wv;                  // wave-uniform
@@ -447,9 +454,10 @@ void k_line_walk(WalkArgs A)
   const int l0 = A.gfirst[g0], l1 = A.gfirst[g1 - 1] + A.gcount[g1 - 1];
   const long long rec0 = A.P.off[w];
 
-  // ---- this lane's layer
-  const bool valid = lane < A.nc;
-  const int r = A.r_top - (valid ? lane : 0), ri = r * A.niso + b;
+  // ---- this lane's layer (and, with lane pairs, its part of the frame: slots part*NS ...)
+  const int li = LPL == 1 ? lane : (lane & 31), part = LPL == 1 ? 0 : (lane >> 5);
+  const bool valid = li < A.nc;
+  const int r = A.r_top - (valid ? li : 0), ri = r * A.niso + b;
   const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
   const double ct = valid ? A.Y.negc_over_t[r] : 0.0;      // idle lanes: strength 0
   const double f = A.Y.strength_f[ri], dens = A.permol ? 1.0 : A.Y.density[ri];
@@ -476,22 +484,22 @@ void k_line_walk(WalkArgs A)
   WalkProfile wp_cur{}, wp_st{};
   if (ROWS) { wp_cur = A.walkprof[lo_i * A.nlor + il]; wp_st = A.walkprof[idst * A.nlor + il]; }
 
-  double acc[NB];
+  double acc[NS];
 #pragma unroll
-  for (int k = 0; k < NB; k++) acc[k] = 0.0;
+  for (int k = 0; k < NS; k++) acc[k] = 0.0;
   int jc = __builtin_amdgcn_readfirstlane(A.lines[l0].cell);   // frame: acc[k] <-> bin jc - Rc + k
   unsigned long long nb = 0, nev = 0, nsk = 0;
 
-  auto flush = [&](int k, double v) {                      // bin of slot k leaves the frame
-    const int j = jc - Rc + k;
-    if (valid && j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = v;     // (idle lanes: nobody reads their entries)
+  auto flush = [&](int k, double v, bool mine = true) {    // bin of this lane's slot k leaves the frame
+    const int j = jc - Rc + part * NS + k;
+    if (valid && mine && j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + li] = v;     // (idle lanes: nobody reads their entries)
   };
 
   // bins of the interval that no frame position covers (a jump over empty or skipped cells, the
   // tail below the last evaluated group) still get their record: zeros
   auto fill_zero = [&](int ja, int jb) {                   // bins ja..jb inclusive
     ja = max(ja, blo); jb = min(jb, bhi);
-    if (valid) for (int j = ja; j <= jb; j++) A.part[(rec0 + (j - blo)) * kWalkLayers + lane] = 0.0;
+    if (valid && part == 0) for (int j = ja; j <= jb; j++) A.part[(rec0 + (j - blo)) * kWalkLayers + li] = 0.0;
   };
 
   double pk = 0.0;                   // strength of the group so far (0 between groups)
@@ -503,12 +511,12 @@ void k_line_walk(WalkArgs A)
   // (every slot takes part, a slot the line does not reach with a table value of 0: adding
   // kk * 0 leaves the sum as it is, and eight unconditional multiply-adds are fewer instructions
   // than eight scalar tests around six of them)
-  float pv_p[NB]; double kk_p = 0.0; bool pend = false;    // pend: wave-uniform
+  float pv_p[NS]; double kk_p = 0.0; bool pend = false;    // pend: wave-uniform
 #pragma unroll
-  for (int k = 0; k < NB; k++) pv_p[k] = 0.f;
+  for (int k = 0; k < NS; k++) pv_p[k] = 0.f;
   auto settle = [&]() {
 #pragma unroll
-    for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);     // :507
+    for (int k = 0; k < NS; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);     // :507
     pend = false;
   };
   // Slot k reads the table at (profile centre) + d, d = (k - Rc)*osamp - imod.  The part of d that
@@ -589,15 +597,17 @@ void k_line_walk(WalkArgs A)
           int sh = jc - cell;
           if (sh >= NB) {
 #pragma unroll
-            for (int k = 0; k < NB; k++) { flush(k, acc[k]); acc[k] = 0.0; }
+            for (int k = 0; k < NS; k++) { flush(k, acc[k]); acc[k] = 0.0; }
             fill_zero(cell + Rc + 2, jc - Rc - 1);
             jc = cell;
           } else {
             for (; sh > 0; sh--) {
-              flush(NB - 1, acc[NB - 1]);
+              flush(NS - 1, acc[NS - 1], part == LPL - 1);            // the frame's last bin
+              double carry = 0.0;                                      // the lower part's last bin moves up a lane
+              if (LPL == 2) carry = __shfl_xor(acc[NS - 1], 32, 64);
 #pragma unroll
-              for (int k = NB - 1; k > 0; k--) acc[k] = acc[k - 1];
-              acc[0] = 0.0;
+              for (int k = NS - 1; k > 0; k--) acc[k] = acc[k - 1];
+              acc[0] = (LPL == 2 && part == 1) ? carry : 0.0;
               jc--;
             }
           }
@@ -605,7 +615,7 @@ void k_line_walk(WalkArgs A)
         // ---- bins: slot k is bin jc - Rc + k at fine distance d = (k - Rc)*osamp - imod from the line
         // (a bin outside the shard may be accumulated too: it never leaves the frame, see flush)
         pend = true;
-        if (ROWS) {
+        if constexpr (ROWS) {
           // one row of the lane's profile holds all the frame's bins: row ph = (ps - imod) mod osamp,
           // entry kk = (ps - imod) div osamp for the centre slot -- from the profile's ps = psq*osamp + psr
           // without a division: psr >= imod ? (psr - imod, psq) : (psr - imod + osamp, psq - 1).
@@ -615,10 +625,10 @@ void k_line_walk(WalkArgs A)
           const int rb = own ? wp_cur.rowb : wp_st.rowb;
           const int d = (own ? wp_cur.psr : wp_st.psr) - imod, sgn = d >> 31;          // sgn = -1: borrowed a cell
           const unsigned at = c4 + (unsigned)((d + (sgn & A.osamp)) * rb) + (unsigned)((sgn + 1) << 2);
-          struct alignas(4) Row { float v[NB]; } row;
-          __builtin_memcpy(&row, tabw_base + at, sizeof row);       // 4-byte aligned wide loads
+          struct alignas(4) Row { float v[NS]; } row;
+          __builtin_memcpy(&row, tabw_base + at + 4u * (unsigned)(NS * part), sizeof row);       // 4-byte aligned wide loads
 #pragma unroll
-          for (int k = 0; k < NB; k++) pv_p[k] = row.v[k];
+          for (int k = 0; k < NS; k++) pv_p[k] = row.v[k];
         } else {
           kk_p = kk;
           const int ps_act = act ? ps : -1;                       // a lane that sits out reaches no slot
@@ -638,7 +648,7 @@ void k_line_walk(WalkArgs A)
   }
   if (pend) settle();
 #pragma unroll
-  for (int k = 0; k < NB; k++) flush(k, acc[k]);
+  for (int k = 0; k < NS; k++) flush(k, acc[k]);
   fill_zero(blo, jc - Rc - 1);
   if (PROF && valid && A.counters) {
     if (nb)  atomicAdd(&A.counters[(long long)r * 3 + 0], nb);
