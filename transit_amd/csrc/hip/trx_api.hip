@@ -816,13 +816,11 @@ int walk_frame_bins(const trx_handle *h, const int32_t *psmax, int r)
 {
   if (!h->walk_ok || !h->walk_temp_ok) return 0;
   const long long rc = layer_psmax(h, psmax, r) / h->osamp;
-  // The 16-bin frame (profiles reaching 4-7 cells) pays only where lines are sparse: its cost goes
-  // with the number of LINES, the two-kernel form's with bins and tiles.  At hundreds of lines
-  // per bin (configs[1], [2]) it is dearer per wide layer than the two-kernel form at any layer
-  // count (1.4 ms against ~0.4 ms for the 9 such layers of configs[2]); at one line per bin
-  // (configs[4]) it is the cheaper one (0.220 s against 0.245 s).  A property of the handle.
-  const bool frame16 = h->ngroups < 16 * h->nwn;
-  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : (rc <= 7 && frame16) ? 16 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
+  // (The 16-bin frame -- profiles reaching 4-7 cells -- used to pay only on sparse lists: with a load
+  // per bin it cost 1.4 ms for the 9 such layers of configs[2] against ~0.4 ms in the two-kernel
+  // form.  Reading rows of the table copy, two lanes per layer, it is the cheaper one there too:
+  // 2.32 -> 2.26 ms.)
+  return rc <= 0 ? 2 : rc <= 1 ? 4 : rc <= 3 ? 8 : rc <= 7 ? 16 : 0;     // (tab_n >= Rc*osamp follows: a profile that wide is in the table)
 }
 
 // plan of the line ranges for a frame of nb bins (built once per handle and frame size)
