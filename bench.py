@@ -486,9 +486,11 @@ def main():
                          "note": "achieved = bytes the dominant kernel's data flow must move (32 B per line record, 4 B "
                                  "per accumulated bin, its partial records) / its measured time (HIP events on its own "
                                  "stream).  bmin_frac / balg_frac = the whole spectrum against SURVEY 8(d)'s layer-fused "
-                                 "minimum / reference-flow byte counts.  The walk is not bandwidth bound: it is bound "
-                                 "by instruction issue (vector + scalar, ~75-200 per line and step; counters in "
-                                 "profiles/), see DESIGN.md section 4"},
+                                 "minimum / reference-flow byte counts.  The walk is not HBM-bandwidth bound: its "
+                                 "two-bin frame keeps ~65 % of the vector issue slots and half of the scalar unit busy "
+                                 "(~75 instructions per line and step), its wider frames wait for their per-lane "
+                                 "table gathers (L1 misses served by L2); counters and probes in profiles/, "
+                                 "DESIGN.md section 4"},
         }
         out["config"].update(extras)
         if dom == "k_accumulate" and ach > HBM_PEAK_GBS:
