@@ -54,7 +54,7 @@ struct trx_handle {
   // step c; ev_ac[c] = extinction of step c complete
   hipStream_t stream4 = nullptr;
   std::vector<hipEvent_t> ev_ac, ev_cb;      // ev_cb[c] = partial records of step c consumed
-  hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr;
+  hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr, ev_run_a = nullptr, ev_run_b = nullptr;
   std::string err;
 
   // grids
@@ -1327,6 +1327,8 @@ void trx_destroy(trx_handle *h)
   for (auto e : h->ev_cb) (void)hipEventDestroy(e);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_inputs) (void)hipEventDestroy(h->ev_inputs);
+  if (h->ev_run_a) (void)hipEventDestroy(h->ev_run_a);
+  if (h->ev_run_b) (void)hipEventDestroy(h->ev_run_b);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_cia) (void)hipEventDestroy(h->ev_cia);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1365,10 +1367,6 @@ int trx_width_grids(const trx_handle *h, double *adop, double *alor)
 }
 
 namespace {
-struct EventPair {        // released on every return path
-  hipEvent_t a = nullptr, b = nullptr;
-  ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-};
 }  // namespace
 
 static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum,
@@ -1656,8 +1654,13 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- events -----------------------------------------------------------------
   Spans spans;
-  EventPair ev;
-  HIPCHK(h, hipEventCreate(&ev.a)); HIPCHK(h, hipEventCreate(&ev.b));
+  // (the run's two timing events live with the handle: creating and destroying a pair per run was
+  // ~10 us of host time, which a small shard waits for)
+  struct { hipEvent_t a, b; } ev{h->ev_run_a, h->ev_run_b};
+  if (!ev.a) {
+    HIPCHK(h, hipEventCreate(&h->ev_run_a)); HIPCHK(h, hipEventCreate(&h->ev_run_b));
+    ev.a = h->ev_run_a; ev.b = h->ev_run_b;
+  }
   HIPCHK(h, hipEventRecord(ev.a, st));
 
   h->stats.walk_steps = 0; h->stats.walk_records = 0; h->stats.walk_record_lanes = 0;
