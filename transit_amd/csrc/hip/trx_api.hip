@@ -578,8 +578,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
                const double *d_dens /* [ncia][nr] on device */, hipStream_t cst)
 {
   const int nr = a->nlayer; const long long nsh = h->nsh;
-  HIPCHK(h, hipMemsetAsync(h->d_ecs.p, 0, sizeof(double) * (size_t)nr * nsh, cst));
-  if (h->cia.empty()) return TRX_OK;
+  if (h->cia.empty()) { HIPCHK(h, hipMemsetAsync(h->d_ecs.p, 0, sizeof(double) * (size_t)nr * nsh, cst)); return TRX_OK; }
   double tmin = 0.0, tmax = 70000.0;                        // crosssec.c:44-45, 175-176
   size_t nwmax = 0;
   for (auto &c : h->cia) { tmin = std::fmax(tmin, c.temp.front()); tmax = std::fmin(tmax, c.temp.back()); nwmax = std::max(nwmax, c.wn.size()); }
@@ -589,19 +588,24 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
   if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 3 * nwmax * (size_t)nr * std::min<size_t>(kCiaBatch, h->cia.size())))) return rc;
   auto wn_at = [&](long long i) { return o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d); };
   CiaBatch B{};
-  auto flush = [&]() {
-    if (B.n == 0) return;
-    int nwave = 0, fj0 = nr, lj1 = 0; long long fi0 = nsh, li1 = 0;
+  bool first = true;             // the first batch writes the whole array (k_cia_eval), also when it is empty
+  auto flush = [&](bool last) {
+    if (B.n == 0 && !(first && last)) return;
+    int nwave = 0, fj0 = nr, lj1 = 0, fjl = nr, ljl = 0; long long fi0 = nsh, li1 = 0;
     for (int t = 0; t < B.n; t++) {
       nwave = std::max(nwave, B.J[t].C.nwave);
       fj0 = std::min(fj0, B.J[t].fj); lj1 = std::max(lj1, B.J[t].lj);
       fi0 = std::min(fi0, B.J[t].fi); li1 = std::max(li1, B.J[t].li);
     }
-    hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr, d_tlay);
-    hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((lj1 - fj0 + 63) / 64), (unsigned)B.n), dim3(64), 0, cst, B, nr);
+    fjl = fj0; ljl = lj1;
+    if (first) { fj0 = 0; lj1 = nr; fi0 = 0; li1 = nsh; }
+    if (B.n > 0) {
+      hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr, d_tlay);
+      hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((ljl - fjl + 63) / 64), (unsigned)B.n), dim3(64), 0, cst, B, nr);
+    }
     hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)(lj1 - fj0)), dim3(256), 0, cst,
-                       B, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi0, li1, fj0, h->d_ecs.as<double>());
-    B.n = 0;
+                       B, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi0, li1, fj0, first ? 1 : 0, h->d_ecs.as<double>());
+    B.n = 0; first = false;
   };
   for (size_t n = 0; n < h->cia.size(); n++) {
     auto &c = h->cia[n];
@@ -625,9 +629,9 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     J.fj = fj; J.lj = lj; J.fi = fi; J.li = li;
     J.mid = h->d_cia_ws.as<double>() + 3 * nwmax * (size_t)nr * (size_t)B.n; J.z2 = J.mid + nwmax * nr; J.v = J.z2 + nwmax * nr;
     J.dens = d_dens + n * nr;
-    if (++B.n == kCiaBatch) flush();
+    if (++B.n == kCiaBatch) flush(false);
   }
-  flush();
+  flush(true);
   HIPCHK(h, hipGetLastError());
   return TRX_OK;
 }

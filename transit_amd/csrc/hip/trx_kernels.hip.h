@@ -956,16 +956,19 @@ void k_cia_layers(CiaBatch B, int nr)
 }
 
 // one lane per (wavenumber, layer): evaluate every table of the batch, scale by its density
-// product, add in table order (grid: the union of the tables' wavenumber and layer ranges)
+// product, add in table order.  The FIRST batch of a run covers the whole [layer][wavenumber]
+// array and starts every sum from zero (a memset of the array ahead of the kernels was a dispatch
+// of its own on this queue, 12-35 us next to a walk); a later batch covers the union of its
+// tables' ranges and adds to what is there.
 __global__ __launch_bounds__(256)
 void k_cia_eval(CiaBatch B, int nr, long long nsh, long long lo, double wn_i, double wn_d, double wn_fct,
-                long long fi0, long long li1, int fj0, double *__restrict__ ecs)
+                long long fi0, long long li1, int fj0, int first, double *__restrict__ ecs)
 {
   const long long w = fi0 + (long long)blockIdx.x * 256 + threadIdx.x;
   const int j = fj0 + blockIdx.y;
   if (w >= li1) return;
   const double xo = wn_fct * (wn_i + (double)(lo + w) * wn_d);
-  double sum = ecs[(long long)j * nsh + w];
+  double sum = first ? 0.0 : ecs[(long long)j * nsh + w];
   bool any = false;
   for (int t = 0; t < B.n; t++) {
     const CiaJob &J = B.J[t];
@@ -973,7 +976,7 @@ void k_cia_eval(CiaBatch B, int nr, long long nsh, long long lo, double wn_i, do
     const double val = spline_eval_pt(J.z2 + j, J.C.nwave, J.C.wn, J.mid + j, xo, nr, 1, nr);
     if (val > 0) { sum += val * J.dens[j]; any = true; }
   }
-  if (any) ecs[(long long)j * nsh + w] = sum;
+  if (any || first) ecs[(long long)j * nsh + w] = sum;
 }
 
 // ---------------------------------------------------------------------------
