@@ -374,6 +374,44 @@ def test_two_handles_on_two_threads():
             assert np.array_equal(o, refs[k])
 
 
+def test_every_walk_frame_and_lane_form_against_oracle(tmp_path):
+    """A demo-shaped atmosphere down to 100 bar meets every form of the line sweep: frames of 2, 4,
+    8 and 16 bins and the two-kernel form below them.  Swept eagerly, once in steps as large as
+    the plan allows (one lane per layer where a wide frame has more than 32 layers) and once in
+    steps of 16 layers (two lanes per layer in the frames of 8+ bins): the extinction of every
+    layer against the oracle's, and the two runs against each other bit for bit -- the order of a
+    bin's sum does not depend on the steps."""
+    from transit_amd import engine
+    d = str(tmp_path / "case")
+    synth.make_case(d, nlines=20000, wnlow=2500, wnhigh=2560, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=91)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    ora = ol.OracleEngine(P.static)
+    P.opts.eager = 1
+    ref = ora.run(P.atm, P.opts, debug=("e",))
+    ora.close()
+    seen, runs = [], []
+    engine.set_log(lambda lvl, msg: seen.append(msg), 5)
+    try:
+        eng = Engine(P.static)
+        for chunk in (0, 16):
+            P.opts.layer_chunk = chunk
+            runs.append(eng.run(P.atm, P.opts, debug=("e",)))
+        eng.close()
+    finally:
+        engine.set_log(None)
+        P.opts.layer_chunk = 0
+        P.opts.eager = 0
+    frames = [m for m in seen if "walk frame (bins) per layer" in m]
+    assert frames, "no frame report in the debug log"
+    kinds = set(int(t) for t in frames[0].split(":")[-1].split())
+    assert kinds == {0, 2, 4, 8, 16}, kinds
+    for r in runs:
+        assert rel_err(r["e"], ref["e"]) < 1e-9
+        assert rel_err(r["spectrum"], ref["spectrum"]) < 1e-9
+    assert np.array_equal(runs[0]["e"], runs[1]["e"])
+
+
 def test_wide_frames_without_the_row_copy_give_the_same_bits(tmp_path, monkeypatch):
     """Frames of 4+ bins read a row copy of the Voigt table (k_line_walk, `tabW`); when that copy
     would pass 4 GB a handle has none and those frames run their per-bin form.  Same spectrum, bit
