@@ -1842,7 +1842,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
     }
     E.intens = h->d_intens.as<double>(); E.flux = d_out; E.e2tab = h->d_e2tab.as<double>();
-    hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + kEmisWaves - 1) / kEmisWaves)), dim3(64 * kEmisWaves), 0, st, E);
+    if (h->nwn > kEmisRowsAbove)       // (by the job's grid, not the shard: all shards of a job add in the same order)
+      hipLaunchKernelGGL(k_emission_rows, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, E);
+    else
+      hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + kEmisWaves - 1) / kEmisWaves)), dim3(64 * kEmisWaves), 0, st, E);
   } else {
     ModArgs M{};
     M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;

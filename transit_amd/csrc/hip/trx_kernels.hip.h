@@ -1606,6 +1606,54 @@ void k_emission(EmisArgs E)
   if (lane == 0) E.flux[w] = fl;
 }
 
+// The same for large grids (more than kEmisRowsAbove wavenumbers in the JOB's grid, so that every
+// shard of a job takes the same form): one LANE per wavenumber going down its heights -- the loads
+// of a height are one coalesced row segment, no lane shifts, no wave sums; with 10^7 rays there are
+// waves enough to hide a lane's chain of exponentials (configs[4]: 27 -> 5 ms).  The trapezoid
+// terms are added in height order (the wave form adds them in its butterfly order).
+constexpr long long kEmisRowsAbove = 65536;
+
+__global__ __launch_bounds__(256)
+void k_emission_rows(EmisArgs E)
+{
+  __shared__ double s_e2[64];
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = E.e2tab[threadIdx.x];
+  __syncthreads();
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= E.nsh) return;
+  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
+  const int last = E.last[w];                  // (< 0: the ray is still descending -- provisional spectrum, zero)
+  const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
+  const double pl_exp = kH * wv * kLs;
+  double sum[kMaxAngles], dtp[kMaxAngles];
+#pragma unroll
+  for (int a = 0; a < kMaxAngles; a++) { sum[a] = 0.0; dtp[a] = 0.0; }
+  double Bp = 0.0;
+  for (int i = 0; i <= last; i++) {
+    const double tv = E.tau[(long long)i * E.nsh + w];
+    const double B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
+#pragma unroll
+    for (int a = 0; a < kMaxAngles; a++) {
+      if (a < E.nang) {
+        const double dt = exp_neg(-tv / E.cosang[a], s_e2);
+        if (i > 0) sum[a] += (dt - dtp[a]) * (B + Bp);
+        dtp[a] = dt;
+      }
+    }
+    Bp = B;
+  }
+  double fl = 0.0;
+#pragma unroll
+  for (int a = 0; a < kMaxAngles; a++) {
+    if (a < E.nang) {
+      const double I = Bp * dtp[a] - 0.5 * sum[a];
+      E.intens[(long long)a * E.nsh + w] = I;
+      fl += kPi * I * E.area[a];
+    }
+  }
+  E.flux[w] = fl;
+}
+
 struct ModArgs {
   int nr, modlevel, transparent; long long nsh;
   double toomuch, ip_fct, srad;
