@@ -180,10 +180,18 @@ TRX_HD int spline_interval(const double *x, long n, double xo, long xs = 1)
 }
 
 // pu/src/spline.c:131-183 (splinterp_pt): Horner form
+// (the evaluation in interval k on its own: a caller that evaluates many splines over the same
+// abscissa at the same point locates the interval once)
+TRX_HD double spline_eval_at(int k, const double *z, const double *x, const double *y, double xo,
+                             long zs = 1, long xs = 1, long ys = 1);
 TRX_HD double spline_eval_pt(const double *z, long n, const double *x, const double *y, double xo,
                              long zs = 1, long xs = 1, long ys = 1)
 {
-  const int k = spline_interval(x, n, xo, xs);
+  return spline_eval_at(spline_interval(x, n, xo, xs), z, x, y, xo, zs, xs, ys);
+}
+TRX_HD double spline_eval_at(int k, const double *z, const double *x, const double *y, double xo,
+                             long zs, long xs, long ys)
+{
   const double xl = x[k*xs], xh = x[(k+1)*xs], yl = y[k*ys], yh = y[(k+1)*ys];
   const double h = xh - xl, dy = yh - yl;
   if (xl == xo) return yl;
