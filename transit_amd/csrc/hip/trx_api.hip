@@ -603,8 +603,12 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
       hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr, d_tlay);
       hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((ljl - fjl + 63) / 64), (unsigned)B.n), dim3(64), 0, cst, B, nr);
     }
-    hipLaunchKernelGGL(k_cia_eval, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)((lj1 - fj0 + kCiaEvalLayers - 1) / kCiaEvalLayers)), dim3(256), 0, cst,
-                       B, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi0, li1, fj0, lj1, first ? 1 : 0, h->d_ecs.as<double>());
+    if (nsh > 65536)
+      hipLaunchKernelGGL(k_cia_eval<16>, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)((lj1 - fj0 + 15) / 16)), dim3(256), 0, cst,
+                         B, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi0, li1, fj0, lj1, first ? 1 : 0, h->d_ecs.as<double>());
+    else
+      hipLaunchKernelGGL(k_cia_eval<1>, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)(lj1 - fj0)), dim3(256), 0, cst,
+                         B, nr, nsh, h->lo, h->wn_i, h->wn_d, o->wn_fct, fi0, li1, fj0, lj1, first ? 1 : 0, h->d_ecs.as<double>());
     B.n = 0; first = false;
   };
   for (size_t n = 0; n < h->cia.size(); n++) {

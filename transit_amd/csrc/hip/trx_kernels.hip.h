@@ -960,26 +960,27 @@ void k_cia_layers(CiaBatch B, int nr)
 // array and starts every sum from zero (a memset of the array ahead of the kernels was a dispatch
 // of its own on this queue, 12-35 us next to a walk); a later batch covers the union of its
 // tables' ranges and adds to what is there.
-constexpr int kCiaEvalLayers = 16;     // layers per lane of k_cia_eval: a table interval is located once for them
-
+// G layers per lane: a table interval is located once for them.  16 on large grids (10^7 rays:
+// 17 -> 10 ms at configs[4]); on small ones the searches are nothing and the lanes are few: 1.
+template <int G>
 __global__ __launch_bounds__(256)
 void k_cia_eval(CiaBatch B, int nr, long long nsh, long long lo, double wn_i, double wn_d, double wn_fct,
                 long long fi0, long long li1, int fj0, int lj1, int first, double *__restrict__ ecs)
 {
   const long long w = fi0 + (long long)blockIdx.x * 256 + threadIdx.x;
-  const int j0 = fj0 + blockIdx.y * kCiaEvalLayers, nj = min(kCiaEvalLayers, lj1 - j0);
+  const int j0 = fj0 + blockIdx.y * G, nj = min(G, lj1 - j0);
   if (w >= li1) return;
   const double xo = wn_fct * (wn_i + (double)(lo + w) * wn_d);
-  double sum[kCiaEvalLayers];
+  double sum[G];
   unsigned any = first ? 0xffffu : 0u;
 #pragma unroll
-  for (int q = 0; q < kCiaEvalLayers; q++) sum[q] = (first || q >= nj) ? 0.0 : ecs[(long long)(j0 + q) * nsh + w];
+  for (int q = 0; q < G; q++) sum[q] = (first || q >= nj) ? 0.0 : ecs[(long long)(j0 + q) * nsh + w];
   for (int t = 0; t < B.n; t++) {
     const CiaJob &J = B.J[t];
     if (w < J.fi || w >= J.li) continue;
     const int k = spline_interval(J.C.wn, J.C.nwave, xo);          // the same for every layer
 #pragma unroll
-    for (int q = 0; q < kCiaEvalLayers; q++) {
+    for (int q = 0; q < G; q++) {
       const int j = j0 + q;
       if (q >= nj || j < J.fj || j >= J.lj) continue;
       const double val = spline_eval_at(k, J.z2 + j, J.C.wn, J.mid + j, xo, nr, 1, nr);
@@ -987,7 +988,7 @@ void k_cia_eval(CiaBatch B, int nr, long long nsh, long long lo, double wn_i, do
     }
   }
 #pragma unroll
-  for (int q = 0; q < kCiaEvalLayers; q++)
+  for (int q = 0; q < G; q++)
     if (q < nj && ((any >> q) & 1u)) ecs[(long long)(j0 + q) * nsh + w] = sum[q];
 }
 
