@@ -159,7 +159,7 @@ void k_cand_pack(int n, const int32_t *__restrict__ cand, const double *__restri
 // kLayerMaxGroup layers: the lines are read once, the lanes keep running maxima per layer and the
 // wave reduces them once at the end.  cand == null: all lines.  kmax is [layer][nmx] bit
 // patterns, zeroed beforehand.
-constexpr int kLayerMaxGroup = 16;
+constexpr int kLayerMaxGroup = 8;
 constexpr int kLayerMaxLines = 4;
 
 __global__ __launch_bounds__(64)
