@@ -474,6 +474,20 @@ def test_sixty_four_isotopes_and_one_too_many(tmp_path):
     assert ei.value.code == -6
 
 
+def test_large_grid_modulation_kernel_against_oracle(tmp_path):
+    """The transit counterpart: above 65 536 wavenumbers the modulation integral runs one lane per
+    wavenumber (k_modulation_rows); spectrum and optical depth against the CPU restatement."""
+    d = str(tmp_path / "wide_t")
+    synth.make_case(d, nlines=60, wnlow=2500, wnhigh=2507, wndelt=1e-4, wnosamp=1, nlayers=9, solution="transit", seed=6,
+                    toomuch=10.0, nwidth=2.0)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    assert P.nwn > 65536
+    got, ref = _both(P.static, P)
+    assert np.array_equal(got["last"], ref["last"])
+    assert_tau_close(P, got, ref)
+    assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-8
+
+
 def test_large_shard_emission_kernel_against_oracle(tmp_path):
     """A 70 001-point grid with few layers: the small-shard variants of the optical-depth and
     start-up kernels switch off above 65 536 wavenumbers; spectrum and per-angle intensities

@@ -1855,7 +1855,10 @@ static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
     M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
     M.ip = d_ipv; M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
-    hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + kModWaves - 1) / kModWaves)), dim3(64 * kModWaves), 0, st, M);
+    if (h->nwn > kEmisRowsAbove)
+      hipLaunchKernelGGL(k_modulation_rows, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
+    else
+      hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + kModWaves - 1) / kModWaves)), dim3(64 * kModWaves), 0, st, M);
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(ev.b, st));

@@ -1747,4 +1747,58 @@ void k_modulation(ModArgs M)
   M.out[w] = res;
 }
 
+// The same for large grids (like k_emission_rows, by the job's grid): one lane per wavenumber,
+// the interval pairs of its radial integral in order.
+__global__ __launch_bounds__(256)
+void k_modulation_rows(ModArgs M)
+{
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= M.nsh) return;
+  const int nr = M.nr;
+  const int last = M.last[w];
+  if (last < 0) { M.out[w] = 0.0; return; }
+  const double *tw = M.tau + w;                           // tw[i*nsh] = tau[i][w]
+  if (M.modlevel == -1) {
+    const double tl = tw[(long long)last * M.nsh];
+    if (tl < M.toomuch) { M.out[w] = -1; *M.status = 1; return; }
+    int ini = last + 1 - 2; if (ini < 0) ini = 0;
+    const double x0 = tw[(long long)ini * M.nsh], x1 = tw[(long long)(ini+1) * M.nsh];
+    const double y0 = M.ip[ini] * M.ip_fct, y1 = M.ip[ini+1] * M.ip_fct;
+    const double r = y0 + (M.toomuch - x0) * ((y1 - y0) / (x1 - x0));
+    M.out[w] = r * r / (M.srad * M.srad);
+    return;
+  }
+  const double tlast = tw[(long long)last * M.nsh];
+  const double maxtau = tlast > M.toomuch ? tlast : M.toomuch;
+  int lastp = last + 1; if (lastp > nr - 1) lastp = nr - 1;
+  const int cnt = lastp + 1;                               // points, including the zero pad
+  if (cnt < 3) { M.out[w] = nan(""); *M.status = 2; return; }
+  const double *g = M.gw + (long long)cnt * M.gstride;
+  auto val = [&](int q) -> double {
+    const int i = cnt - 1 - q;
+    if (i > last) return 0.0;                              // slantpath.c:383-386
+    const double b = M.ip[i] * M.ip_fct;
+    return exp(-tw[(long long)i * M.nsh]) * b;
+  };
+  const int even = (cnt % 2 == 0), npair = (cnt - 1) / 2;
+  double acc = 0.0;
+  double va = val(even);                                   // a pair's last point is the next pair's first
+  for (int i = 0; i < npair; i++) {
+    const int j = 2*i + even;
+    const double vb = val(j+1), vc = val(j+2);
+    acc += (va * g[4*i] + vb * g[4*i+1] + vc * g[4*i+2]) * g[4*i+3];
+    va = vc;
+  }
+  double res = acc / 6.0;
+  if (even) res += M.gh0[cnt] * (val(0) + val(1)) / 2;
+  const double rtop = M.ip[0] * M.ip_fct;
+  res = rtop * rtop - 2.0 * res;
+  if (M.transparent) {
+    const double bmin = M.ip[cnt - 1] * M.ip_fct;
+    res -= exp(-maxtau) * bmin * bmin;
+  }
+  res *= 1.0 / (M.srad * M.srad);
+  M.out[w] = res;
+}
+
 }  // namespace trx
