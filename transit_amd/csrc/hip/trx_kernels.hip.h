@@ -4,7 +4,7 @@
 // dense contraction, hence no MFMA.  Wavefront = 64 lanes.
 //
 //   k_voigt_bins / k_voigt_bins_wave  Voigt-profile table      (opacity.c:219-277, voigt.c)
-//   (the line sweep of layers whose profiles reach <= 3 cells is trx_walk.hip.h: k_line_walk)
+//   (the line sweep of layers whose profiles reach <= 7 cells is trx_walk.hip.h: k_line_walk)
 //   k_group_sweep                     two-kernel form, wider profiles: passes 1+2a, co-added
 //                                     group strength and Doppler index (extinction.c:399-483)
 //   k_sticky_index                    sticky Doppler index, all layers of a run up front
@@ -12,7 +12,8 @@
 //   k_accumulate                      pass 2b: threshold + profile accumulation into
 //                                     e[layer][wn], gather per 4-bin tile (extinction.c:467-509)
 //   k_accumulate_wide                 the same for profiles >= 64 coarse bins: lanes own bins,
-//                                     phase-major table (k_table_phase_major)
+//                                     phase-major table (k_table_phase_major, which also makes the
+//                                     walk's row copy)
 //   k_grid_extinction                 opacity-grid mode          (extinction.c:535-581)
 //   k_cia_rows/_layers/_eval          CIA extinction            (crosssec.c:272-428)
 //   k_slant_geometry                  transit rays: impact parameters, bracket layers, Simpson weights
@@ -20,9 +21,12 @@
 //   k_optical_depth(_vertical)        total extinction + ray quadrature + toomuch cut
 //                                                               (tau.c:216-305, eclipse.c:29-105,
 //                                                                slantpath.c:19-108)
+//   k_extras_factors                  scattering / cloud models: their wavenumber factors, once per ray
 //   k_extras_dump                     scattering / cloud terms alone (savefiles dumps, tau.c:180-190)
 //   k_emission / k_modulation         spectrum from tau         (eclipse.c:118-287, slantpath.c:351-473);
-//                                     k_emission: one wave per wavenumber, lanes = heights
+//                                     k_emission: one wave per wavenumber, lanes = heights;
+//                                     k_emission_rows / k_modulation_rows: one lane per wavenumber
+//                                     (grids of more than 65 536 wavenumbers)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

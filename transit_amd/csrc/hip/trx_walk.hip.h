@@ -6,7 +6,9 @@
 //   k_layer_max                          strongest single line of every layer (extinction.c:399-427)
 //   k_wave_plan                          bin interval and partial-sum slot of every line range
 //   k_line_walk<NB>                      passes 2a + 2b of computemolext (extinction.c:429-511)
-//                                        for up to 64 layers at once: LANES ARE LAYERS
+//                                        for up to 64 layers at once: LANES ARE LAYERS (frames of
+//                                        8+ bins in steps of <= 32 layers: two lanes per layer);
+//                                        frames of 4+ bins read a row copy of the Voigt table
 //   k_walk_combine                       adds the line ranges' partial sums into e[layer][wn]
 //
 // Why lanes = layers.  At 1 cm-1 output resolution a line reaches 0-2 coarse bins per layer, so
