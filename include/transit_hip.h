@@ -207,7 +207,7 @@ typedef struct {
   int64_t sum_bins;       /* accumulated (group,layer,bin) triples             */
   int64_t table_floats;   /* Voigt table size                                  */
   double  ms_create_table;/* device time of the Voigt-table build              */
-  double  ms_run_total;   /* device time of the last run, first to last kernel */
+  double  ms_run_total;   /* device time of the last run, first to last kernel (profiled runs, trx_opts.profile; else 0) */
   double  ms_sweep;       /* line-sweep kernels (profile >= 1; as ms_k_* and ms_tau) */
   double  ms_k_sweep;      /* sum over launches of the line kernel (k_line_walk, or k_group_sweep where profiles are wide) */
   double  ms_k_sticky;     /* unused (the sticky Doppler index is computed once per run)  */
