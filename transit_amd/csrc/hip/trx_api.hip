@@ -27,6 +27,7 @@
 #include "transit_hip.h"
 #include "trx_kernels.hip.h"
 #include "trx_walk.hip.h"
+#include "trx_rows.hip.h"
 
 using namespace trx;
 
@@ -74,6 +75,8 @@ struct trx_handle {
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
   // the walk's copy: phase-major rows with kWalkPad zeros behind each, one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
+  long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
+  bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
   DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge, d_cntsub;
@@ -263,7 +266,8 @@ int build_table(trx_handle *h, const trx_static *s)
   DevBuf d_jobs;
   if ((rc = upload(h, d_jobs, jobs))) return rc;
   // (behind the table: kWalkMaxFrame cells of zeros, where the walk's lanes read what a slot does not reach)
-  const size_t tab_alloc = (size_t)h->tab_n + 2 * kTabPad + (size_t)kWalkMaxFrame * (size_t)std::min<int64_t>(s->osamp, 1 << 21);
+  // (and kRowTail more: k_accumulate_rows stages whole 256-float pieces of a row, trx_rows.hip.h)
+  const size_t tab_alloc = (size_t)h->tab_n + 2 * kTabPad + (size_t)kWalkMaxFrame * (size_t)std::min<int64_t>(s->osamp, 1 << 21) + kRowTail;
   if ((rc = ensure(h, h->d_tab, sizeof(float) * tab_alloc))) return rc;
   HIPCHK(h, hipMemsetAsync(h->d_tab.p, 0, sizeof(float) * tab_alloc, h->stream));
   h->tab = h->d_tab.as<float>() + kTabPad;
@@ -347,6 +351,8 @@ int build_table(trx_handle *h, const trx_static *s)
     long long totW = 0;
     for (size_t j = 0; j < jobs.size(); j++) { joffW[j] = totW; totW += (long long)s->osamp * ((jobs[j].nv - 1) / s->osamp + 1 + kWalkPad); }
     h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !std::getenv("TRX_NO_ROW_COPY");      // (the variable: tests of the fallback)
+    h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");
+    if (const char *v = std::getenv("TRX_ROWS_M8_FROM")) h->row_m8_from = std::atoll(v);
     if (h->tabw_ok) {
       std::vector<WalkProfile> desc((size_t)s->ndop * s->nlor);
       size_t j = 0;
@@ -1038,7 +1044,26 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
       WideArgs W{}; W.A = A; W.tabT = h->tabT; W.poffT = h->poffT;
       W.gimod = h->d_gimod.as<int32_t>(); W.gidiv = h->d_gidiv.as<int32_t>(); W.layer_mask = wide_mask;
       const unsigned wtiles = (unsigned)((nsh + 64 * kWideM - 1) / (64 * kWideM));
-      hipLaunchKernelGGL(k_accumulate_wide, dim3((wtiles + 3) / 4, (unsigned)nc), dim3(256), 0, st, W);
+      // no oversampling: every group of a profile reads the same row -- staged in LDS (trx_rows.hip.h);
+      // layers whose profiles are much wider than a tile take tiles of 512 bins, the others of 256
+      if (h->osamp == 1 && h->row_staging) {
+        unsigned m8 = 0;
+        for (int c = 0; c < nc; c++)
+          if (((wide_mask >> c) & 1u) && 2 * layer_psmax(h, psmax, r_top - c) + 1 >= h->row_m8_from) m8 |= 1u << c;
+        auto launch = [&](unsigned mask, int m) {
+          if (!mask) return;
+          W.layer_mask = mask;
+          const unsigned tiles = (unsigned)((nsh + 64 * m - 1) / (64 * m));
+          const dim3 grid((tiles + 3) / 4, (unsigned)nc);
+          const size_t lds = rows_lds_bytes(h->ndop, m);
+          if (M.prof) hipLaunchKernelGGL((k_accumulate_rows<true, 4>), grid, dim3(256), lds, st, W);      // (counting runs: one tile size)
+          else if (m == 8) hipLaunchKernelGGL((k_accumulate_rows<false, 8>), grid, dim3(256), lds, st, W);
+          else hipLaunchKernelGGL((k_accumulate_rows<false, 4>), grid, dim3(256), lds, st, W);
+        };
+        if (M.prof) launch(wide_mask, 4);
+        else { launch(wide_mask & ~m8, 4); launch(m8, 8); }
+      }
+      else hipLaunchKernelGGL(k_accumulate_wide, dim3((wtiles + 3) / 4, (unsigned)nc), dim3(256), 0, st, W);
     }
   }
   if (sp && sp->end(st)) return fail(h, TRX_E_HIP, "event");

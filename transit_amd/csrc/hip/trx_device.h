@@ -13,7 +13,7 @@ constexpr int kMaxIso     = 64;    // isotopes per run
 constexpr int kMaxAngles  = 16;
 constexpr int kMaxDop     = 256;   // Doppler-width samples (ndop)
 constexpr int kTileBins   = 4;     // coarse bins per wavefront tile in the accumulate kernel
-constexpr int kTabPad     = 256;   // zero floats in front of and behind the Voigt tables (>= bins per wide tile)
+constexpr int kTabPad     = 512;   // zero floats in front of and behind the Voigt tables (>= bins per wide tile, trx_rows.hip.h's too)
 
 // One distinct Voigt profile of the table (opacity.c:258-270, getprofile).
 struct ProfileJob {
