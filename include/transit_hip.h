@@ -270,6 +270,9 @@ int  trx_width_grids(const trx_handle *h, double *adop /* [ndop] */, double *alo
 int  trx_comm_unique_id(void *id_out /* TRX_COMM_ID_BYTES */);
 int  trx_comm_create(const void *id, int nranks, int rank, int device, void **comm_out);
 void trx_comm_destroy(void *comm);
+/* Give a communicator up without the collective teardown (ncclCommAbort): for the error path of a
+ * job in which some rank failed and the others must not wait for it. */
+void trx_comm_abort(void *comm);
 
 /* The one exchange of a wavenumber-sharded job ("one ncclAllGather of the
  * spectrum slices at the end"): every rank hands in `count` doubles in device memory (its slice,

@@ -163,3 +163,41 @@ def test_cli_multi_gpu_shards_give_the_single_gpu_files(tmp_path, case, ngpus):
     got = ol.read_spectrum(outs[ngpus] / "spectrum.dat")
     ref = ol.read_spectrum(os.path.join(GOLDEN, case, "spectrum.dat"))
     assert rel_err(got[:, 1], ref[:, 1]) < 2e-8
+
+
+def _run_ranks(tmp_path, case, ngpus, env=None):
+    exe = build.build_cli() or build.lib_path("transit_hip")
+    work = tmp_path / ("%s_%d" % (case, ngpus))
+    shutil.copytree(os.path.join(GOLDEN, case), work)
+    if os.path.exists(work / "spectrum.dat"):
+        os.remove(work / "spectrum.dat")
+    p = subprocess.run([exe, "-c", "case.cfg", "--gpus", str(ngpus)], cwd=work, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, **(env or {})))
+    return work, p
+
+
+def test_cli_ranks_without_gpu_stop_together(tmp_path):
+    """--gpus 3 on a box without a device: every rank fails in its own phase, the job reports
+    them all and ends -- no rank is left waiting in a collective (the timeout is the test)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    work, p = _run_ranks(tmp_path, "eclipse_small", 3)
+    assert p.returncode != 0
+    for k in range(3):
+        assert "rank %d: trx_create failed" % k in p.stderr
+    assert "no rank enters the next one" in p.stderr
+    assert not os.path.exists(work / "spectrum.dat")
+
+
+@pytest.mark.gpu
+def test_cli_one_failing_rank_stops_the_job_before_the_gather(tmp_path):
+    """One rank of three fails on its own (injected: TRANSIT_HIP_FAIL_RANK) while the others
+    finish their spectra: the job must not enter the gather (with a communicator the other ranks
+    would wait in ncclAllGather for ever), must name the rank and must not write a spectrum."""
+    work, p = _run_ranks(tmp_path, "eclipse_small", 3, env={"TRANSIT_HIP_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert "rank 1: trx_run (TRANSIT_HIP_FAIL_RANK) failed" in p.stderr
+    assert "rank 0:" not in p.stderr and "rank 2:" not in p.stderr
+    assert "stopping after the spectrum phase" in p.stderr
+    assert not os.path.exists(work / "spectrum.dat")

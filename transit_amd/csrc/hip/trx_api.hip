@@ -73,7 +73,7 @@ struct trx_handle {
   // both tables carry kTabPad zero floats in front and behind: k_accumulate_wide reads whole
   // 4-float lane segments around a profile row and masks what lies outside the row
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
-  // the walk's copy: phase-major rows with kWalkPad zeros behind each, one WalkProfile per table entry
+  // the walk's copy: phase-major rows of whole cache lines (walk_row_layout), one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
@@ -342,14 +342,17 @@ int build_table(trx_handle *h, const trx_static *s)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->tabT = h->d_tabT.as<float>() + kTabPad; h->poffT = h->d_poffT.as<long long>();
   }
-  // The walk's copy (trx_walk.hip.h): phase-major rows, each followed by kWalkPad zeros -- the
+  // The walk's copy (trx_walk.hip.h): phase-major rows, each between zeros (walk_row_layout) -- the
   // bins of a frame are CONSECUTIVE entries of one row, and what a narrow profile does not reach
   // is zero by position (the pad behind a row is also the pad in front of the next).  One
   // descriptor per table entry.  32-bit byte offsets: no copy when it would pass 4 GB (walk_chunk).
   {
     std::vector<long long> joffW(jobs.size());
     long long totW = 0;
-    for (size_t j = 0; j < jobs.size(); j++) { joffW[j] = totW; totW += (long long)s->osamp * ((jobs[j].nv - 1) / s->osamp + 1 + kWalkPad); }
+    for (size_t j = 0; j < jobs.size(); j++) {
+      int front, stride; walk_row_layout((jobs[j].nv - 1) / s->osamp + 1, front, stride);
+      joffW[j] = totW; totW += (long long)s->osamp * stride;
+    }
     h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !std::getenv("TRX_NO_ROW_COPY");      // (the variable: tests of the fallback)
     h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");
     if (const char *v = std::getenv("TRX_ROWS_M8_FROM")) h->row_m8_from = std::atoll(v);
@@ -361,8 +364,9 @@ int build_table(trx_handle *h, const trx_static *s)
           const size_t e = (size_t)i * s->nlor + k;
           if (h->adop[i] * 10.0 < h->alor[k] && i != 0) { desc[e] = desc[e - s->nlor]; continue; }
           const long long ps = h->psize[e], K = (2 * ps) / s->osamp + 1;
-          desc[e].centre4 = (uint32_t)(4 * (joffW[j++] + ps / s->osamp));
-          desc[e].rowb = (int32_t)(4 * (K + kWalkPad));
+          int front, stride; walk_row_layout((int)K, front, stride);
+          desc[e].centre4 = (uint32_t)(4 * (joffW[j++] + front + ps / s->osamp));
+          desc[e].rowb = (int32_t)(4 * stride);
           desc[e].psr = (int32_t)(ps % s->osamp);
           desc[e].ps = (int32_t)ps;
         }
@@ -373,7 +377,7 @@ int build_table(trx_handle *h, const trx_static *s)
       for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
         const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
         hipLaunchKernelGGL(k_table_phase_major, dim3(32, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
-                           d_joffW.as<long long>() + j0, h->tab, h->d_tabW.as<float>() + kTabPad, s->osamp, kWalkPad);
+                           d_joffW.as<long long>() + j0, h->tab, h->d_tabW.as<float>() + kTabPad, s->osamp, 1);
       }
       HIPCHK(h, hipStreamSynchronize(h->stream));
       h->tabW = h->d_tabW.as<float>() + kTabPad;
@@ -694,6 +698,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   const char *(*GetLastError)(ncclComm_t) = nullptr;
@@ -710,6 +715,7 @@ Rccl &rccl()
   R.GetUniqueId  = (decltype(R.GetUniqueId))dlsym(R.lib, "ncclGetUniqueId");
   R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.lib, "ncclCommInitRank");
   R.CommDestroy  = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
+  R.CommAbort    = (decltype(R.CommAbort))dlsym(R.lib, "ncclCommAbort");
   R.AllGather    = (decltype(R.AllGather))dlsym(R.lib, "ncclAllGather");
   R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
   R.GetLastError = (decltype(R.GetLastError))dlsym(R.lib, "ncclGetLastError");
@@ -1154,6 +1160,13 @@ int trx_comm_create(const void *idp, int nranks, int rank, int device, void **co
 void trx_comm_destroy(void *comm)
 {
   if (comm && rccl().ok()) (void)rccl().CommDestroy((ncclComm_t)comm);
+}
+
+void trx_comm_abort(void *comm)
+{
+  if (!comm || !rccl().ok()) return;
+  if (rccl().CommAbort) (void)rccl().CommAbort((ncclComm_t)comm);
+  else (void)rccl().CommDestroy((ncclComm_t)comm);
 }
 
 

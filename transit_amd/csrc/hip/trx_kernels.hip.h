@@ -798,21 +798,36 @@ void k_accumulate_wide(WideArgs W)
   }
 }
 
-// phase-major copy of one profile: tabT[offT + ph*(K + pad) + k] = tab[off + osamp*k + ph], each row
-// followed by `pad` zeros (pad = 0: the wide-profile kernel's copy; kWalkPad: the walk's)
+// The walk's rows (trx_walk.hip.h): every row is a whole number of 64-byte lines, its K entries
+// behind `front` zeros and in front of at least as many -- the bins of a frame are consecutive
+// entries of ONE row, inside ONE or two cache lines, and what a narrow profile does not reach is
+// zero by position.  Profiles of up to 8 entries per row: 4 zeros, the entries, zeros to 16 floats
+// (a frame of 8 bins = one aligned 64-byte line); up to 16 entries: 8 zeros, the entries, zeros to
+// 32 floats; wider ones (no frame reads them) the same with whole lines.
+__host__ __device__ inline void walk_row_layout(int K, int &front, int &stride)
+{
+  if (K <= 8) { front = 4; stride = 16; }
+  else if (K <= 16) { front = 8; stride = 32; }
+  else { front = 8; stride = (K + 16 + 15) & ~15; }
+}
+
+// phase-major copy of one profile: tabT[offT + ph*stride + front + k] = tab[off + osamp*k + ph]
+// (walk = 0: the wide-profile kernel's copy, rows back to back; 1: the walk's, walk_row_layout)
 __global__ __launch_bounds__(256)
 void k_table_phase_major(const ProfileJob *jobs, const long long *joffT, const float *__restrict__ tab,
-                         float *__restrict__ tabT, int of, int pad)
+                         float *__restrict__ tabT, int of, int walk)
 {
   const ProfileJob J = jobs[blockIdx.y];
   const long long offT = joffT[blockIdx.y];
   const int npt = J.nv;                                  // 2*ps + 1
   const int K = (npt - 1) / of + 1;
+  int front = 0, stride = K;
+  if (walk) walk_row_layout(K, front, stride);
   const long long total = (long long)of * K;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int ph = (int)(t / K), k = (int)(t - (long long)ph * K);
     const long long q = (long long)of * k + ph;
-    tabT[offT + (long long)ph * (K + pad) + k] = (q < npt) ? tab[J.off + q] : 0.f;
+    tabT[offT + (long long)ph * stride + front + k] = (q < npt) ? tab[J.off + q] : 0.f;
   }
 }
 

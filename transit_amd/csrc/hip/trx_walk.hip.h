@@ -325,14 +325,14 @@ constexpr double kWalkMinTemp = 1.4387752 * kRebaseSpan * 256.0 * 1.05;
 constexpr int kWalkMaxFrame = 16;    // bins of the widest frame (k_line_walk<16>)
 
 // The walk's copy of the Voigt table ("tabW", built by trx_create): per profile `osamp` rows, row
-// `ph` holding the entries q = osamp*kk + ph, kk = 0..K-1, followed by kWalkPad zeros.  The bins of a
-// frame sit a whole cell apart: they are CONSECUTIVE entries of one row, one or two wide loads per
-// lane instead of a load per bin, and where a profile does not reach the entries are zero by
-// position (a row's pad is also the pad in front of the next row; kTabPad zeros around the whole).
-constexpr int kWalkPad = kWalkMaxFrame / 2;
+// `ph` holding the entries q = osamp*kk + ph, kk = 0..K-1, between zeros (walk_row_layout,
+// trx_kernels.hip.h: rows are whole 64-byte lines).  The bins of a frame sit a whole cell apart: they are
+// CONSECUTIVE entries of one row, one or two wide loads per lane instead of a load per bin, inside
+// one cache line for frames of up to 8 bins, and where a profile does not reach the entries are
+// zero by position (kTabPad zeros around the whole).
 struct alignas(16) WalkProfile {
   uint32_t centre4;                  // byte offset of (row 0, kk = ps / osamp)
-  int32_t rowb;                      // bytes per row, 4*(K + kWalkPad)
+  int32_t rowb;                      // bytes per row (walk_row_layout)
   int32_t psr;                       // ps % osamp
   int32_t ps;                        // half-width in table samples
 };
@@ -414,7 +414,7 @@ __device__ __forceinline__ double exp_small(double x)
 constexpr int kWalkWaves = 4;        // independent waves per workgroup (a CU holds few workgroups)
 
 // LPL = 2 (steps of at most 32 layers, row form): TWO lanes per layer, each with half of the frame --
-// lane = 32*half + layer.  The frame's row segment is then fetched by ONE load instruction per
+// lane = 2*layer + half: the two halves of a frame are neighbouring lanes reading one cache line.  The frame's row segment is then fetched by ONE load instruction per
 // group instead of two (the wide frames are bound by their table loads: a further 16-byte load per
 // lane and group costs 35 us of 153 even when it hits the same cache line); the strength
 // arithmetic is done twice, on lanes that would be idle.
@@ -457,7 +457,7 @@ void k_line_walk(WalkArgs A)
   const long long rec0 = A.P.off[w];
 
   // ---- this lane's layer (and, with lane pairs, its part of the frame: slots part*NS ...)
-  const int li = LPL == 1 ? lane : (lane & 31), part = LPL == 1 ? 0 : (lane >> 5);
+  const int li = LPL == 1 ? lane : (lane >> 1), part = LPL == 1 ? 0 : (lane & 1);
   const bool valid = li < A.nc;
   const int r = A.r_top - (valid ? li : 0), ri = r * A.niso + b;
   const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
@@ -606,7 +606,7 @@ void k_line_walk(WalkArgs A)
             for (; sh > 0; sh--) {
               flush(NS - 1, acc[NS - 1], part == LPL - 1);            // the frame's last bin
               double carry = 0.0;                                      // the lower part's last bin moves up a lane
-              if (LPL == 2) carry = __shfl_xor(acc[NS - 1], 32, 64);
+              if (LPL == 2) carry = __shfl_xor(acc[NS - 1], 1, 64);
 #pragma unroll
               for (int k = NS - 1; k > 0; k--) acc[k] = acc[k - 1];
               acc[0] = (LPL == 2 && part == 1) ? carry : 0.0;
@@ -626,7 +626,7 @@ void k_line_walk(WalkArgs A)
           const unsigned c4 = own ? wp_cur.centre4 : wp_st.centre4;
           const int rb = own ? wp_cur.rowb : wp_st.rowb;
           const int d = (own ? wp_cur.psr : wp_st.psr) - imod, sgn = d >> 31;          // sgn = -1: borrowed a cell
-          const unsigned at = c4 + (unsigned)((d + (sgn & A.osamp)) * rb) + (unsigned)((sgn + 1) << 2);
+          const unsigned at = c4 + (unsigned)(d + (sgn & A.osamp)) * (unsigned)rb + (unsigned)((sgn + 1) << 2);     // (unsigned product: a profile's rows may pass 2 GB, the copy as a whole stays below 4 GB)
           struct alignas(4) Row { float v[NS]; } row;
           __builtin_memcpy(&row, tabw_base + at + 4u * (unsigned)(NS * part), sizeof row);       // 4-byte aligned wide loads
 #pragma unroll

@@ -127,7 +127,39 @@ int main(int argc, char **argv)
   t0 = now_s();
   std::vector<Rank> R((size_t)ngpus);
   std::vector<double> gathered((size_t)count * ngpus);    // rank 0's copy of the gather
-  auto work = [&](int k) {
+  // Three phases, every rank's status checked between them: a collective (the communicator's
+  // start-up, the gather) is entered only when EVERY rank got that far -- a rank that failed alone
+  // would leave the others waiting in it for ever.
+  //   1 communicator (collective: ncclCommInitRank)     2 create + run (no exchange: a rank may fail alone)
+  //   3 gather (collective: ncclAllGather)
+  // TRANSIT_HIP_FAIL_RANK=k (tests): rank k reports a failure in phase 2 without running.
+  const char *fail_env = std::getenv("TRANSIT_HIP_FAIL_RANK");
+  const int fail_rank = fail_env ? std::atoi(fail_env) : -1;
+  auto in_parallel = [&](auto &&phase) {
+    if (ngpus == 1) { phase(0); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < ngpus; k++) th.emplace_back(phase, k);
+    for (auto &t : th) t.join();
+  };
+  auto cleanup = [&](bool failed) {
+    for (auto &r : R) {
+      void *c = r.st.comm;
+      if (r.h) trx_destroy(r.h);
+      if (c) { if (failed) trx_comm_abort(c); else trx_comm_destroy(c); }     // (after a failure: no collective teardown either)
+    }
+    trh_free(P);
+  };
+  auto all_ok = [&](const char *phase) {
+    bool ok = true;
+    for (auto &r : R)
+      if (r.rc != TRX_OK) {
+        std::fprintf(stderr, "transit_hip: rank %d: %s failed: %s\n", r.rank, r.err.c_str(), trx_strerror(r.rc));
+        ok = false;
+      }
+    if (!ok && ngpus > 1) std::fprintf(stderr, "transit_hip: stopping after the %s phase: no rank enters the next one\n", phase);
+    return ok;
+  };
+  auto setup = [&](int k) {
     Rank &r = R[(size_t)k];
     r.rank = k; r.device = ndev > 0 ? k % ndev : 0;
     r.st = *trh_static(P);
@@ -138,6 +170,10 @@ int main(int argc, char **argv)
       if ((r.rc = trx_comm_create(comm_id, ngpus, k, r.device, &c)) != TRX_OK) { r.err = std::string("trx_comm_create: ") + trx_last_error(nullptr); return; }
       r.st.comm = c; r.st.nranks = ngpus; r.st.rank = k;
     }
+  };
+  auto work = [&](int k) {
+    Rank &r = R[(size_t)k];
+    if (k == fail_rank) { r.rc = TRX_E_HIP; r.err = "trx_run (TRANSIT_HIP_FAIL_RANK)"; return; }
     if ((r.rc = trx_create(&r.st, &r.h)) != TRX_OK) { r.err = "trx_create"; return; }
     const int64_t n = bounds[k + 1] - bounds[k];
     r.slice.assign((size_t)count, 0.0);
@@ -155,28 +191,22 @@ int main(int argc, char **argv)
     r.rc = trx_run(r.h, trh_atm(P), &opts, r.slice.data(), (dbg.tau || dbg.e || dbg.e_cs || dbg.intens) ? &dbg : nullptr);
     if (r.rc != TRX_OK) { r.err = std::string("trx_run: ") + trx_last_error(r.h); return; }
     trx_get_stats(r.h, &r.stats);
-    if (rccl) {                                            // the one exchange: all slices to every rank
-      std::vector<double> all((size_t)count * ngpus);
-      r.rc = trx_gather_host(r.h, r.slice.data(), all.data(), count);
-      if (r.rc != TRX_OK) { r.err = std::string("trx_gather: ") + trx_last_error(r.h); return; }
-      if (k == 0) gathered = all;
-    }
   };
-  if (ngpus == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int k = 0; k < ngpus; k++) th.emplace_back(work, k);
-    for (auto &t : th) t.join();
+  auto gather = [&](int k) {                               // the one exchange: all slices to every rank
+    Rank &r = R[(size_t)k];
+    std::vector<double> all((size_t)count * ngpus);
+    r.rc = trx_gather_host(r.h, r.slice.data(), all.data(), count);
+    if (r.rc != TRX_OK) { r.err = std::string("trx_gather: ") + trx_last_error(r.h); return; }
+    if (k == 0) gathered = all;
+  };
+  in_parallel(setup);
+  if (!all_ok("communicator")) { cleanup(true); return EXIT_FAILURE; }
+  in_parallel(work);
+  if (!all_ok("spectrum")) { cleanup(true); return EXIT_FAILURE; }
+  if (rccl) {
+    in_parallel(gather);
+    if (!all_ok("gather")) { cleanup(true); return EXIT_FAILURE; }
   }
-  auto cleanup = [&]() {
-    for (auto &r : R) { void *c = r.st.comm; if (r.h) trx_destroy(r.h); if (c) trx_comm_destroy(c); }
-    trh_free(P);
-  };
-  for (auto &r : R)
-    if (r.rc != TRX_OK) {
-      std::fprintf(stderr, "transit_hip: rank %d: %s failed: %s\n", r.rank, r.err.c_str(), trx_strerror(r.rc));
-      cleanup(); return EXIT_FAILURE;
-    }
   if (!rccl) for (int k = 0; k < ngpus; k++) std::memcpy(&gathered[(size_t)k * count], R[(size_t)k].slice.data(), sizeof(double) * (size_t)count);
 
   // ---- rank 0 stitches and writes
@@ -228,6 +258,6 @@ int main(int argc, char **argv)
   rc = trh_write_spectrum(P, spectrum.data(), nullptr);
   if (rc != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the spectrum file\n");
   if (verblevel > 3) std::printf("Check point: 00 - 15 outputs written:  wall since start = %.4f sec.\n", now_s() - t_start);
-  cleanup();
+  cleanup(false);
   return rc == TRX_OK ? EXIT_SUCCESS : EXIT_FAILURE;
 }
