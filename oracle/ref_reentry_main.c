@@ -7,7 +7,9 @@
  * -DTEST_TRANSIT so that its own main() steps aside, transit.c:230-234) and
  * contains no reference code.  Usage:
  *     transit_reentry <cfg> <inputs.txt> <out_prefix>
- * inputs.txt: one run per line, (1+nmol)*nlayer numbers: T(nlayer), q_0(nlayer), ...
+ * inputs.txt: one run per line, (1+nmol)*nlayer numbers: T(nlayer), q_0(nlayer), ...; a line
+ * that starts with a word calls one of the reference's setters between runs (transit.c:97-116):
+ *     radius <refradius>   |   cloudtop <log10 bar>   |   scattering <flag> <log10 factor>
  * Writes <out_prefix><k>.dat with one flux/modulation value per line (%.17g) and
  * <out_prefix><k>_radii.dat: per layer the reference's radius sampling after the reload
  * (tr->rads.v, the output of radpress + makeradsample, readatm.c:787-865, makesample.c:409-549)
@@ -35,6 +37,10 @@ int main(int argc, char **argv)
   double *out = malloc(sizeof(double) * nwn);
   int run = 0;
   while (fgets(line, (int)cap, in)) {
+    double a = 0, b = 0;
+    if (sscanf(line, " radius %lf", &a) == 1) { set_radius(a); continue; }
+    if (sscanf(line, " cloudtop %lf", &a) == 1) { set_cloudtop(a); continue; }
+    if (sscanf(line, " scattering %lf %lf", &a, &b) == 2) { set_scattering((int)a, b); continue; }
     size_t n = 0, room = 1024;
     double *v = malloc(sizeof(double) * room);
     char *p = line, *e;

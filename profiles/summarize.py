@@ -58,27 +58,50 @@ def kernel_source_hash():
     fingerprint matches the kernel sources of the tree it runs from."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("trx_walk.hip.h", "trx_kernels.hip.h"):
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h"):
         h.update(open(os.path.join(HERE, "..", "transit_amd", "csrc", "hip", f), "rb").read())
     return h.hexdigest()[:12]
 
 
-def sq_mix(d, tag):
-    """SQ instruction counts per launch and kernel (the walk is issue-bound, not HBM-bound)."""
-    names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES")
+def workload_key(src):
+    """What bench.py calls this workload (its own n_wn x n_layers x n_lines), from the bench line of the
+    traced run: bench.py quotes counters only from a summary of the workload it is running."""
+    line = os.path.join(src, "bench_line_under_trace.json")
+    try:
+        c = json.loads(open(line).read().strip().splitlines()[-1])["config"]
+        return "%d x %d x %d" % (c["n_wn"], c["n_layers"], c["n_lines"])
+    except Exception:
+        return None
+
+
+def counter_pass(d, tag, prefix, names, suffix, what, key):
+    """One PMC pass (its own rocprofv3 run) -> profiles/<tag>_<suffix>.json: per kernel and counter the
+    average per launch (summed over the XCD instances the CSV reports) and the number of launches."""
     out = collections.OrderedDict()
     for c in names:
         try:
-            for k, v in counter_by_kernel(d, c, "sq").items():
+            for k, v in counter_by_kernel(d, c, prefix).items():
                 if "trx::" in k:
                     out.setdefault(k, collections.OrderedDict())[c + "_avg_launch"] = sum(v) / len(v)
                     out[k]["launches"] = len(v)
         except SystemExit:
             return
-    dst = os.path.join(HERE, tag + "_sq_mix.json")
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc " + " ".join(names) + " (own pass)", "kernels": out},
+    dst = os.path.join(HERE, tag + "_" + suffix + ".json")
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc " + " ".join(names) + " (own pass)", "what": what,
+               "workload_key": key, "kernel_sources": kernel_source_hash(), "kernels": out},
               open(dst, "w"), indent=1)
     print("wrote", dst)
+
+
+def sq_mix(d, tag, key):
+    """SQ instruction counts per launch and kernel (the walk is issue-bound, not HBM-bound)."""
+    counter_pass(d, tag, "sq", ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES"), "sq_mix",
+                 "instructions issued per launch", key)
+    counter_pass(d, tag, "wait", ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                                  "SQ_BUSY_CYCLES", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"), "sq_wait",
+                 "wave-cycle split (SQ_* cycle counters in units of four clocks; GRBM_GUI_ACTIVE summed over the 8 XCDs)", key)
+    counter_pass(d, tag, "tcp", ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"), "tcp",
+                 "L1 tag look-ups, L1 -> L2 read requests, LDS-array cycles", key)
 
 
 def main():
@@ -130,7 +153,7 @@ def main():
             }
         doc = {
             "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + a.cmd,
-            "workload": a.workload,
+            "workload": a.workload, "workload_key": workload_key(a.src) if a.src else None,
             "kernel_sources": kernel_source_hash(),
             "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (HBM section: on gfx950 "
                           "FETCH_SIZE tallies 128-B requests at 64 B).  The guide calibrates that factor for wide coalesced "
@@ -143,7 +166,7 @@ def main():
         json.dump(doc, open(dst, "w"), indent=1)
         print("wrote", dst)
     if a.src:
-        sq_mix(a.src, a.tag)
+        sq_mix(a.src, a.tag, workload_key(a.src))
         line = os.path.join(a.src, "bench_line_under_trace.json")
         if os.path.exists(line):
             import shutil

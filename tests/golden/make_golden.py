@@ -76,6 +76,12 @@ CASES = {
     # same in transmission geometry: the case that exposed the reference's compiled form of
     # tau.c:274, b = (h*hfct)*(1/rfct); the radii after every radpress()
     # are kept too (<prefix>N_radii.dat)
+    # the same with the library's setters between the runs (set_radius, set_cloudtop, set_scattering:
+    # transit.c:97-116) -- reentry_inputs.txt carries them as keyword lines
+    "reentry_set": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="eclipse", seed=55,
+                        reentry="set", extra={"refpress": "0.1", "gsurf": "1000.0"}),
+    "reentry_set_transit": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="transit", seed=55,
+                                reentry="set", extra={"refpress": "0.1", "gsurf": "1000.0"}),
     "reentry_transit": dict(nlines=2000, wnlow=2500, wnhigh=2540, nlayers=20, solution="transit", seed=55,
                             reentry=True, extra={"refpress": "0.1", "gsurf": "1000.0"}),
     # abundance scaling while the atmosphere is read (qmol/qscale, readatm.c:394-405, 519-540:
@@ -157,8 +163,14 @@ def main():
             q3 = q.copy(); q3[atm.species.index("H2O")] *= 0.5
             t3 = atm.temperature * (1.0 - 0.04 * np.linspace(0, 1, nl))
             runs.append(np.concatenate([t3, q3.ravel()]))
+            setters = {}
+            if reentry == "set":          # before run 2 / 3 / 4 (run 4 repeats the first atmosphere under all three)
+                runs.append(runs[0])
+                setters = {1: "radius %.17g" % (1.015 * atm.radius[k0]), 2: "cloudtop -1.5", 3: "scattering 1 1.25"}
             with open(os.path.join(tmp, "reentry_inputs.txt"), "w") as f:
-                for r in runs:
+                for k, r in enumerate(runs):
+                    if k in setters:
+                        f.write(setters[k] + "\n")
                     f.write(" ".join("%.17g" % v for v in r) + "\n")
         if reentry:
             log = subprocess.run([REF_REENTRY, "case.cfg", "reentry_inputs.txt", "reentry_out"], cwd=tmp,

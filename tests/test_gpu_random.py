@@ -32,7 +32,7 @@ def random_case(seed):
                 seed=int(rng.integers(1, 10**6)), line_margin=float(rng.choice([0.0, 1.5])))
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("TRX_RANDOM_CASES", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TRX_RANDOM_CASES", "48"))))
 def test_random_problem_against_oracle(tmp_path, seed):
     kw = random_case(seed)
     d = str(tmp_path / "r")

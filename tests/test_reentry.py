@@ -124,3 +124,106 @@ def test_swig_module_lookalike_follows_the_reference():
     finally:
         os.chdir(old)
         trm.free_memory()
+
+
+# ---- the setters between runs: set_radius / set_cloudtop / set_scattering (transit.c:97-116) ----
+CASE_S = os.path.join(GOLDEN, "reentry_set")
+CASE_ST = os.path.join(GOLDEN, "reentry_set_transit")
+
+
+def setter_script(case):
+    """reentry_inputs.txt of the setter goldens: ("radius", r) / ("cloudtop", c) / ("scattering", flag, x)
+    between ("run", vector) entries, in file order (oracle/ref_reentry_main.c reads the same file)."""
+    out = []
+    for ln in open(os.path.join(case, "reentry_inputs.txt")):
+        w = ln.split()
+        if not w:
+            continue
+        if w[0] in ("radius", "cloudtop", "scattering"):
+            out.append((w[0],) + tuple(float(x) for x in w[1:]))
+        else:
+            out.append(("run", np.array([float(x) for x in w])))
+    return out
+
+
+def run_setter_sequence(engine_cls, case):
+    """Spectra and radii of the setter script through trh_set_* + trh_reload_atm + the engine."""
+    P = Problem.from_cfg(os.path.join(case, "case.cfg"))
+    eng = engine_cls(P.static)
+    outs, radii = [], []
+    for step in setter_script(case):
+        if step[0] == "radius":
+            P.set_radius(step[1])
+        elif step[0] == "cloudtop":
+            P.set_cloudtop(step[1])
+        elif step[0] == "scattering":
+            P.set_scattering(int(step[1]), step[2])
+        else:
+            P.reload_atm(step[1])
+            radii.append(P.layer_arrays()["radius"].copy())
+            outs.append(eng.run(P.atm, P.opts)["spectrum"])
+    eng.close()
+    return outs, radii
+
+
+def expected(case):
+    n = sum(1 for s in setter_script(case) if s[0] == "run")
+    return ([np.loadtxt(os.path.join(case, "reentry_out%d.dat" % (k + 1))) for k in range(n)],
+            [np.loadtxt(os.path.join(case, "reentry_out%d_radii.dat" % (k + 1))) for k in range(n)])
+
+
+def test_setter_script_uses_all_three_setters_and_they_matter():
+    for case in (CASE_S, CASE_ST):
+        kinds = [s[0] for s in setter_script(case)]
+        assert kinds == ["run", "radius", "run", "cloudtop", "run", "scattering", "run"]
+        spec, _ = expected(case)
+        # the last run repeats the first atmosphere: what differs is the setters' doing
+        assert rel_err(spec[3], spec[0]) > 1e-2 and rel_err(spec[1], spec[0]) > 1e-2
+
+
+@pytest.mark.parametrize("case,tol", [(CASE_S, 1e-9), (CASE_ST, 1e-9)])
+def test_oracle_follows_the_reference_through_the_setters(case, tol):
+    got, radii = run_setter_sequence(ol.OracleEngine, case)
+    spec, rad = expected(case)
+    for k in range(len(spec)):
+        assert np.array_equal(radii[k], rad[k]), (case, k)          # set_radius moves the hydrostatic radii: bit for bit
+        assert rel_err(got[k], spec[k]) < tol, (case, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,tol", [(CASE_S, 1e-9), (CASE_ST, 1e-8)])
+def test_gpu_follows_the_reference_through_the_setters(case, tol):
+    from transit_amd.engine import Engine
+    got, radii = run_setter_sequence(Engine, case)
+    spec, rad = expected(case)
+    for k in range(len(spec)):
+        assert np.array_equal(radii[k], rad[k]), (case, k)
+        assert rel_err(got[k], spec[k]) < tol, (case, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,tol", [(CASE_S, 1e-9), (CASE_ST, 1e-8)])
+def test_swig_module_lookalike_setters_follow_the_reference(case, tol):
+    """set_radius / set_cloudtop / set_scattering of transit_amd.transit_module, driven as BART does."""
+    import transit_amd.transit_module as trm
+    old = os.getcwd()
+    os.chdir(case)
+    try:
+        argv = ["transit", "-c", "case.cfg"]
+        trm.transit_init(len(argv), argv)
+        n = trm.get_no_samples()
+        spec, _ = expected(case)
+        k = 0
+        for step in setter_script(case):
+            if step[0] == "radius":
+                trm.set_radius(step[1])
+            elif step[0] == "cloudtop":
+                trm.set_cloudtop(step[1])
+            elif step[0] == "scattering":
+                trm.set_scattering(int(step[1]), step[2])
+            else:
+                assert rel_err(trm.run_transit(step[1], n), spec[k]) < tol, (case, k)
+                k += 1
+    finally:
+        os.chdir(old)
+        trm.free_memory()

@@ -57,9 +57,10 @@ def layer_quanta(radius, y):
     return q
 
 
-def tau_allowance(problem, dbg):
+def tau_allowance(problem, dbg, parts=False):
     """[wn][height] absolute allowance on the optical depth of a debug run (`dbg` must hold
-    e, e_scat, e_cloud, e_cs and tau), heights top first as in trx_debug.tau."""
+    e, e_scat, e_cloud, e_cs and tau), heights top first as in trx_debug.tau.  parts: the
+    arithmetic's share and the parabola quanta separately."""
     rad = problem.layer_arrays()["radius"]
     fct = float(problem.atm.rad_fct)
     nr = len(rad)
@@ -84,20 +85,30 @@ def tau_allowance(problem, dbg):
             chord = np.sqrt(max(rad[rs + 1] ** 2 - rad[rs] ** 2, 0.0))
             allow[:, ri] = NQ * fct * q[rs] * 2 * chord
     scale = np.abs(dbg["tau"]).max(axis=1, keepdims=True)
+    if parts:
+        return STRICT * scale, allow
     return STRICT * scale + allow
 
 
 def assert_tau_close(problem, got, ref, note=None):
-    """got["tau"] against ref["tau"] (ref a debug run with the arrays tau_allowance needs)."""
+    """got["tau"] against ref["tau"] (ref a debug run with the arrays tau_allowance needs).
+    Returns the rays that CAN carry parabola noise into the spectrum: those for which, at some
+    height that enters the spectrum (down to the ray's toomuch crossing, ref["last"]), the quanta
+    allowed there exceed the arithmetic's own 1e-9 of THAT height's optical depth.  (By the ray's
+    largest optical depth instead -- 1e4..1e6 at the bottom of an opaque ray -- a three-layer
+    atmosphere whose extinction jumps 1e7 between layers looked noise-free while its middle
+    height, the one the spectrum is made of, was 1e-6 off inside the allowance.)"""
     diff = np.abs(got["tau"] - ref["tau"])
-    allow = tau_allowance(problem, ref)
+    strict, quanta = tau_allowance(problem, ref, parts=True)
+    allow = strict + quanta
     bad = diff > allow
     if bad.any():
         w, ri = np.argwhere(bad)[0]
         raise AssertionError("tau differs by %.3e at wn %d height %d: allowed %.3e (%.3e strict + %.1f quanta); %s"
                              % (diff[w, ri], w, ri, allow[w, ri], STRICT * np.abs(ref["tau"][w]).max(), NQ, note))
-    strict_only = diff <= STRICT * np.abs(ref["tau"]).max(axis=1, keepdims=True)
-    return ~strict_only.all(axis=1)           # rays that needed the allowance
+    nh = ref["tau"].shape[1]
+    used = np.arange(nh)[None, :] <= np.asarray(ref["last"])[:, None] if "last" in ref else np.ones_like(bad)
+    return (used & (quanta > STRICT * np.abs(ref["tau"]))).any(axis=1)
 
 
 DEBUG_KEYS = ("e", "e_cs", "tau", "last", "intens", "computed", "e_scat", "e_cloud")
