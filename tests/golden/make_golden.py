@@ -107,6 +107,9 @@ CASES = {
                             extra={"raddelt": "400"}),
     "resample_transit": dict(nlines=2000, wnlow=2500, wnhigh=2530, nlayers=25, solution="transit", seed=72, ncia=2,
                              extra={"raddelt": "350", "radlow": "93500"}),
+    # 130 isotopes in 8 line databases (the reference allocates per isotope without a cap,
+    # readlineinfo.c:134-224; its own isotopologues.dat lists more than 100)
+    "many_isotopes": dict(dbs="iso130", wnlow=2500, wnhigh=2520, nlayers=12, solution="eclipse", seed=91),
     "midres_os4": dict(nlines=2500, wnlow=3100, wnhigh=3108, wndelt=0.02, wnosamp=4, nlayers=20,
                        solution="transit", seed=17, ncia=2),
 }
@@ -137,6 +140,8 @@ def main():
         kw = dict(kw)
         if kw.get("dbs") == "multi":
             kw["dbs"] = multi_species_dbs()
+        if kw.get("dbs") == "iso130":
+            kw["dbs"] = synth.many_isotope_dbs()
         if kw.get("dbs") == "multi2":      # two molecules, three isotopes, in the 2500-2540 band
             kw["dbs"] = [synth.synth_linedb(1500, 2500, 2540, seed=41),
                          synth.synth_linedb(900, 2500, 2540, seed=42, name="HITEMP CO (synthetic)", molname="CO",

@@ -991,37 +991,34 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   const int ntiles = (int)((nsh + kTileBins - 1) / kTileBins);
   double *d_SG = h->d_SG.as<double>();
   uint8_t *d_idop8 = h->d_idop8.as<uint8_t>();
-  // lines whose profiles can reach this shard in any layer of the step (contiguous per isotope block)
-  Segments GG{};
-  {
-    long long tot = 0;
-    for (int b = 0; b < niso; b++) {
-      const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
-      if (gb0 == gb1) continue;
-      int ga = gb0, gz = gb1;
-      if (h->windowed()) {
-        long long psm = 0;
-        for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
-        const long long lo_f = (long long)h->osamp * h->lo - psm;
-        long long klo = lo_f > 0 ? lo_f / h->osamp : 0;
-        long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp;
-        if (khi > h->nwn - 1) khi = h->nwn - 1;
-        const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
-        ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
-      }
-      if (ga >= gz) continue;
-      const long long la = h->h_gfirst[ga], lz = (long long)h->h_gfirst[gz - 1] + h->h_gcount[gz - 1];
-      GG.start[GG.n] = la; GG.base[GG.n] = tot; tot += lz - la; GG.n++;
+  // lines whose profiles can reach this shard in any layer of the step (contiguous per isotope block):
+  // their number here, for the launch; the runs themselves are found by the kernel (SweepWindow)
+  SweepWindow Wn{};
+  Wn.windowed = h->windowed() ? 1 : 0; Wn.osamp = h->osamp; Wn.lo = h->lo; Wn.hi = h->hi; Wn.nwn = h->nwn;
+  long long seg_lines = 0;
+  for (int b = 0; b < niso; b++) {
+    const int gb0 = h->h_gblock[b], gb1 = h->h_gblock[b + 1];
+    if (gb0 == gb1) continue;
+    int ga = gb0, gz = gb1;
+    if (h->windowed()) {
+      long long psm = 0;
+      for (int c = 0; c < nc; c++) psm = std::max<long long>(psm, psmax[(size_t)(r_top - c) * niso + b]);
+      const long long lo_f = (long long)h->osamp * h->lo - psm;
+      long long klo = lo_f > 0 ? lo_f / h->osamp : 0;
+      long long khi = ((long long)h->osamp * (h->hi - 1) + psm) / h->osamp;
+      if (khi > h->nwn - 1) khi = h->nwn - 1;
+      const int32_t *cg = &h->h_cntge[(size_t)b * (h->nwn + 1)];
+      ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
     }
-    GG.base[GG.n] = tot;
+    if (ga >= gz) continue;
+    seg_lines += ((long long)h->h_gfirst[gz - 1] + h->h_gcount[gz - 1]) - h->h_gfirst[ga];
   }
-  const long long seg_lines = GG.base[GG.n];
   constexpr unsigned kSpan = kXcds * kAccumXcdGroup;
   const unsigned tblocks = (unsigned)(((ntiles + 3) / 4 + kSpan - 1) / kSpan * kSpan);   // multiple of 8*G: xcd_grouped_x()
   if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
     hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
-                       h->L, Y, GG, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, h->d_e2tab.as<double>(), d_wcut,
+                       h->L, Y, Wn, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, h->d_e2tab.as<double>(), d_wcut,
                        d_SG, d_idop8, h->d_flags.as<int>(), (int)M.eager);
   }
   if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
@@ -1104,7 +1101,7 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
     const bool with_init = init && r0 == 0;
     RunInit R{}; R.nsh = -1;
     if (with_init) { R = *init; *init_done = true; }
-    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines)), ny + (with_init ? 1u : 0u)), dim3(64), 0, st,
+    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines)), ny + (with_init ? 1u : 0u)), dim3(64), sizeof(double) * (size_t)kLayerMaxGroup * (size_t)std::max(h->niso, 1), st,
                        h->L, Yr, h->niso, nr, pruned ? h->d_candrec.as<CandLine>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
                        (unsigned long long *)(kmax + (size_t)r0 * nmx), R, with_init ? (int)ny : -1);
   }

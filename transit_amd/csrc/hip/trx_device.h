@@ -9,7 +9,7 @@
 namespace trx {
 
 constexpr int kMaxChunk   = 32;    // layers swept per top-down step (upper bound)
-constexpr int kMaxIso     = 64;    // isotopes per run
+constexpr int kMaxIso     = 256;   // isotopes per run (per-isotope tables of a block live in LDS)
 constexpr int kMaxAngles  = 16;
 constexpr int kMaxDop     = 256;   // Doppler-width samples (ndop)
 constexpr int kTileBins   = 4;     // coarse bins per wavefront tile in the accumulate kernel
@@ -62,13 +62,13 @@ struct LayerDev {
   const int32_t *psmax;       // largest profile half-size the isotope can use in this layer
 };
 
-// Contiguous index ranges (one per isotope block) that a kernel walks as one
-// flat iteration space: item t belongs to segment s with base[s] <= t < base[s+1]
-// and maps to start[s] + (t - base[s]).
-struct Segments {
-  int n;
-  long long start[kMaxIso];
-  long long base[kMaxIso + 1];
+// What k_group_sweep needs to find, per isotope block, the lines whose profiles can reach the
+// shard in some layer of the step (one contiguous run per block: the TLI is wavelength-sorted):
+// every workgroup builds the table of those runs in LDS itself (up to kMaxIso blocks), from
+// psmax of the step's layers and cnt_ge -- a shard of the grid (windowed) or the whole grid.
+struct SweepWindow {
+  int windowed, osamp;
+  long long lo, hi, nwn;            // shard [lo, hi) of nwn coarse bins
 };
 
 }  // namespace trx

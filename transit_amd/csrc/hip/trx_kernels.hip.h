@@ -118,11 +118,14 @@ __device__ __forceinline__ bool sweep_active(const int *flags, int eager)
   return eager || flags[0] != 0;
 }
 
-__device__ __forceinline__ long long seg_index(const Segments &G, long long t)
+// item t of the flat iteration space over `n` contiguous runs: run s with base[s] <= t < base[s+1]
+// (runs may be empty), mapped to start[s] + (t - base[s]); -1 past the end
+__device__ __forceinline__ long long seg_index(const long long *start, const long long *base, int n, long long t)
 {
-  int s = 0;
-  while (s + 1 < G.n && t >= G.base[s + 1]) s++;
-  return (t < G.base[G.n]) ? G.start[s] + (t - G.base[s]) : -1;
+  if (t >= base[n]) return -1;
+  int a = 0, z = n - 1;              // last s with base[s] <= t
+  while (a < z) { const int m = (a + z + 1) >> 1; if (base[m] <= t) a = m; else z = m - 1; }
+  return start[a] + (t - base[a]);
 }
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
@@ -293,9 +296,9 @@ __device__ __forceinline__ double exp_neg(double x, const double *e2tab)
 
 constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are staged in LDS
 
-// G walks line ranges (contiguous per isotope block).
+// The lines of every isotope block that can reach the shard (SweepWindow): one flat iteration space.
 __global__ __launch_bounds__(256)
-void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int nc,
+void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, int nc,
                    const double *__restrict__ dthr, int ndop,   // steps of the Doppler index, [ndop + 1]
                    const double *__restrict__ e2tab,            // 2^(j/64), j = 0..63
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
@@ -308,6 +311,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
   __shared__ double s_ct[kMaxChunk];
   __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
   __shared__ double s_s[2][256];                         // line strengths of the layer in flight
+  __shared__ long long s_start[kMaxIso], s_base[kMaxIso + 1];
   for (int i = threadIdx.x; i <= ndop; i += 256) s_thr[i] = dthr[i];
   if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
   if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
@@ -316,8 +320,35 @@ void k_group_sweep(LinesDev L, LayerDev Y, Segments G, int niso, int r_top, int 
     const int c = i / nst, b = i - c * nst, ri = (r_top - c) * niso + b;
     s_f[c][b] = Y.strength_f[ri]; s_wc[c][b] = wcut[ri]; s_ad[c][b] = Y.alphad[ri];
   }
+  // the runs of lines: block b -> [la, lz) (the same arithmetic as the host's launch size, sweep_chunk)
+  for (int b = threadIdx.x; b < niso; b += 256) {
+    const int gb0 = L.gblock[b], gb1 = L.gblock[b + 1];
+    long long la = 0, lz = 0;
+    if (gb0 != gb1) {
+      int ga = gb0, gz = gb1;
+      if (Wn.windowed) {
+        long long psm = 0;
+        for (int c = 0; c < nc; c++) psm = max(psm, (long long)Y.psmax[(long long)(r_top - c) * niso + b]);
+        const long long lo_f = (long long)Wn.osamp * Wn.lo - psm;
+        const long long klo = lo_f > 0 ? lo_f / Wn.osamp : 0;
+        long long khi = ((long long)Wn.osamp * (Wn.hi - 1) + psm) / Wn.osamp;
+        if (khi > Wn.nwn - 1) khi = Wn.nwn - 1;
+        const int32_t *cg = L.cnt_ge + (long long)b * (Wn.nwn + 1);
+        ga = gb0 + cg[khi + 1]; gz = gb0 + cg[klo];
+      }
+      if (ga < gz) { la = L.gfirst[ga]; lz = (long long)L.gfirst[gz - 1] + L.gcount[gz - 1]; }
+    }
+    s_start[b] = la; s_base[b + 1] = lz - la;              // (lengths first; the running sum below)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long tot = 0;
+    for (int b = 0; b < niso; b++) { const long long len = s_base[b + 1]; s_base[b] = tot; tot += len; }
+    s_base[niso] = tot;
+  }
+  __syncthreads();
   const long long t0 = (long long)blockIdx.x * 256;
-  const long long ln = seg_index(G, t0 + threadIdx.x);
+  const long long ln = niso > 0 ? seg_index(s_start, s_base, niso, t0 + threadIdx.x) : -1;
   const bool ok = ln >= 0;
   int g = -1, cnt = 0, iso = 0;
   double wavn = 0, elow = 0, gf = 0;

@@ -189,7 +189,8 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__res
   const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
   // the wave's layer scalars in LDS, one round trip for all of them (read per layer from global
   // memory they were a dependent round trip per layer of this one-wave chain)
-  __shared__ double s_ct[kLayerMaxGroup], s_f[kLayerMaxGroup * kMaxIso];
+  __shared__ double s_ct[kLayerMaxGroup];
+  extern __shared__ double s_f[];                      // [kLayerMaxGroup][niso] (dynamic: the launch sizes it)
   for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64) s_f[t] = Y.strength_f[r0 * niso + t];
   if ((int)threadIdx.x < r1 - r0) s_ct[threadIdx.x] = Y.negc_over_t[r0 + threadIdx.x];
   __builtin_amdgcn_wave_barrier();

@@ -168,6 +168,24 @@ def synth_linedb(nlines: int, wn_lo: float, wn_hi: float, seed: int = 1234,
     return db
 
 
+def many_isotope_dbs(niso_total: int = 130, lines_per_iso: int = 40, wn_lo: float = 2500.0, wn_hi: float = 2520.0,
+                     seed: int = 900) -> List[LineDB]:
+    """Eight line databases (one per molecule of the demo atmosphere that can carry lines) with
+    `niso_total` isotopes between them: more than any fixed small table holds."""
+    mols = ["H2O", "CH4", "CO", "CO2", "H2", "H", "He", "C"]
+    masses = {m[1]: m[2] for m in MOLECULE_TABLE}
+    per = [niso_total // len(mols) + (1 if k < niso_total % len(mols) else 0) for k in range(len(mols))]
+    dbs = []
+    for k, (mol, n) in enumerate(zip(mols, per)):
+        ratios = np.array([0.5 ** (i + 1) for i in range(n)])
+        ratios[0] += 1.0 - ratios.sum()
+        dbs.append(synth_linedb(n * lines_per_iso, wn_lo, wn_hi, seed=seed + k, name="synthetic %s, %d isotopes" % (mol, n),
+                                molname=mol, iso_names=tuple("%d%02d" % (k + 1, i) for i in range(n)),
+                                iso_masses=tuple(masses[mol] + 0.37 * i for i in range(n)), iso_ratios=tuple(float(r) for r in ratios),
+                                iso_split=tuple([1.0 / n] * n), z_scale=100.0 + 60.0 * k, log_gf=(-9.0, -4.0)))
+    return dbs
+
+
 def write_tli(path: str, dbs: Sequence[LineDB], wl_ini: Optional[float] = None,
               wl_fin: Optional[float] = None) -> str:
     """TLI v6, little-endian, no padding; lines sorted by (cumulative) isotope
