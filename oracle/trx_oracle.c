@@ -885,6 +885,12 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
   const long nwn = s->nwn, nr = a->nlayer;
   const int niso = s->niso, nmol = s->nmol;
   if (nr < 1 || nwn < 2) return TRX_E_ARG;
+  /* a wavenumber shard [w0, w1) of the grid (trx_static.wn_lo / wn_hi, one rank of a sharded job):
+   * the extinction of a layer is computed on the whole grid as always, the rays -- and with them
+   * the lazy sweep's depth -- are the shard's own, and every output holds the shard's w1 - w0 bins */
+  const long w0 = (s->wn_hi > s->wn_lo) ? (long)s->wn_lo : 0, w1 = (s->wn_hi > s->wn_lo) ? (long)s->wn_hi : nwn;
+  if (w0 < 0 || w1 > nwn) return TRX_E_ARG;
+  const long nsh = w1 - w0;
   if (o->solution != TRX_SOL_ECLIPSE && o->solution != TRX_SOL_TRANSIT) return TRX_E_ARG;
   h->stats.neval = h->stats.nskip = h->stats.sum_bins = 0;
 
@@ -965,7 +971,7 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
     }
 
   long lastr = nr - 1;
-  for (long wi = 0; wi < nwn; wi++) {
+  for (long wi = w0; wi < w1; wi++) {
     double *tw = tau + (size_t)wi*nr;
     const double wcgs = (s->wn_i + (double)wi * s->wn_d) * o->wn_fct;
     scat_extinction(es, nr, h, a, o, wcgs);
@@ -994,9 +1000,9 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
     if (ri == nr) last[wi] = ri - 1;                       /* tau.c:299-304 */
     /* the reference's total / cloud / scattering dumps: the per-wavenumber arrays as they stand
      * after the height loop (save1Darray, tau.c:293-297) */
-    if (dbg && dbg->er)      for (long r = 0; r < nr; r++) dbg->er[(size_t)r*nwn + wi] = er[r];
-    if (dbg && dbg->e_scat)  for (long r = 0; r < nr; r++) dbg->e_scat[(size_t)r*nwn + wi] = es[r];
-    if (dbg && dbg->e_cloud) for (long r = 0; r < nr; r++) dbg->e_cloud[(size_t)r*nwn + wi] = ec[r];
+    if (dbg && dbg->er)      for (long r = 0; r < nr; r++) dbg->er[(size_t)r*nsh + (wi - w0)] = er[r];
+    if (dbg && dbg->e_scat)  for (long r = 0; r < nr; r++) dbg->e_scat[(size_t)r*nsh + (wi - w0)] = es[r];
+    if (dbg && dbg->e_cloud) for (long r = 0; r < nr; r++) dbg->e_cloud[(size_t)r*nsh + (wi - w0)] = ec[r];
   }
 #undef SWEEP
 
@@ -1006,20 +1012,20 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
     double *grid = calloc(an + 1, sizeof(double));          /* eclipse.c:262-269 */
     grid[0] = 0.0 * C_DEG; grid[an] = 90.0 * C_DEG;
     for (int i = 1; i < an; i++) grid[i] = (o->angles_deg[i-1] + o->angles_deg[i]) * C_DEG / 2.0;
-    for (long w = 0; w < nwn; w++) spectrum[w] = 0.0;
+    for (long w = 0; w < nsh; w++) spectrum[w] = 0.0;
     for (int i = 0; i < an; i++) {
       const double area = pow(sin(grid[i+1]), 2.0) - pow(sin(grid[i]), 2.0);
-      for (long w = 0; w < nwn; w++) {
+      for (long w = w0; w < w1; w++) {
         const double wv = s->wn_i + (double)w * s->wn_d;
         const double I = intensity(tau + (size_t)w*nr, wv * o->wn_fct, last[w],
                                    o->angles_deg[i], a->temp, nr);
-        if (dbg && dbg->intens) dbg->intens[(size_t)i*nwn + w] = I;
-        spectrum[w] += C_PI * I * area;                     /* eclipse.c:275-279 */
+        if (dbg && dbg->intens) dbg->intens[(size_t)i*nsh + (w - w0)] = I;
+        spectrum[w - w0] += C_PI * I * area;                     /* eclipse.c:275-279 */
       }
     }
     free(grid);
   } else {
-    for (long w = 0; w < nwn; w++) {
+    for (long w = w0; w < w1; w++) {
       double m;
       if (o->modlevel == -1)
         m = modulation_rad(tau + (size_t)w*nr, last[w], o->toomuch, hh, a->rad_fct, o->starrad_cm);
@@ -1027,7 +1033,7 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
         m = modulation_int(tau + (size_t)w*nr, last[w], o->toomuch, hh, nr, a->rad_fct,
                            o->starrad_cm, o->transparent);
       if (o->modlevel == -1 && m < 0) { rc = TRX_E_NOTREACHED; goto done; }
-      spectrum[w] = m;
+      spectrum[w - w0] = m;
     }
   }
 
@@ -1037,13 +1043,13 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
     h->stats.layers_swept = swept;
   }
   if (dbg) {
-    if (dbg->e)    memcpy(dbg->e, e, sizeof(double)*nwn*nr);
-    if (dbg->tau)  memcpy(dbg->tau, tau, sizeof(double)*nwn*nr);
-    if (dbg->last) for (long w = 0; w < nwn; w++) dbg->last[w] = last[w];
+    if (dbg->e)    for (long r = 0; r < nr; r++) memcpy(dbg->e + (size_t)r*nsh, e + (size_t)r*nwn + w0, sizeof(double)*nsh);
+    if (dbg->tau)  memcpy(dbg->tau, tau + (size_t)w0*nr, sizeof(double)*nsh*nr);
+    if (dbg->last) for (long w = w0; w < w1; w++) dbg->last[w - w0] = last[w];
     if (dbg->computed) memcpy(dbg->computed, comp, nr);
     if (dbg->e_cs)                                          /* transposed to [layer][wn] */
-      for (long w = 0; w < nwn; w++)
-        for (long r = 0; r < nr; r++) dbg->e_cs[(size_t)r*nwn + w] = ecs[(size_t)w*nr + r];
+      for (long w = w0; w < w1; w++)
+        for (long r = 0; r < nr; r++) dbg->e_cs[(size_t)r*nsh + (w - w0)] = ecs[(size_t)w*nr + r];
   }
 done:
   free(ecs); free(e); free(tau); free(last); free(comp); free(dens); free(zp);

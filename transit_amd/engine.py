@@ -57,7 +57,7 @@ class CEngine:
 
     @property
     def nwn(self) -> int:
-        return self.hi - self.lo if self._p == "trx_" else self.nwn_total
+        return self.hi - self.lo if self.hi > self.lo else self.nwn_total
 
     def run(self, atm: _abi.TrxAtm, opts: _abi.TrxOpts, debug=False,
             n_out: Optional[int] = None) -> Dict[str, np.ndarray]:
