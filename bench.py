@@ -470,6 +470,7 @@ def main():
         L, R, nang = stats["nlines_inrange"], stats["layers_swept"], int(opts.nangles)
         launches = max(int(stats["sweep_launches"]), 1)
         walked = int(stats["walk_steps"]) == launches
+        mixed = 0 < int(stats["walk_steps"]) < launches      # upper layers walked, deep ones in the two-kernel form
         line_k = "k_line_walk" if walked else "k_group_sweep"
         acc_k = "k_walk_combine" if walked else "k_accumulate"
         ev = stats["events"]
@@ -522,7 +523,9 @@ def main():
                            world, [h - l for l, h in M["bounds"]]) if world > 1 else "one GPU",
                        "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps (<= 64 layers where "
                                                           "the line walk applies, one lane per layer)",
-                       "steps_per_run": launches, "line_kernel": line_k,
+                       "steps_per_run": launches, "walk_steps_per_run": int(stats["walk_steps"]),
+                       "line_kernel": "k_line_walk (%d steps) + k_group_sweep (%d steps): ms_kernels sums both under the "
+                                      "second name" % (int(stats["walk_steps"]), launches - int(stats["walk_steps"])) if mixed else line_k,
                        "depth_hint": "step plan ends at the previous run's deepest layer (retrieval-loop reuse; "
                                      "warm-up runs provide it); a run that needs more goes on from there",
                        "ms_create_voigt_table_kernels": stats["ms_create_table"],

@@ -22,7 +22,9 @@ def test_replayed_runs_give_the_queued_path_s_bits(tmp_path, solution):
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
     dens = np.ctypeslib.as_array(P.atm.density, shape=(P.static.nmol * P.nlayer,))
     base = dens.copy()
-    scales = [1.0] * 5 + [0.02] * 4 + [30.0] * 4 + [1.0] * 3
+    # (the layer maxima of consecutive runs alternate between two buffers, and so do the graphs: a plan
+    # is captured when it comes by the second time on the same buffer, replayed from the third)
+    scales = [1.0] * 9 + [0.02] * 6 + [30.0] * 6 + [1.0] * 4
     msgs = []
     engine.set_log(lambda lvl, m: msgs.append(m), 5)
     os.environ["TRX_RUN_GRAPH"] = "1"
@@ -42,4 +44,4 @@ def test_replayed_runs_give_the_queued_path_s_bits(tmp_path, solution):
         g.close(); q.close()
     captured = sum("captured as a graph" in m for m in msgs)
     replayed = sum("graph " in m and "queueing by phase" in m for m in msgs)
-    assert captured >= 2 and replayed >= 4, (captured, replayed)
+    assert captured >= 4 and replayed >= 8, (captured, replayed)

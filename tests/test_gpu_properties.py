@@ -496,3 +496,29 @@ def test_large_shard_emission_kernel_against_oracle(tmp_path):
     assert np.array_equal(got["last"], ref["last"])
     assert rel_err(got["spectrum"], ref["spectrum"]) < 1e-9
     assert rel_err(got["intens"], ref["intens"]) < 1e-9
+
+
+@pytest.mark.parametrize("osamp,wndelt", [(1, 0.004), (2160, 1.0)])
+def test_threaded_create_gives_the_single_thread_groups(tmp_path, osamp, wndelt):
+    """trx_create groups the list on several host threads (pieces cut where the co-add chain
+    provably restarts); groups, co-add count and spectrum must be the single-threaded ones --
+    on a list dense enough to co-add (0.4 lines per fine cell) and on a sparse one."""
+    d = str(tmp_path / "thr")
+    synth.make_case(d, nlines=400_000, wnlow=2500, wnhigh=2500 + (4000 if osamp == 1 else 2000), wndelt=wndelt, wnosamp=osamp,
+                    nlayers=12, solution="eclipse", seed=9, nwidth=2.0)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    res = []
+    for nth in ("1", "7"):
+        os.environ["TRX_CREATE_THREADS"] = nth
+        try:
+            e = Engine(P.static)
+        finally:
+            os.environ.pop("TRX_CREATE_THREADS", None)
+        out = e.run(P.atm, P.opts)
+        st = e.stats()
+        e.close()
+        res.append((out["spectrum"], st["ngroups"], st["nadd"], st["nlines_inrange"]))
+    assert res[0][1:] == res[1][1:]
+    assert np.array_equal(res[0][0], res[1][0])
+    if osamp == 1:
+        assert res[0][2] > 10_000          # the dense list does co-add

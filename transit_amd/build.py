@@ -25,7 +25,7 @@ CXX = os.environ.get("CXX") or "g++"
 HIP_SOURCES = ["hip/trx_api.hip"]
 HIP_DEPS = ["hip/trx_kernels.hip.h", "hip/trx_walk.hip.h", "hip/trx_rows.hip.h", "hip/trx_device.h", "trx_numerics.h"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-             "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+             "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 def lib_path(name: str) -> str:

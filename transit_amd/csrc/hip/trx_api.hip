@@ -21,7 +21,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "transit_hip.h"
@@ -38,6 +40,22 @@ struct DevBuf {
   ~DevBuf() { release(); }
   void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
   template <class T> T *as() const { return (T *)p; }
+};
+
+// host array WITHOUT initialisation (a std::vector of 10^7 doubles spends 10 ms of one thread
+// zeroing what the next loop overwrites; these are written by several threads, first touch included)
+template <class T>
+struct HostBuf {
+  std::unique_ptr<T[]> p; size_t n = 0;
+  void alloc(size_t m) { p.reset(m ? new T[m] : nullptr); n = m; }
+  T *data() { return p.get(); }
+  const T *data() const { return p.get(); }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T *begin() { return p.get(); }
+  T *end() { return p.get() + n; }
 };
 
 // view into another allocation (same accessors as DevBuf, owns nothing)
@@ -82,7 +100,7 @@ struct trx_handle {
   DevBuf d_lgroup, d_wavn, d_elow, d_gf, d_iso, d_inr, d_gfirst, d_gcount, d_giown, d_giso, d_gwavn, d_gblock, d_cntge, d_cntsub;
   int sub_f = 1;                        // sub-buckets per coarse cell of d_cntsub (1: it is d_cntge)
   LinesDev L{};
-  std::vector<double> h_gwavn; std::vector<int32_t> h_gblock, h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
+  HostBuf<double> h_gwavn; std::vector<int32_t> h_gblock; HostBuf<int32_t> h_cntge, h_gfirst, h_gcount;   // host copies for the per-run prologue
   void *comm = nullptr; int nranks = 1, rank = 0;          // RCCL communicator: only trx_gather uses it
   bool windowed() const { return lo > 0 || hi < nwn; }    // a shard sweeps only the lines that can reach it
   // candidates for the layer maximum (k_cand_*): indices into the line arrays; -1 = use every line
@@ -202,6 +220,9 @@ int upload(trx_handle *h, DevBuf &b, const std::vector<T> &v)
   if (!v.empty()) HIPCHK(h, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
   return TRX_OK;
 }
+
+template <class T>
+int upload(trx_handle *h, DevBuf &b, const HostBuf<T> &v) { return upload_raw(h, b, v.data(), v.size()); }
 
 // pu/src/iomisc.c:1064-1083 (logspace)
 void logspace(double lo, double hi, int n, std::vector<double> &out)
@@ -405,99 +426,212 @@ int build_table(trx_handle *h, const trx_static *s)
 }
 
 // ---- line list preparation --------------------------------------------------
+// The host part of trx_create is linear in the list (10^7 lines: a quarter of a second on one
+// core, 110 ms of it the co-add grouping).  All of it runs on a few host threads:
+int create_threads()
+{
+  if (const char *e = std::getenv("TRX_CREATE_THREADS")) return std::max(1, std::atoi(e));
+  const unsigned hc = std::thread::hardware_concurrency();
+  return (int)std::min<unsigned>(std::max<unsigned>(hc, 1u), 16u);
+}
+
+// f(part, begin, end) over [0, n) cut into `parts` contiguous pieces, one thread each
+template <class F>
+void parallel_parts(int64_t n, int parts, F f)
+{
+  parts = (int)std::max<int64_t>(1, std::min<int64_t>(parts, n / 65536 + 1));     // (small lists: one thread)
+  if (parts == 1) { f(0, (int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < parts; t++) th.emplace_back([=]() { f(t, n * t / parts, n * (t + 1) / parts); });
+  for (auto &x : th) x.join();
+}
+
+// cnt[k] = number of the block's groups with key >= k, k = 0..nkey (keys descend along the block)
+template <class Key>
+void count_ge(const int32_t *giown, int g0, int g1, long long nkey, Key key, int32_t *cnt, int nth)
+{
+  parallel_parts(nkey + 1, nth, [&](int, int64_t k0, int64_t k1) {
+    // groups with key >= k1 - 1: found by bisection, then the pointer only moves forward as k falls
+    int a = g0, z = g1;
+    while (a < z) { const int m = (a + z) >> 1; if (key(giown[m]) >= k1 - 1) a = m + 1; else z = m; }
+    int p = a;
+    for (int64_t k = k1 - 1; k >= k0; k--) {
+      while (p < g1 && key(giown[p]) >= k) p++;
+      cnt[k] = p - g0;
+    }
+  });
+}
+
 int prepare_lines(trx_handle *h, const trx_static *s)
 {
   const int64_t n = s->nlines;
   StageTimer T;
+  const int nth = create_threads();
   const double wn0 = s->wn_i, odwn = s->wn_d / s->osamp;
   const double own_last = wn0 + (double)(s->nown - 1) * odwn;
   auto own = [&](long long k) { return wn0 + (double)k * odwn; };
   if (n > 2000000000LL) return fail(h, TRX_E_UNSUPPORTED, "more than 2^31 lines per handle");
-  std::vector<double> wavn((size_t)n);
-  std::vector<uint8_t> inr((size_t)n);
-  for (int64_t i = 0; i < n; i++) {
-    if (s->isoid[i] < 0 || s->isoid[i] >= s->niso) return fail(h, TRX_E_ARG, "isotope id out of range");
-    wavn[i] = 1.0 / (s->wl_um[i] * kTliWfct);
-    inr[i] = !(wavn[i] < wn0 || wavn[i] > own_last);             // extinction.c:410
-    h->ninrange += inr[i];
+  // the three arrays that go up as they are leave now, on a thread of their own, under the grouping
+  const double *elow = s->elow, *gf = s->gf;
+  int rc_raw = TRX_OK;
+  std::thread raw_up([&]() {
+    (void)hipSetDevice(h->device);
+    if ((rc_raw = upload_raw(h, h->d_elow, elow, (size_t)n)) || (rc_raw = upload_raw(h, h->d_gf, gf, (size_t)n)) ||
+        (rc_raw = upload_raw(h, h->d_iso, s->isoid, (size_t)n))) return;
+  });
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } raw_join{raw_up};
+  HostBuf<double> wavn; wavn.alloc((size_t)n);
+  HostBuf<uint8_t> inr; inr.alloc((size_t)n);
+  {
+    std::vector<int64_t> cnt((size_t)nth + 1, 0); std::vector<int> bad((size_t)nth + 1, 0);
+    parallel_parts(n, nth, [&](int t, int64_t i0, int64_t i1) {
+      int64_t c = 0;
+      for (int64_t i = i0; i < i1; i++) {
+        if (s->isoid[i] < 0 || s->isoid[i] >= s->niso) { bad[t] = 1; continue; }
+        wavn[i] = 1.0 / (s->wl_um[i] * kTliWfct);
+        inr[i] = !(wavn[i] < wn0 || wavn[i] > own_last);             // extinction.c:410
+        c += inr[i];
+      }
+      cnt[t] = c;
+    });
+    for (int t = 0; t <= nth; t++) { if (bad[t]) return fail(h, TRX_E_ARG, "isotope id out of range"); h->ninrange += cnt[t]; }
   }
   T.lap("wavn + range flags");
   // TLI order: isotope blocks in ascending id, wavelength ascending inside a
   // block (pylineread.py:369-383); the gather kernel relies on it.
-  for (int64_t i = 1; i < n; i++) {
-    if (s->isoid[i] < s->isoid[i-1]) return fail(h, TRX_E_ORDER, "isotope blocks are not in ascending order");
-    if (s->isoid[i] == s->isoid[i-1] && wavn[i] > wavn[i-1])
-      return fail(h, TRX_E_ORDER, "wavelengths are not ascending inside an isotope block");
+  {
+    std::vector<int> bad((size_t)nth + 1, 0);
+    parallel_parts(n, nth, [&](int t, int64_t i0, int64_t i1) {
+      for (int64_t i = std::max<int64_t>(i0, 1); i < i1; i++) {
+        if (s->isoid[i] < s->isoid[i-1]) bad[t] |= 1;
+        else if (s->isoid[i] == s->isoid[i-1] && wavn[i] > wavn[i-1]) bad[t] |= 2;
+      }
+    });
+    int any = 0;
+    for (int t = 0; t <= nth; t++) any |= bad[t];
+    if (any & 1) return fail(h, TRX_E_ORDER, "isotope blocks are not in ascending order");
+    if (any & 2) return fail(h, TRX_E_ORDER, "wavelengths are not ascending inside an isotope block");
   }
   T.lap("order check");
-  std::vector<int32_t> gfirst, gcount, giown; std::vector<int16_t> giso; std::vector<double> gwavn;
-  gfirst.reserve((size_t)h->ninrange); gcount.reserve((size_t)h->ninrange); giown.reserve((size_t)h->ninrange);
-  giso.reserve((size_t)h->ninrange); gwavn.reserve((size_t)h->ninrange);
+  // Co-added groups (extinction.c:445-462): a greedy chain -- a group's anchor decides which of the
+  // following lines join it, and the line after them is the next anchor -- so it is sequential by
+  // nature.  But a line that starts an isotope block, or lies more than 1.6 fine-grid steps below
+  // its predecessor, can belong to NO earlier group (an anchor's grid point is at most half a step
+  // from it): the chain restarts there whatever came before.  The list is cut at such lines and the
+  // pieces are grouped side by side, each with the reference's own loop; a piece without such a
+  // line nearby (a list much denser than the fine grid) is simply left to the piece before it.
+  HostBuf<int32_t> gfirst, gcount, giown; HostBuf<int16_t> giso; HostBuf<double> gwavn;
   h->iso_wmin.assign(s->niso, HUGE_VAL); h->iso_wmax.assign(s->niso, 0.0);
-  for (int64_t ln = 0; ln < n; ln++) {
-    if (!inr[ln]) continue;
-    const double w = wavn[ln]; const int iso = s->isoid[ln];
-    int iown = (int)((w - wn0) / odwn);                          // extinction.c:445-447
-    if (std::fabs(w - own(iown + 1)) < std::fabs(w - own(iown))) iown++;
-    const int64_t first = ln;
-    while (ln != n - 1 && s->isoid[ln + 1] == iso) {             // extinction.c:449-462
-      if (std::fabs(wavn[ln + 1] - own(iown)) < odwn) { h->nadd++; ln++; }
-      else break;
+  {
+    int parts = (int)std::max<int64_t>(1, std::min<int64_t>(nth, n / 65536 + 1));
+    std::vector<int64_t> cut;                       // piece p = lines [cut[p], cut[p+1])
+    cut.push_back(0);
+    for (int t = 1; t < parts; t++) {
+      const int64_t from = std::max<int64_t>(n * t / parts, cut.back() + 1), to = std::min<int64_t>(n, from + n / parts / 2);
+      for (int64_t l = from; l < to; l++)
+        if (s->isoid[l] != s->isoid[l-1] || wavn[l-1] - wavn[l] >= 1.6 * odwn) { cut.push_back(l); break; }
     }
-    gfirst.push_back((int32_t)first); gcount.push_back((int32_t)(ln - first + 1));
-    giown.push_back(iown); giso.push_back((int16_t)iso); gwavn.push_back(w);
-    h->iso_wmin[iso] = std::min(h->iso_wmin[iso], w); h->iso_wmax[iso] = std::max(h->iso_wmax[iso], w);
+    cut.push_back(n);
+    parts = (int)cut.size() - 1;
+    struct Piece { std::vector<int32_t> first, count, iown; std::vector<int16_t> iso; std::vector<double> wv; int64_t nadd = 0; std::vector<double> wmin, wmax; };
+    std::vector<Piece> P((size_t)parts);
+    auto work = [&](int p) {
+      Piece &Q = P[(size_t)p];
+      Q.wmin.assign(s->niso, HUGE_VAL); Q.wmax.assign(s->niso, 0.0);
+      const int64_t l0 = cut[(size_t)p], l1 = cut[(size_t)p + 1];
+      const size_t guess = (size_t)(l1 - l0) / 2 + 16;
+      Q.first.reserve(guess); Q.count.reserve(guess); Q.iown.reserve(guess); Q.iso.reserve(guess); Q.wv.reserve(guess);
+      for (int64_t ln = l0; ln < l1; ln++) {
+        if (!inr[ln]) continue;
+        const double w = wavn[ln]; const int iso = s->isoid[ln];
+        int iown = (int)((w - wn0) / odwn);                          // extinction.c:445-447
+        if (std::fabs(w - own(iown + 1)) < std::fabs(w - own(iown))) iown++;
+        const int64_t first = ln;
+        while (ln != n - 1 && s->isoid[ln + 1] == iso) {             // extinction.c:449-462
+          if (std::fabs(wavn[ln + 1] - own(iown)) < odwn) { Q.nadd++; ln++; }
+          else break;
+        }
+        Q.first.push_back((int32_t)first); Q.count.push_back((int32_t)(ln - first + 1));
+        Q.iown.push_back(iown); Q.iso.push_back((int16_t)iso); Q.wv.push_back(w);
+        Q.wmin[iso] = std::min(Q.wmin[iso], w); Q.wmax[iso] = std::max(Q.wmax[iso], w);
+      }
+    };
+    if (parts == 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int p = 0; p < parts; p++) th.emplace_back(work, p);
+      for (auto &x : th) x.join();
+    }
+    std::vector<size_t> at((size_t)parts + 1, 0);
+    for (int p = 0; p < parts; p++) at[(size_t)p + 1] = at[(size_t)p] + P[(size_t)p].first.size();
+    const size_t ng = at[(size_t)parts];
+    gfirst.alloc(ng); gcount.alloc(ng); giown.alloc(ng); giso.alloc(ng); gwavn.alloc(ng);
+    auto gather = [&](int p) {
+      const Piece &Q = P[(size_t)p]; const size_t o = at[(size_t)p], m = Q.first.size();
+      if (!m) return;
+      std::memcpy(&gfirst[o], Q.first.data(), 4 * m); std::memcpy(&gcount[o], Q.count.data(), 4 * m);
+      std::memcpy(&giown[o], Q.iown.data(), 4 * m); std::memcpy(&giso[o], Q.iso.data(), 2 * m); std::memcpy(&gwavn[o], Q.wv.data(), 8 * m);
+    };
+    if (parts == 1) gather(0);
+    else {
+      std::vector<std::thread> th;
+      for (int p = 0; p < parts; p++) th.emplace_back(gather, p);
+      for (auto &x : th) x.join();
+    }
+    for (int p = 0; p < parts; p++) {
+      h->nadd += P[(size_t)p].nadd;
+      for (int b = 0; b < s->niso; b++) {
+        h->iso_wmin[b] = std::min(h->iso_wmin[b], P[(size_t)p].wmin[b]); h->iso_wmax[b] = std::max(h->iso_wmax[b], P[(size_t)p].wmax[b]);
+      }
+    }
   }
   T.lap("grouping");
   h->nlines = n; h->ngroups = (int64_t)gfirst.size();
-  // isotope blocks and the coarse-bin index over them
+  // isotope blocks (groups are in line order: the first group of every isotope by bisection) and
+  // the coarse-bin index over them
   std::vector<int32_t> gblock(s->niso + 1, 0);
-  for (size_t g = 0; g < giso.size(); g++) gblock[giso[g] + 1]++;
-  for (int b = 0; b < s->niso; b++) gblock[b + 1] += gblock[b];
-  std::vector<int32_t> cntge((size_t)s->niso * (s->nwn + 1), 0);
-  for (size_t g = 0; g < giso.size(); g++) {
-    long long k = giown[g] / s->osamp;
-    if (k > s->nwn - 1) k = s->nwn - 1;
-    cntge[(size_t)giso[g] * (s->nwn + 1) + k]++;
+  for (int b = 0; b <= s->niso; b++) gblock[b] = (int32_t)(std::lower_bound(giso.data(), giso.data() + giso.size(), (int16_t)b) - giso.data());
+  {
+    std::vector<int> bad((size_t)nth + 1, 0);
+    parallel_parts((int64_t)giown.size(), nth, [&](int t, int64_t g0, int64_t g1) {
+      for (int64_t g = std::max<int64_t>(g0, 1); g < g1; g++) if (giso[g] == giso[g-1] && giown[g] > giown[g-1]) bad[t] = 1;
+    });
+    for (int t = 0; t <= nth; t++) if (bad[t]) return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
   }
-  for (int b = 0; b < s->niso; b++) {                             // suffix sums: groups with key >= k
-    int32_t *c = &cntge[(size_t)b * (s->nwn + 1)];
-    for (long long k = s->nwn - 1; k >= 0; k--) c[k] += c[k + 1];
+  HostBuf<int32_t> cntge; cntge.alloc((size_t)s->niso * (s->nwn + 1));
+  for (int b = 0; b < s->niso; b++) {
+    const long long osamp = s->osamp, kmaxc = s->nwn - 1;
+    count_ge(giown.data(), gblock[b], gblock[b + 1], s->nwn, [=](int32_t io) { return std::min<long long>(io / osamp, kmaxc); },
+             &cntge[(size_t)b * (s->nwn + 1)], nth);
   }
-  for (size_t g = 1; g < giown.size(); g++)
-    if (giso[g] == giso[g-1] && giown[g] > giown[g-1])
-      return fail(h, TRX_E_ORDER, "fine-grid indices are not descending inside an isotope block");
   T.lap("cnt_ge");
   // the same counts at F sub-buckets per coarse cell (key iown*F/osamp): k_accumulate sizes its
   // windows with them, so that it does not stream whole cells of groups that lie between the
   // reach of two bins.  F = 1 (the table above) when the fine grid is no finer or the table
   // would be large.
-  std::vector<int32_t> cntsub;
+  HostBuf<int32_t> cntsub;
   {
     int F = (int)std::min<long long>(16, s->osamp);
     while (F > 1 && (size_t)s->niso * (size_t)F * (size_t)s->nwn * 4 > ((size_t)64 << 20)) F /= 2;
     h->sub_f = F;
     if (F > 1) {
       const size_t stride = (size_t)F * s->nwn + 1;
-      cntsub.assign((size_t)s->niso * stride, 0);
-      for (size_t g = 0; g < giso.size(); g++) {
-        long long k = (long long)giown[g] * F / s->osamp;
-        if (k > (long long)stride - 2) k = (long long)stride - 2;
-        cntsub[(size_t)giso[g] * stride + k]++;
-      }
+      cntsub.alloc((size_t)s->niso * stride);
       for (int b = 0; b < s->niso; b++) {
-        int32_t *c = &cntsub[(size_t)b * stride];
-        for (long long k = (long long)stride - 2; k >= 0; k--) c[k] += c[k + 1];
+        const long long osamp = s->osamp, kmaxs = (long long)stride - 2, FF = F;
+        count_ge(giown.data(), gblock[b], gblock[b + 1], (long long)stride - 1,
+                 [=](int32_t io) { return std::min<long long>((long long)io * FF / osamp, kmaxs); }, &cntsub[(size_t)b * stride], nth);
       }
     }
   }
 
-  std::vector<int32_t> lgroup((size_t)n, -1);
-  for (size_t g = 0; g < gfirst.size(); g++) lgroup[(size_t)gfirst[g]] = (int32_t)g;
-  std::vector<int32_t> gimod(giown.size()), gidiv(giown.size());
-  for (size_t g = 0; g < giown.size(); g++) { gimod[g] = giown[g] % s->osamp; gidiv[g] = giown[g] / s->osamp; }
+  HostBuf<int32_t> lgroup; lgroup.alloc((size_t)n);
+  parallel_parts(n, nth, [&](int, int64_t i0, int64_t i1) { std::fill(lgroup.begin() + i0, lgroup.begin() + i1, -1); });
+  HostBuf<int32_t> gimod, gidiv; gimod.alloc(giown.size()); gidiv.alloc(giown.size());
+  parallel_parts((int64_t)giown.size(), nth, [&](int, int64_t g0, int64_t g1) {
+    for (int64_t g = g0; g < g1; g++) { lgroup[(size_t)gfirst[g]] = (int32_t)g; gimod[g] = giown[g] % s->osamp; gidiv[g] = giown[g] / s->osamp; }
+  });
   T.lap("cnt_sub, lgroup, gimod");
-  const double *elow = s->elow, *gf = s->gf;
   int rc;
   // ---- the walk's view of the list (k_line_walk): one 32-byte record per line, and line
   // ranges of ngw consecutive groups per isotope block
@@ -517,15 +651,16 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     h->nwaves = h->h_wbase[s->niso];
     if ((rc = upload(h, h->d_wbase, h->h_wbase))) return rc;
   }
-  if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload_raw(h, h->d_elow, elow, (size_t)n)) || (rc = upload_raw(h, h->d_gf, gf, (size_t)n)) ||
-      (rc = upload_raw(h, h->d_iso, s->isoid, (size_t)n)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
+  raw_up.join();
+  if (rc_raw) return rc_raw;
+  if ((rc = upload(h, h->d_wavn, wavn)) || (rc = upload(h, h->d_inr, inr)) || (rc = upload(h, h->d_lgroup, lgroup)) || (rc = upload(h, h->d_gfirst, gfirst)) ||
       (rc = upload(h, h->d_gcount, gcount)) || (rc = upload(h, h->d_giown, giown)) || (rc = upload(h, h->d_giso, giso)) ||
       (rc = upload(h, h->d_gwavn, gwavn)) || (rc = upload(h, h->d_gimod, gimod)) || (rc = upload(h, h->d_gidiv, gidiv)) || (rc = upload(h, h->d_gblock, gblock)) || (rc = upload(h, h->d_cntge, cntge)) ||
       (rc = upload(h, h->d_cntsub, cntsub)))
     return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));    // host vectors die at return
-  T.lap("17 uploads + sync");
-  h->h_gwavn = gwavn; h->h_gblock = gblock; h->h_cntge = cntge; h->h_gfirst = gfirst; h->h_gcount = gcount;
+  T.lap("uploads + sync");
+  h->h_gwavn = std::move(gwavn); h->h_gblock = gblock; h->h_cntge = std::move(cntge); h->h_gfirst = std::move(gfirst); h->h_gcount = std::move(gcount);
   T.lap("host copies");
   LinesDev &L = h->L;
   L.nlines = n; L.wavn = h->d_wavn.as<double>(); L.elow = h->d_elow.as<double>(); L.gf = h->d_gf.as<double>();
@@ -546,7 +681,15 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   h->ncand = -1;
   if (h->ninrange > 4096 && s->niso > 0) {
     double emin = HUGE_VAL, emax = -HUGE_VAL;
-    for (int64_t i = 0; i < n; i++) if (inr[i]) { emin = std::min(emin, elow[i]); emax = std::max(emax, elow[i]); }
+    {
+      std::vector<double> lo((size_t)nth + 1, HUGE_VAL), hi((size_t)nth + 1, -HUGE_VAL);
+      parallel_parts(n, nth, [&](int t, int64_t i0, int64_t i1) {
+        double a = HUGE_VAL, b = -HUGE_VAL;
+        for (int64_t i = i0; i < i1; i++) if (inr[i]) { a = std::min(a, elow[i]); b = std::max(b, elow[i]); }
+        lo[t] = a; hi[t] = b;
+      });
+      for (int t = 0; t <= nth; t++) { emin = std::min(emin, lo[t]); emax = std::max(emax, hi[t]); }
+    }
     CandGeom Gm{};
     Gm.e_min = emin; Gm.e_scale = emax > emin ? kCandGrid / (emax - emin) : 0.0;
     Gm.w_min = wn0;  Gm.w_scale = own_last > wn0 ? kCandGrid / (own_last - wn0) : 0.0;
@@ -1028,7 +1171,7 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   const unsigned tblocks = (unsigned)(((ntiles + 3) / 4 + kSpan - 1) / kSpan * kSpan);   // multiple of 8*G: xcd_grouped_x()
   if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
-    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), sizeof(long long) * (2 * (size_t)niso + 1), st,
                        h->L, Y, Wn, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, h->d_e2tab.as<double>(), d_wcut,
                        d_SG, d_idop8, h->d_flags.as<int>(), (int)M.eager);
   }

@@ -66,6 +66,7 @@ struct LayerDev {
 // shard in some layer of the step (one contiguous run per block: the TLI is wavelength-sorted):
 // every workgroup builds the table of those runs in LDS itself (up to kMaxIso blocks), from
 // psmax of the step's layers and cnt_ge -- a shard of the grid (windowed) or the whole grid.
+// (The runs as a kernel argument for lists of few isotopes were measured: no difference.)
 struct SweepWindow {
   int windowed, osamp;
   long long lo, hi, nwn;            // shard [lo, hi) of nwn coarse bins

@@ -311,7 +311,8 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
   __shared__ double s_ct[kMaxChunk];
   __shared__ double s_f[kMaxChunk][kSweepIsoLds], s_wc[kMaxChunk][kSweepIsoLds], s_ad[kMaxChunk][kSweepIsoLds];
   __shared__ double s_s[2][256];                         // line strengths of the layer in flight
-  __shared__ long long s_start[kMaxIso], s_base[kMaxIso + 1];
+  extern __shared__ long long s_runs[];                  // [niso] first line, [niso + 1] running count (dynamic: 16 niso + 8 bytes)
+  long long *s_start = s_runs, *s_base = s_runs + niso;
   for (int i = threadIdx.x; i <= ndop; i += 256) s_thr[i] = dthr[i];
   if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
   if (threadIdx.x < nc) s_ct[threadIdx.x] = Y.negc_over_t[r_top - threadIdx.x];
@@ -321,6 +322,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
     s_f[c][b] = Y.strength_f[ri]; s_wc[c][b] = wcut[ri]; s_ad[c][b] = Y.alphad[ri];
   }
   // the runs of lines: block b -> [la, lz) (the same arithmetic as the host's launch size, sweep_chunk)
+  const long long t0 = (long long)blockIdx.x * 256;
   for (int b = threadIdx.x; b < niso; b += 256) {
     const int gb0 = L.gblock[b], gb1 = L.gblock[b + 1];
     long long la = 0, lz = 0;
@@ -347,7 +349,6 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
     s_base[niso] = tot;
   }
   __syncthreads();
-  const long long t0 = (long long)blockIdx.x * 256;
   const long long ln = niso > 0 ? seg_index(s_start, s_base, niso, t0 + threadIdx.x) : -1;
   const bool ok = ln >= 0;
   int g = -1, cnt = 0, iso = 0;
