@@ -230,6 +230,9 @@ typedef struct trx_handle trx_handle;
 
 int  trx_abi_version(void);
 int  trx_device_count(void);
+/* HIP version the library was built with / of the runtime it runs on (HIP_VERSION encoding:
+ * major*10000000 + minor*100000 + patch); a caller that maps a runtime of its own first can check. */
+int  trx_hip_versions(int *built, int *running);
 
 int  trx_create (const trx_static *st, trx_handle **out);
 int  trx_run    (trx_handle *h, const trx_atm *atm, const trx_opts *opts,

@@ -1323,6 +1323,17 @@ void trx_comm_abort(void *comm)
 
 int trx_abi_version(void) { return TRX_ABI_VERSION; }
 
+// HIP version the library was built with and the one of the runtime it is running on (a process
+// may have mapped another copy of libamdhip64.so first, e.g. the one a PyTorch wheel bundles)
+int trx_hip_versions(int *built, int *running)
+{
+  if (built) *built = HIP_VERSION;
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) != hipSuccess) return TRX_E_HIP;
+  if (running) *running = v;
+  return TRX_OK;
+}
+
 int trx_device_count(void)
 {
   int n = 0;

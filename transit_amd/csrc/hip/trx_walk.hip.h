@@ -689,7 +689,10 @@ void k_walk_combine(CombineArgs C)
     if (!open) return;
   }
   const long long j = j0 + wv;                       // this wave's bin
-  const bool have = wv < nbins;
+  // (a bin whose ray has stopped: the walk may have skipped the whole range that would have written
+  // its records -- nothing reads such a bin again, and it gets a zero rather than whatever the record
+  // buffer held two steps ago)
+  const bool have = wv < nbins && !(C.last && C.last[j - C.lo] >= 0);
   int cur_mx = -1;
   double sum = 0.0;
   auto store = [&](int mx) {                         // all waves of the block arrive here together

@@ -135,6 +135,7 @@ class CEngine:
 
 
 _hip = None
+HIP_VERSIONS = None
 
 
 def _one_hip_runtime():
@@ -149,8 +150,8 @@ def _one_hip_runtime():
     # three busy queues per handle: see INTEGRATION.md section 4 (only effective while the HIP
     # runtime has not initialised yet; multi-GPU launchers should export it themselves)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    if "torch" in sys.modules:
-        return                                   # torch's runtime is mapped already
+    if "torch" in sys.modules or os.environ.get("TRANSIT_AMD_OWN_HIP_RUNTIME"):
+        return                                   # torch's runtime is mapped already / the caller wants /opt/rocm's
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
@@ -180,6 +181,16 @@ def hip_library():
         lib.trx_abi_version.restype = C.c_int
         if lib.trx_abi_version() != _abi.ABI_VERSION:
             raise RuntimeError("libtransit_hip.so ABI %d != binding %d" % (lib.trx_abi_version(), _abi.ABI_VERSION))
+        # the runtime in this process may be the copy a PyTorch wheel bundles, not the toolchain's the
+        # library was compiled against: a different MAJOR version is refused, a different minor one told
+        built, running = C.c_int(0), C.c_int(0)
+        lib.trx_hip_versions.argtypes, lib.trx_hip_versions.restype = [C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int
+        if lib.trx_hip_versions(C.byref(built), C.byref(running)) == 0 and built.value and running.value:
+            if built.value // 10000000 != running.value // 10000000:
+                raise RuntimeError("libtransit_hip.so was built with HIP %d but runs on runtime %d (set "
+                                   "TRANSIT_AMD_OWN_HIP_RUNTIME=1 to keep torch's bundled runtime out)" % (built.value, running.value))
+            global HIP_VERSIONS                  # (built, running): 7.2 against the 7.0 of torch's wheel on this image -- same major
+            HIP_VERSIONS = (built.value, running.value)
         _hip = lib
     return _hip
 
