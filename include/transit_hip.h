@@ -229,6 +229,12 @@ typedef struct {
 typedef struct trx_handle trx_handle;
 
 int  trx_abi_version(void);
+/* Extinction of layers computed by an earlier run (the reference's --saveext file: restfile_extinct,
+ * extinction.c:97-137, called at the head of tau(), tau.c:155-156).  The following trx_run calls take
+ * e[layer][.] of every flagged layer from here instead of sweeping it (a step whose layers are all
+ * flagged launches no line kernel); flags and values stay until replaced (nlayer = 0: forget them).
+ * e: [nlayer][nwn_shard] host memory, this handle's shard; computed: [nlayer]. */
+int  trx_restore_extinction(trx_handle *h, int32_t nlayer, const double *e, const uint8_t *computed);
 int  trx_device_count(void);
 /* HIP version the library was built with / of the runtime it runs on (HIP_VERSION encoding:
  * major*10000000 + minor*100000 + patch); a caller that maps a runtime of its own first can check. */

@@ -100,6 +100,11 @@ int  trh_write_detail(const trh_problem *p, int which, const double *arr);
 /* outsample (makesample.c:744-770): the samplings file; the reference writes it only together
  * with `savefiles yes` (makesample.c:598-599).  path NULL = the outsample option. */
 int  trh_write_sample(const trh_problem *p, const char *path);
+/* --saveext FILE (savefile_extinct / restfile_extinct, extinction.c:62-137; tau.c:155-156, 340-341):
+ * e [nlayer][nwn] and one flag per layer.  read: TRX_OK, or 1 when there is no valid file (a note goes
+ * to trh_messages, as the reference warns and continues); hand the arrays to trx_restore_extinction. */
+int  trh_saveext_read(trh_problem *p, double *e, uint8_t *computed);
+int  trh_saveext_write(const trh_problem *p, const double *e, const uint8_t *computed);
 const char *trh_option(const trh_problem *p, const char *name);  /* accepted value of an option */
 
 #ifdef __cplusplus

@@ -28,13 +28,17 @@ KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "ci
         "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "intens.dat",
         # cases that ask for them: samplings file, detailout files, the three per-wavenumber dumps
         "sample.dat", "detail_ext.dat", "detail_tau.dat", "detail_cia.dat",
-        "total_extion.dat", "cloud_extion.dat", "scatt_extion.dat"]
+        "total_extion.dat", "cloud_extion.dat", "scatt_extion.dat", "ext.sav"]
 DUMPS3 = ("total_extion.dat", "cloud_extion.dat", "scatt_extion.dat")
 
 CASES = {
     # demo-shaped emission run, narrow band
     "eclipse_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="eclipse",
                           extra={"outintens": "intens.dat"}),      # + the per-angle intensity file (printintens)
+    # --saveext: the reference's extinction save file (savefile_extinct, extinction.c:62-95) of a small
+    # transmission run -- its lazy sweep reaches only the layers its rays need
+    "saveext_transit": dict(nlines=1500, wnlow=2500, wnhigh=2530, nlayers=20, solution="transit", seed=808,
+                            extra={"saveext": "ext.sav"}),
     # transmission geometry, two CIA tables
     "transit_small": dict(nlines=3000, wnlow=2500, wnhigh=2560, nlayers=30, solution="transit", ncia=2,
                           seed=4321),

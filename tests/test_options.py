@@ -126,7 +126,7 @@ PROBES = {
     "detailext": (["--detailext", "de2.dat:2505"], changed("plan")),
     "detailcia": (["--detailcia", "dc2.dat:2505"], changed("plan")),
     "csfile": (["--csfile", "cia2.dat"], changed("st.cia0")),
-    "saveext": (["--saveext", "ext.sav"], fails(-6)),
+    "saveext": (["--saveext", "ext.sav"], changed("plan")),
     "opacityfile": (["--opacityfile", "opa.dat", "--tlow", "1100", "--thigh", "1900", "--tempdelt", "200"],
                     changed("plan", "grid")),
     "tlow": (["--tlow", "600"], changed("grid")),
@@ -324,6 +324,6 @@ def test_cli_help_and_version_exit_cleanly():
     assert p.returncode == 0 and "--qscale" in p.stdout and "--raygrid" in p.stdout
     p = subprocess.run([exe, "-V"], capture_output=True, text=True)
     assert p.returncode == 0 and "transit_hip" in p.stdout
-    p = subprocess.run([exe, "-c", os.path.join(GOLDEN, CASE, "case.cfg"), "--saveext", "x"], capture_output=True,
+    p = subprocess.run([exe, "-c", os.path.join(GOLDEN, CASE, "case.cfg"), "--taulevel", "2"], capture_output=True,
                        text=True, cwd=os.path.join(GOLDEN, CASE))
-    assert p.returncode != 0 and "saveext" in p.stderr
+    assert p.returncode != 0 and "taulevel" in p.stderr

@@ -140,6 +140,7 @@ struct trx_handle {
   // through the pinned input block, whose address the graph holds.
   struct RunGraph { uint64_t sig = 0; hipGraphExec_t exec = nullptr; int r_top = 0, nchunks = 0, nwalks = 0; int64_t walk_steps = 0, walk_records = 0, walk_record_lanes = 0; uint64_t used = 0; };
   std::vector<RunGraph> graphs; uint64_t last_sig[2] = {0, 0}, graph_clock = 0; bool graph_off = false;   // (last_sig: per half of the alternating layer maxima)
+  DevBuf d_e_saved; std::vector<uint8_t> saved;          // trx_restore_extinction: [nlayer][nsh] and the flags (empty: none)
   void *h_spec = nullptr; size_t h_spec_bytes = 0;     // pinned staging of the spectrum (trx_run hands over pageable memory)
 };
 
@@ -1321,6 +1322,19 @@ void trx_comm_abort(void *comm)
 }
 
 
+int trx_restore_extinction(trx_handle *h, int32_t nlayer, const double *e, const uint8_t *computed)
+{
+  if (!h || nlayer < 0 || (nlayer > 0 && (!e || !computed))) return TRX_E_ARG;
+  h->saved.clear();
+  if (nlayer == 0) return TRX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->d_e_saved, sizeof(double) * (size_t)nlayer * (size_t)h->nsh);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(h->d_e_saved.p, e, sizeof(double) * (size_t)nlayer * (size_t)h->nsh, hipMemcpyHostToDevice));
+  h->saved.assign(computed, computed + nlayer);
+  return TRX_OK;
+}
+
 int trx_abi_version(void) { return TRX_ABI_VERSION; }
 
 // HIP version the library was built with and the one of the runtime it is running on (a process
@@ -1614,6 +1628,8 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const int nr = a->nlayer, nmol = h->nmol;
   const int64_t nsh = h->nsh;
   if (nr < 3) return fail(h, TRX_E_ARG, "at least three layers are needed");
+  if (!h->saved.empty() && (int)h->saved.size() != nr) return fail(h, TRX_E_ARG, "restored extinction has another number of layers");
+  if (!h->saved.empty() && h->has_grid) return fail(h, TRX_E_UNSUPPORTED, "restored extinction together with an opacity grid");
   if (o->solution != TRX_SOL_ECLIPSE && o->solution != TRX_SOL_TRANSIT) return fail(h, TRX_E_ARG, "unknown solution");
   if (o->solution == TRX_SOL_ECLIPSE && (o->nangles < 1 || o->nangles > kMaxAngles || !o->angles_deg))
     return fail(h, TRX_E_ARG, "eclipse needs 1..16 angles");
@@ -1745,7 +1761,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   uint64_t sig = 0xcbf29ce484222325ull;
   {
     const bool kmax_reset = h->d_kmax.bytes < sizeof(double) * 2 * (size_t)nr || !h->kmax_clean || h->kmax_nr != nr;
-    const bool ok = allow_graph && pipelined && stop_at_hint_ok && !prof && !dbg && !eager && h->ngroups > 0 && !kmax_reset;
+    const bool ok = allow_graph && pipelined && stop_at_hint_ok && !prof && !dbg && !eager && h->ngroups > 0 && !kmax_reset && h->saved.empty();
     if (ok) {
       SIG_ADD(nr); sig = fnv1a(sig, psmax, sizeof(int32_t) * nli);
       SIG_ADD(h->kmax_parity); SIG_ADD(h->hint_layers); SIG_ADD(h->walk_temp_ok); SIG_ADD(in_bytes);
@@ -1981,6 +1997,13 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     }
     if (S.st_tau == st) { if ((rc = join_early())) return rc; }       // the optical depths of the earlier steps
     else early_dirty = true;
+    if (!h->saved.empty())        // layers restored from an earlier run (trx_restore_extinction): their rows as they were saved
+      for (int c = 0; c < S.nc; c++) {
+        const int r = S.r_top - c;
+        if (h->saved[(size_t)r])
+          HIPCHK(h, hipMemcpyAsync(h->d_e.as<double>() + (size_t)r * nsh, h->d_e_saved.as<double>() + (size_t)r * nsh, sizeof(double) * (size_t)nsh,
+                                   hipMemcpyDeviceToDevice, S.st_tau));
+      }
     if (prof && spans.begin(Spans::kTau, S.st_tau)) return fail(h, TRX_E_HIP, "event");
     for (int done = 0; done < S.nc; ) {          // optical depth in sub-steps of at most tau_cap layers
       int nt = std::min(tau_cap, S.nc - done);
@@ -2091,7 +2114,9 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
       M.d_e = h->d_e.as<double>(); M.d_kmax = kmax_run; M.d_sticky = h->d_sticky.as<int>();
       M.st = st_sweep;
-      if (h->ngroups > 0) {
+      bool all_saved = !h->saved.empty();
+      for (int c = 0; c < nc && all_saved; c++) all_saved = h->saved[(size_t)(r_top - c)] != 0;
+      if (h->ngroups > 0 && !all_saved) {
         if (nb) {
           rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, st_tau != st ? st_tau : nullptr, h->ev_ac[nchunks],
                           nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()], &S.pc);

@@ -76,7 +76,7 @@ const OptDef kOptions[] = {
   {"detailext", 0, true, nullptr, 'a', "file:wn,... extinction at the given wavenumbers"},
   {"detailcia", 0, true, nullptr, 'a', "file:wn,... CIA extinction at the given wavenumbers"},
   {"csfile", 0, true, nullptr, 'a', "cross-section files"},
-  {"saveext", 0, true, nullptr, 'x', "not supported (the extinction is recomputed on the device in milliseconds)"},
+  {"saveext", 0, true, nullptr, 'a', "extinction save/restore file (extinction.c:62-137)"},
   {"opacityfile", 0, true, nullptr, 'a', "opacity-grid file"}, {"tlow", 0, true, "500", 'a', "grid: lowest temperature"},
   {"thigh", 0, true, "3000", 'a', "grid: highest temperature"},
   {"tempdelt", 0, true, "100.0", 'a', "grid: temperature spacing"}, {"justOpacity", 0, false, nullptr, 'a', "stop after the grid"},
@@ -1104,6 +1104,45 @@ int trh_write_spectrum(const trh_problem *p, const double *sp, const char *path)
   return TRX_OK;
 }
 
+// --saveext FILE (tau.c:155-156, 340-341; extinction.c:62-137): the molecular extinction of the layers a
+// run computed, kept "for a possible next run" -- magic "@E@S@", e[nlayer][nwn] doubles, one flag per
+// layer (a short: the reference defines _Bool as short, transit.h:129).  Read: TRX_OK and the arrays filled, or 1 with a note in trh_messages when there is no
+// (valid) file, as the reference warns and goes on.
+int trh_saveext_read(trh_problem *p, double *e, uint8_t *computed)
+{
+  if (!p || !e || !computed) return TRX_E_ARG;
+  if (!has(*p, "saveext")) return 1;
+  const std::string f = join_path(p->base_dir, str(*p, "saveext"));
+  const size_t nr = (size_t)p->atm.nlayer, ne = nr * (size_t)p->nwn;
+  FILE *in = std::fopen(f.c_str(), "rb");
+  if (!in) { p->messages += "W: extinction savefile '" + f + "' cannot be opened for reading: continuing without restoring\n"; return 1; }
+  char mn[5];
+  bool ok = std::fread(mn, 1, 5, in) == 5 && std::memcmp(mn, "@E@S@", 5) == 0;
+  std::vector<int16_t> c16(nr);                              // (transit.h:129: "#define _Bool short" -- the flags are shorts)
+  if (ok) ok = std::fread(e, sizeof(double), ne, in) == ne && std::fread(c16.data(), sizeof(int16_t), nr, in) == nr;
+  if (ok) ok = std::fgetc(in) == EOF;                        // (a file of another grid is longer or shorter)
+  std::fclose(in);
+  for (size_t i = 0; ok && i < nr; i++) computed[i] = c16[i] != 0;
+  if (!ok) { p->messages += "W: '" + f + "' is not a valid extinction savefile for this grid: not restored\n"; return 1; }
+  return TRX_OK;
+}
+
+int trh_saveext_write(const trh_problem *p, const double *e, const uint8_t *computed)
+{
+  if (!p || !e || !computed) return TRX_E_ARG;
+  if (!has(*p, "saveext")) return TRX_OK;
+  const std::string f = join_path(p->base_dir, str(*p, "saveext"));
+  const size_t nr = (size_t)p->atm.nlayer, ne = nr * (size_t)p->nwn;
+  FILE *out = std::fopen(f.c_str(), "wb");
+  if (!out) return TRX_E_ARG;
+  std::vector<int16_t> c16(nr);
+  for (size_t i = 0; i < nr; i++) c16[i] = computed[i] ? 1 : 0;
+  const bool ok = std::fwrite("@E@S@", 1, 5, out) == 5 && std::fwrite(e, sizeof(double), ne, out) == ne &&
+                  std::fwrite(c16.data(), sizeof(int16_t), nr, out) == nr;
+  std::fclose(out);
+  return ok ? TRX_OK : TRX_E_ARG;
+}
+
 int trh_write_toomuch(const trh_problem *p, const double *tau, const int64_t *last, const char *path)
 {
   if (!p || !tau || !last) return TRX_E_ARG;
@@ -1250,6 +1289,7 @@ const char *trh_output_plan(trh_problem *p)
   if (!p->det_ext.wn.empty()) add("detailext", p->det_ext.file + " " + std::to_string(p->det_ext.wn.size()));
   if (!p->det_cia.wn.empty()) add("detailcia", p->det_cia.file + " " + std::to_string(p->det_cia.wn.size()));
   if (has(*p, "opacityfile")) add("opacity", str(*p, "opacityfile"));
+  if (has(*p, "saveext")) add("saveext", str(*p, "saveext"));
   return o.c_str();
 }
 

@@ -36,7 +36,7 @@ struct Rank {
   trx_static st{};                   // this rank's copy: shard, device, communicator
   trx_handle *h = nullptr;
   int rc = TRX_OK; std::string err;
-  std::vector<double> slice, tau, e, ecs, intens, er, es, ec; std::vector<int64_t> last;
+  std::vector<double> slice, tau, e, ecs, intens, er, es, ec; std::vector<int64_t> last; std::vector<uint8_t> comp;
   trx_stats stats{};
 };
 
@@ -105,7 +105,16 @@ int main(int argc, char **argv)
   const bool want_dumps = sf && std::strncmp(sf, "yes", 3) == 0;                // argum.c:461-470
   const bool det_tau = trh_wants_detail(P, 0), det_ext = trh_wants_detail(P, 1), det_cia = trh_wants_detail(P, 2);
   const bool want_intens = trh_option(P, "outintens") != nullptr && trh_opts(P)->solution == TRX_SOL_ECLIPSE;
-  const bool need_tau = want_toomuch || want_dumps || det_tau || det_ext, need_e = want_dumps || det_ext, need_ecs = want_dumps || det_cia;
+  // --saveext: the extinction of an earlier run back in (restfile_extinct, tau.c:155-156), this run's out (tau.c:340-341)
+  const bool want_saveext = trh_option(P, "saveext") != nullptr;
+  std::vector<double> ext_in; std::vector<uint8_t> ext_flags;
+  bool restored = false;
+  if (want_saveext) {
+    ext_in.resize((size_t)nwn * nr); ext_flags.assign((size_t)nr, 0);
+    restored = trh_saveext_read(P, ext_in.data(), ext_flags.data()) == TRX_OK;
+    if (!restored && verblevel >= 2) std::fprintf(stderr, "transit_hip: note: no extinction restored from '%s'\n", trh_option(P, "saveext"));
+  }
+  const bool need_tau = want_toomuch || want_dumps || det_tau || det_ext, need_e = want_dumps || det_ext || want_saveext, need_ecs = want_dumps || det_cia;
   const int nang = trh_opts(P)->nangles;
   if (want_dumps && trh_write_sample(P, nullptr) != TRX_OK)                     // makesample.c:598-599
     std::fprintf(stderr, "transit_hip: cannot write the sampling file\n");
@@ -176,10 +185,16 @@ int main(int argc, char **argv)
     if (k == fail_rank) { r.rc = TRX_E_HIP; r.err = "trx_run (TRANSIT_HIP_FAIL_RANK)"; return; }
     if ((r.rc = trx_create(&r.st, &r.h)) != TRX_OK) { r.err = "trx_create"; return; }
     const int64_t n = bounds[k + 1] - bounds[k];
+    if (restored) {                                        // this shard's columns of the restored rows
+      std::vector<double> part((size_t)n * nr);
+      for (int l = 0; l < nr; l++) std::memcpy(&part[(size_t)l * n], &ext_in[(size_t)l * nwn + bounds[k]], sizeof(double) * (size_t)n);
+      if ((r.rc = trx_restore_extinction(r.h, nr, part.data(), ext_flags.data())) != TRX_OK) { r.err = "trx_restore_extinction"; return; }
+    }
     r.slice.assign((size_t)count, 0.0);
     trx_debug dbg{};
     if (need_tau) { r.tau.resize((size_t)n * nr); r.last.resize((size_t)n); dbg.tau = r.tau.data(); dbg.last = r.last.data(); }
     if (need_e) { r.e.resize((size_t)n * nr); dbg.e = r.e.data(); }
+    if (want_saveext) { r.comp.assign((size_t)nr, 0); dbg.computed = r.comp.data(); }
     if (need_ecs) { r.ecs.resize((size_t)n * nr); dbg.e_cs = r.ecs.data(); }
     if (want_intens) { r.intens.resize((size_t)n * nang); dbg.intens = r.intens.data(); }
     trx_opts opts = *trh_opts(P);
@@ -234,7 +249,17 @@ int main(int argc, char **argv)
     }
     for (int a = 0; a < nang && want_intens; a++) std::memcpy(&intens[(size_t)a * nwn + lo], &r.intens[(size_t)a * n], sizeof(double) * (size_t)n);
   }
-  if (need_e) {                                            // the run may have swept deeper than the deepest ray: give the rows
+  if (want_saveext) {
+    // a layer is in the file when EVERY shard swept it or it came out of the file already (whose row it keeps)
+    std::vector<uint8_t> flags((size_t)nr, 1);
+    for (int l = 0; l < nr; l++) {
+      for (auto &r : R) flags[(size_t)l] &= r.comp[(size_t)l];
+      if (restored && ext_flags[(size_t)l]) { flags[(size_t)l] = 1; std::memcpy(&e[(size_t)l * nwn], &ext_in[(size_t)l * nwn], sizeof(double) * (size_t)nwn); }
+      if (!flags[(size_t)l]) std::fill(e.begin() + (size_t)l * nwn, e.begin() + (size_t)(l + 1) * nwn, 0.0);
+    }
+    if (trh_saveext_write(P, e.data(), flags.data()) != TRX_OK) std::fprintf(stderr, "transit_hip: cannot write the extinction savefile\n");
+  }
+  if (need_e && need_tau) {                                // the run may have swept deeper than the deepest ray: give the rows
     int64_t deep = 0;                                      // below it back the zeros the reference's lazy sweep leaves there
     for (int64_t w = 0; w < nwn; w++) deep = std::max(deep, last[(size_t)w]);
     std::fill(e.begin(), e.begin() + (size_t)(nr - 1 - deep) * nwn, 0.0);

@@ -103,6 +103,18 @@ class CEngine:
         problem.install_opacity(o)
         return o
 
+    def restore_extinction(self, e: Optional[np.ndarray], computed: Optional[np.ndarray] = None):
+        """trx_restore_extinction: e [nlayer][nwn_shard] and one flag per layer (None: forget them)."""
+        fn = self._f("restore_extinction")
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_int32, _abi.c_double_p, _abi.c_uint8_p], C.c_int
+        if e is None:
+            rc = fn(self._h, 0, None, None)
+        else:
+            e = np.ascontiguousarray(e, dtype=np.float64); c = np.ascontiguousarray(computed, dtype=np.uint8)
+            rc = fn(self._h, e.shape[0], e.ctypes.data_as(_abi.c_double_p), c.ctypes.data_as(_abi.c_uint8_p))
+        if rc != 0:
+            raise EngineError(rc, self._p + "restore_extinction", self._last_error())
+
     def stats(self) -> Dict[str, float]:
         s = _abi.TrxStats()
         rc = self._f("get_stats")(self._h, C.byref(s))

@@ -178,6 +178,37 @@ class Problem:
         v = _load().trh_output_plan(self._h)
         return dict(ln.split(" ", 1) for ln in (v.decode() if v else "").split("\n") if ln)
 
+    def saveext_read(self):
+        """--saveext: (e [nlayer][nwn], computed [nlayer]) of the file, or None when there is no valid one
+        (restfile_extinct, extinction.c:97-137)."""
+        lib = _load()
+        lib.trh_saveext_read.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_uint8_p]
+        lib.trh_saveext_read.restype = C.c_int
+        e = np.zeros((self.nlayer, self.nwn)); c = np.zeros(self.nlayer, dtype=np.uint8)
+        old = os.getcwd()
+        try:
+            os.chdir(self.cwd)
+            rc = lib.trh_saveext_read(self._h, e.ctypes.data_as(_abi.c_double_p), c.ctypes.data_as(_abi.c_uint8_p))
+        finally:
+            os.chdir(old)
+        if rc < 0:
+            raise HostError(rc, "trh_saveext_read")
+        return (e, c) if rc == 0 else None
+
+    def saveext_write(self, e: np.ndarray, computed: np.ndarray):
+        lib = _load()
+        lib.trh_saveext_write.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_uint8_p]
+        lib.trh_saveext_write.restype = C.c_int
+        e = np.ascontiguousarray(e, dtype=np.float64); c = np.ascontiguousarray(computed, dtype=np.uint8)
+        old = os.getcwd()
+        try:
+            os.chdir(self.cwd)
+            rc = lib.trh_saveext_write(self._h, e.ctypes.data_as(_abi.c_double_p), c.ctypes.data_as(_abi.c_uint8_p))
+        finally:
+            os.chdir(old)
+        if rc != 0:
+            raise HostError(rc, "trh_saveext_write")
+
     def write_detail(self, which: int, arr: np.ndarray):
         a = np.ascontiguousarray(arr, dtype=np.float64)
         old = os.getcwd()
