@@ -90,7 +90,7 @@ def production_launches(kernels, kernel, launch_key):
     prod = {}
     for name, k in kernels.items():
         m = re.match(r"(?:void )?trx::(\w+)(?:<([^>]*)>)?", name)
-        if not m or m.group(1) != kernel:
+        if not m or (m.group(1) != kernel and not (kernel == "k_line_walk" and m.group(1) == "k_line_walk_packed")):
             continue
         targs = [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
         if "true" in targs:            # PROF / COUNT

@@ -94,6 +94,7 @@ struct trx_handle {
   // the walk's copy: phase-major rows of whole cache lines (walk_row_layout), one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
+  bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
@@ -384,6 +385,8 @@ int build_table(trx_handle *h, const trx_static *s)
     }
     h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !std::getenv("TRX_NO_ROW_COPY");      // (the variable: tests of the fallback)
     h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");
+    h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");
+    if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
     // (run graphs are opt-in: on ROCm 7.2 hipGraphLaunch of this graph -- ~28 nodes on three streams --
     // costs the host as much as queueing them one by one, ~105 us, and the device runs it no faster:
     // 0.43 against 0.36 ms per spectrum, 0.218 against 0.210 for one shard of eight)
@@ -1115,7 +1118,17 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     nw = (unsigned)cum;
     if (ns == 0) { A.nseg = 1; A.seg_w0[0] = 0; A.seg_cum[0] = 0; A.seg_cum[1] = 0; }     // nothing reaches: no wave does anything
   }
-  if (nw > 0) {
+  // steps of few layers: several ranges per wave (k_line_walk_packed: an instruction serves S lines)
+  const bool packed = nw > 0 && !M.prof && A.tabw != nullptr && nc <= h->packed_max_layers && h->packed_walk;
+  if (packed) {
+    const int S = 64 / nc;
+    const unsigned pw = (nw + (unsigned)S - 1) / (unsigned)S;
+    const dim3 grid((pw + kWalkWaves - 1) / kWalkWaves), block(64 * kWalkWaves);
+    if (nb <= 4)      hipLaunchKernelGGL(k_line_walk_packed<4>, grid, block, 0, st, A, S);      // (a 2-bin step in the 4-bin row form: the same values)
+    else if (nb == 8) hipLaunchKernelGGL(k_line_walk_packed<8>, grid, block, 0, st, A, S);
+    else              hipLaunchKernelGGL(k_line_walk_packed<16>, grid, block, 0, st, A, S);
+  }
+  else if (nw > 0) {
     // (no row copy -- it would have passed 4 GB: the wide frames run their per-bin form, which is
     // the counting instantiation with the counters switched off)
     const bool per_bin = M.prof || (nb >= kWalkRowsFrom && A.tabw == nullptr);

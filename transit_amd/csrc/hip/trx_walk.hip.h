@@ -660,6 +660,182 @@ void k_line_walk(WalkArgs A)
   }
 }
 
+// ---------------------------------------------------------------------------
+// the walk for steps of few layers: several line ranges per wavefront
+// ---------------------------------------------------------------------------
+// k_line_walk costs what its instructions cost whatever the number of busy lanes: the demo's second
+// step (17 layers) pays 140 us for 27 % of the lanes, a step of 3 layers the same.  Here a wave
+// takes S = 64 / nc CONSECUTIVE ranges at once, lane = slot * nc + layer: every slot walks its own
+// range exactly as a wave of k_line_walk would -- same lines, same order, same frame, same partial
+// records (one per (range, bin), written by the slot that owns the range), so the sums and the
+// combine are untouched and the results are the same bits -- but an instruction now serves S lines.
+// What k_line_walk keeps wave-uniform in scalar registers (the line's record, its cell, the frame's
+// position, which bins it can reach) is per lane here: the records come through the vector
+// memory path (the lanes of a slot ask for the same 32 bytes: one request), the frame moves under
+// the lanes' own masks.  Row form only (frames of 4+ bins; a step of narrower layers runs its
+// 4-bin frame: the same values from the row copy), production only (counting runs: k_line_walk).
+template <int NB>
+__global__ __launch_bounds__(64 * kWalkWaves)
+void k_line_walk_packed(WalkArgs A, int S)
+{
+  constexpr int Rc = NB / 2 - 1;
+  if (!A.eager && A.flags[0] == 0) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = blockIdx.x * kWalkWaves + wv;             // wave-uniform: ranges W*S .. W*S + S - 1 of the launch
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / A.nc, li = lane - slot * A.nc;
+  int widx = W * S + slot;                                // index into the launched ranges
+  bool valid = slot < S;
+  int w = widx;
+  if (A.nseg > 0) {                                       // only the ranges that can reach the shard were launched
+    if (widx >= A.seg_cum[A.nseg]) valid = false;
+    int w0 = A.seg_w0[0], c0 = A.seg_cum[0];
+#pragma unroll
+    for (int sg = 1; sg < kWalkSegs; sg++)
+      if (sg < A.nseg && widx >= A.seg_cum[sg]) { w0 = A.seg_w0[sg]; c0 = A.seg_cum[sg]; }
+    w = w0 + (widx - c0);
+  }
+  if (w >= A.P.nwaves) valid = false;
+  if (!valid) w = 0;
+  int blo = A.P.blo[w], bhi = A.P.bhi[w];
+  if (bhi < blo) valid = false;                           // nothing of this range reaches the shard
+  if (A.last) {   // every ray of the range's bins has stopped (tau.c:277-287): nobody reads them
+    bool open = false;
+    if (valid) for (int j = blo + li; j <= bhi; j += A.nc) open |= A.last[j - A.lo] < 0;
+    bool slot_open = false;
+    for (int sl = 0; sl < S; sl++) {                      // (S <= 32 ballots: any lane of the slot saw an open ray)
+      const unsigned long long m = __ballot(open && slot == sl);
+      if (slot == sl) slot_open = m != 0ull;
+    }
+    valid = valid && slot_open;
+  }
+  if (__ballot(valid) == 0ull) return;
+  __shared__ double s_thr_w[kWalkWaves][kMaxDop + 1];
+  __shared__ double s_e2_w[kWalkWaves][64];
+  double *s_thr = s_thr_w[wv], *s_e2 = s_e2_w[wv];
+  for (int i = lane; i <= A.ndop; i += 64) s_thr[i] = A.dthr[i];
+  s_e2[lane] = A.e2tab[lane];
+  __builtin_amdgcn_wave_barrier();
+
+  const int b = walk_block_of(A.P.wbase, A.niso, w);
+  const int g0 = A.gblock[b] + (w - A.P.wbase[b]) * A.P.ngw, g1 = min(g0 + A.P.ngw, A.gblock[b + 1]);
+  const int l0 = A.gfirst[g0], l1 = A.gfirst[g1 - 1] + A.gcount[g1 - 1];
+  const long long rec0 = A.P.off[w];
+
+  const int r = A.r_top - (valid ? li : 0), ri = r * A.niso + b;
+  const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
+  const double ct = valid ? A.Y.negc_over_t[r] : 0.0;      // idle lanes: strength 0
+  const double f = A.Y.strength_f[ri], dens = A.permol ? 1.0 : A.Y.density[ri];
+  const double lim = A.ethresh * A.kmax[(long long)r * A.nmx + mx];
+  const double wc = A.wcut[ri], ad = A.Y.alphad[ri];
+  const int il = A.Y.ilor[ri];
+  const int idst = A.sticky_idop[ri];
+  // this slot's lines, requested kAhead lines ahead (vector loads: the slot's lanes share the address; a
+  // packed step has few waves, a wave hides its own memory latency): ring Q, line t in Q[t % kAhead]
+  constexpr int kAhead = 4;
+  const WalkLine *lp = A.lines + l0;
+  const int nlines_slot = valid ? l1 - l0 : 0;
+  WalkLine Q[kAhead];
+#pragma unroll
+  for (int u = 0; u < kAhead; u++) Q[u] = lp[min(u, max(nlines_slot - 1, 0))];
+  WalkLine L = Q[0];
+  L.meta |= 4;                                              // (a range starts on a base point)
+
+  // Doppler index of the first anchor, then followed downwards (wavenumbers descend => it never rises)
+  int lo_i = index_from(s_thr, ad * L.wavn, A.Y.idop0[ri]);
+  double thr_lo = s_thr[lo_i];
+  WalkProfile wp_cur = A.walkprof[lo_i * A.nlor + il];
+  const WalkProfile wp_st = A.walkprof[idst * A.nlor + il];
+
+  double acc[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) acc[k] = 0.0;
+  int jc = L.cell;                                          // frame: acc[k] <-> bin jc - Rc + k
+  auto flush = [&](int k, double v, bool on) {              // bin of slot k leaves the frame
+    const int j = jc - Rc + k;
+    if (on && j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + li] = v;
+  };
+  float pv_p[NB]; double kk_p = 0.0; bool pend = false;
+#pragma unroll
+  for (int k = 0; k < NB; k++) pv_p[k] = 0.f;
+  const char *tabw_base = (const char *)A.tabw - 4 * (Rc + 1);
+
+  double pk = 0.0, c0 = 0.0, E0 = 1.0, wav_a = L.wavn;
+  int cell = jc, imod = 0;
+  int left = nlines_slot;
+  const int trips = wave_max_i(left);
+  auto step = [&](const WalkLine &L, bool on) {
+    if (on && (L.meta & 4)) {                               // base point of the rebased exponential
+      const double t0 = ct * L.wavn;
+      E0 = exp_neg(t0, s_e2); c0 = -t0;
+    }
+    if (on && (L.meta & 1)) { cell = L.cell; imod = L.meta >> 3; wav_a = L.wavn; }
+    // ---- strength of the line in the lane's layer
+    const double e1 = exp_neg(ct * L.elow, s_e2);
+    const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, L.wavn, c0)), 1.0);
+    if (on) pk += L.gf * e1 * q;
+    if (on && (L.meta & 2)) {
+      // ---- the group is complete: threshold, density, profile, bins (extinction.c:464-509)
+      const double pkf = pk * f;
+      pk = 0.0;
+      const bool below = pkf < lim;                          // :467
+      const double kk = pkf * dens;                          // :472-473
+      const double v = ad * wav_a;
+      while (v < thr_lo) { lo_i--; thr_lo = s_thr[lo_i]; wp_cur = A.walkprof[lo_i * A.nlor + il]; }
+      const bool own = wav_a >= wc;
+      if (pend) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);     // :507
+      }
+      // ---- move the frame down to the group's cell
+      int sh = jc - cell;
+      if (sh >= NB) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) { flush(k, acc[k], valid); acc[k] = 0.0; }
+        // bins of the interval that no frame position covers still get their record: zeros
+        for (int j = max(cell + Rc + 2, blo); j <= min(jc - Rc - 1, bhi); j++) A.part[(rec0 + (j - blo)) * kWalkLayers + li] = 0.0;
+        jc = cell;
+      } else {
+        for (; sh > 0; sh--) {
+          flush(NB - 1, acc[NB - 1], valid);
+#pragma unroll
+          for (int k = NB - 1; k > 0; k--) acc[k] = acc[k - 1];
+          acc[0] = 0.0;
+          jc--;
+        }
+      }
+      // ---- bins: one row of the lane's profile holds all the frame's bins (k_line_walk, row form)
+      pend = true;
+      kk_p = (valid && !below) ? kk : 0.0;
+      const unsigned c4 = own ? wp_cur.centre4 : wp_st.centre4;
+      const int rb = own ? wp_cur.rowb : wp_st.rowb;
+      const int d = (own ? wp_cur.psr : wp_st.psr) - imod, sgn = d >> 31;
+      const unsigned at = c4 + (unsigned)(d + (sgn & A.osamp)) * (unsigned)rb + (unsigned)((sgn + 1) << 2);
+      struct alignas(4) Row { float v[NB]; } row;
+      __builtin_memcpy(&row, tabw_base + at, sizeof row);
+#pragma unroll
+      for (int k = 0; k < NB; k++) pv_p[k] = row.v[k];
+    }
+  };
+  Q[0] = L;
+  for (int t = 0; t < trips; t += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      const WalkLine Lu = Q[u];
+      const int nx = t + u + kAhead;                          // the line that takes this place in the ring
+      Q[u] = lp[min(nx, max(nlines_slot - 1, 0))];            // (past the range's end: its last line again, never used)
+      step(Lu, t + u < left);
+    }
+  }
+  if (pend) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++) flush(k, acc[k], valid);
+  if (valid) for (int j = blo; j <= min(jc - Rc - 1, bhi); j++) A.part[(rec0 + (j - blo)) * kWalkLayers + li] = 0.0;
+}
+
 // e[layer][j] = sum of the partial records of bin j, isotope blocks in order, ranges in order.
 // A block handles 8 consecutive bins, one wavefront (lanes = layers) per bin; the records of a
 // bin are requested four at a time and added in order; the 8 x 64 results cross an LDS tile so
