@@ -755,38 +755,50 @@ void k_line_walk_packed(WalkArgs A, int S)
     const int j = jc - Rc + k;
     if (on && j >= blo && j <= bhi) A.part[(rec0 + (j - blo)) * kWalkLayers + li] = v;
   };
-  float pv_p[NB]; double kk_p = 0.0; bool pend = false;
+  // Rows of the table: a group's row segment depends on its anchor line alone (profile from the anchor's
+  // wavenumber, phase from its fine-grid index), not on the strength -- so it is requested when the anchor is
+  // TWO lines ahead in the ring (stage "ahead"), into the row buffer of that ring place, and used when the
+  // group completes: the wait for the table, 63 % of this kernel's wave-cycles with a request per completed
+  // group, is gone from the chain.  grow: the row of the group in progress (taken over at its anchor line).
+  struct alignas(4) Row { float v[NB]; };
+  Row R[kAhead], grow;
 #pragma unroll
-  for (int k = 0; k < NB; k++) pv_p[k] = 0.f;
+  for (int k = 0; k < NB; k++) grow.v[k] = 0.f;
   const char *tabw_base = (const char *)A.tabw - 4 * (Rc + 1);
+  auto ahead = [&](const WalkLine &La, bool on_a, Row &dst) {
+    if (on_a && (La.meta & 1)) {
+      // nearest Doppler-width index: own one while alphad*wn/alphal >= 0.1, else the sticky one (:480-483)
+      const double v = ad * La.wavn;
+      while (v < thr_lo) { lo_i--; thr_lo = s_thr[lo_i]; wp_cur = A.walkprof[lo_i * A.nlor + il]; }
+      const bool own = La.wavn >= wc;
+      const unsigned c4 = own ? wp_cur.centre4 : wp_st.centre4;
+      const int rb = own ? wp_cur.rowb : wp_st.rowb;
+      const int d = (own ? wp_cur.psr : wp_st.psr) - (La.meta >> 3), sgn = d >> 31;
+      const unsigned at = c4 + (unsigned)(d + (sgn & A.osamp)) * (unsigned)rb + (unsigned)((sgn + 1) << 2);
+      __builtin_memcpy(&dst, tabw_base + at, sizeof dst);
+    }
+  };
+  ahead(Q[0], nlines_slot > 0, R[0]);                       // (the first two lines' rows: nobody was ahead of them)
+  ahead(Q[1], nlines_slot > 1, R[1]);
 
-  double pk = 0.0, c0 = 0.0, E0 = 1.0, wav_a = L.wavn;
-  int cell = jc, imod = 0;
-  int left = nlines_slot;
-  const int trips = wave_max_i(left);
-  auto step = [&](const WalkLine &L, bool on) {
+  double pk = 0.0, c0 = 0.0, E0 = 1.0;
+  int cell = jc;
+  const int trips = wave_max_i(nlines_slot);
+  auto step = [&](const WalkLine &L, bool on, double e1, const Row &mine) {
     if (on && (L.meta & 4)) {                               // base point of the rebased exponential
       const double t0 = ct * L.wavn;
       E0 = exp_neg(t0, s_e2); c0 = -t0;
     }
-    if (on && (L.meta & 1)) { cell = L.cell; imod = L.meta >> 3; wav_a = L.wavn; }
+    if (on && (L.meta & 1)) { cell = L.cell; grow = mine; }
     // ---- strength of the line in the lane's layer
-    const double e1 = exp_neg(ct * L.elow, s_e2);
     const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, L.wavn, c0)), 1.0);
     if (on) pk += L.gf * e1 * q;
     if (on && (L.meta & 2)) {
-      // ---- the group is complete: threshold, density, profile, bins (extinction.c:464-509)
+      // ---- the group is complete: threshold, density, bins (extinction.c:464-509)
       const double pkf = pk * f;
       pk = 0.0;
       const bool below = pkf < lim;                          // :467
-      const double kk = pkf * dens;                          // :472-473
-      const double v = ad * wav_a;
-      while (v < thr_lo) { lo_i--; thr_lo = s_thr[lo_i]; wp_cur = A.walkprof[lo_i * A.nlor + il]; }
-      const bool own = wav_a >= wc;
-      if (pend) {
-#pragma unroll
-        for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);     // :507
-      }
+      const double kk = below ? 0.0 : pkf * dens;            // :472-473 (a group below the threshold adds 0 x its row)
       // ---- move the frame down to the group's cell
       int sh = jc - cell;
       if (sh >= NB) {
@@ -805,31 +817,25 @@ void k_line_walk_packed(WalkArgs A, int S)
         }
       }
       // ---- bins: one row of the lane's profile holds all the frame's bins (k_line_walk, row form)
-      pend = true;
-      kk_p = (valid && !below) ? kk : 0.0;
-      const unsigned c4 = own ? wp_cur.centre4 : wp_st.centre4;
-      const int rb = own ? wp_cur.rowb : wp_st.rowb;
-      const int d = (own ? wp_cur.psr : wp_st.psr) - imod, sgn = d >> 31;
-      const unsigned at = c4 + (unsigned)(d + (sgn & A.osamp)) * (unsigned)rb + (unsigned)((sgn + 1) << 2);
-      struct alignas(4) Row { float v[NB]; } row;
-      __builtin_memcpy(&row, tabw_base + at, sizeof row);
 #pragma unroll
-      for (int k = 0; k < NB; k++) pv_p[k] = row.v[k];
+      for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk, (double)grow.v[k], acc[k]);     // :507
     }
   };
   Q[0] = L;
   for (int t = 0; t < trips; t += kAhead) {
+    // the four lines' exp(-c Elow/T) side by side: four independent chains instead of one after the other
+    double e1[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) e1[u] = exp_neg(ct * Q[u].elow, s_e2);
 #pragma unroll
     for (int u = 0; u < kAhead; u++) {
       const WalkLine Lu = Q[u];
+      const Row Ru = R[u];
+      ahead(Q[(u + 2) % kAhead], t + u + 2 < nlines_slot, R[(u + 2) % kAhead]);      // line t+u+2: its row, two lines early
       const int nx = t + u + kAhead;                          // the line that takes this place in the ring
       Q[u] = lp[min(nx, max(nlines_slot - 1, 0))];            // (past the range's end: its last line again, never used)
-      step(Lu, t + u < left);
+      step(Lu, t + u < nlines_slot, e1[u], Ru);
     }
-  }
-  if (pend) {
-#pragma unroll
-    for (int k = 0; k < NB; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);
   }
 #pragma unroll
   for (int k = 0; k < NB; k++) flush(k, acc[k], valid);
