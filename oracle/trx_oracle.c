@@ -298,6 +298,9 @@ struct trxo_handle {
   float   *tab;
   int64_t  tab_n;
   trx_stats stats;
+  /* restfile_extinct (extinction.c:97-137, called at tau.c:155-156): rows and flags of layers an
+   * earlier run computed; [nsaved][nsh] and [nsaved], NULL when nothing was restored */
+  double *e_saved; unsigned char *c_saved; long nsaved;
 };
 
 static void *dupmem(const void *p, size_t n)
@@ -425,7 +428,24 @@ void trxo_destroy(trxo_handle *h)
   }
   if (h->st.ogrid) { free((void*)h->grid.mol_index); free((void*)h->grid.temp); free((void*)h->grid.o); }
   free(h->adop); free(h->alor); free(h->psize); free(h->poff); free(h->tab);
+  free(h->e_saved); free(h->c_saved);
   free(h);
+}
+
+/* transit/src/extinction.c:97-137 + tau.c:155-156: e[][] and comp[] as the save file holds them are what
+ * tau() starts from; a layer with comp set is never swept (tau.c:158, 246). */
+int trxo_restore_extinction(trxo_handle *h, int32_t nlayer, const double *e, const unsigned char *computed)
+{
+  if (!h || nlayer < 0 || (nlayer > 0 && (!e || !computed))) return TRX_E_ARG;
+  free(h->e_saved); free(h->c_saved); h->e_saved = NULL; h->c_saved = NULL; h->nsaved = 0;
+  if (nlayer == 0) return TRX_OK;
+  const trx_static *s = &h->st;
+  const long nsh = (s->wn_hi > s->wn_lo) ? (long)(s->wn_hi - s->wn_lo) : (long)s->nwn;
+  h->e_saved = dupmem(e, sizeof(double) * (size_t)nlayer * (size_t)nsh);
+  h->c_saved = dupmem(computed, (size_t)nlayer);
+  if (!h->e_saved || !h->c_saved) return TRX_E_NOMEM;
+  h->nsaved = nlayer;
+  return TRX_OK;
 }
 
 int trxo_get_stats(const trxo_handle *h, trx_stats *out)
@@ -935,6 +955,11 @@ int trxo_run(trxo_handle *h, const trx_atm *a, const trx_opts *o, double *spectr
     else layer_extinction(h, o->ethresh, e + (size_t)(L)*nwn, a->temp[(L)], dens, zp, 1, NULL); \
     comp[(L)] = 1; } while (0)
 
+  if (h->e_saved) {                                        /* restfile_extinct, tau.c:155-156 */
+    if (h->nsaved != nr) { rc = TRX_E_ARG; goto done; }
+    for (long L = 0; L < nr; L++)
+      if (h->c_saved[L]) { memcpy(e + (size_t)L*nwn + w0, h->e_saved + (size_t)L*nsh, sizeof(double)*nsh); comp[L] = 1; }
+  }
   if (!comp[nr-1]) SWEEP(nr-1);                            /* tau.c:158-177 */
   /* eager: every layer, independent of each other -- the one place where this restatement uses
    * more than one core (OMP_NUM_THREADS; bench.py's all-core CPU figure).  Each thread has its

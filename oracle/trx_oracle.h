@@ -29,6 +29,7 @@ int  trxo_run    (trxo_handle *h, const trx_atm *atm, const trx_opts *opts,
 void trxo_destroy(trxo_handle *h);
 int  trxo_sweep_permol(trxo_handle *h, int32_t nv, const double *temp, const double *density,
                        const double *zpart, double ethresh, int32_t nslot, const int32_t *iso_slot, double *out);
+int  trxo_restore_extinction(trxo_handle *h, int32_t nlayer, const double *e, const unsigned char *computed);
 int  trxo_get_stats(const trxo_handle *h, trx_stats *out);
 int  trxo_table_info(const trxo_handle *h, int64_t *profsize, int64_t *offset, int64_t *total);
 int  trxo_table_copy(const trxo_handle *h, float *out);

@@ -47,6 +47,29 @@ def test_host_reads_and_writes_the_reference_s_file(tmp_path):
     assert P.saveext_read() is None
 
 
+def test_oracle_restores_the_reference_s_file():
+    """restfile_extinct + the lazy sweep: with the reference's own file restored, the layers it flags are
+    never swept (the counters say so) and the spectrum is the reference's."""
+    g = golden("saveext_transit")
+    P = g.problem
+    e_ref, c_ref = ref_file()
+    ora = ol.OracleEngine(P.static)
+    try:
+        ora.restore_extinction(e_ref, (c_ref != 0).astype(np.uint8))
+        got = ora.run(P.atm, P.opts, debug=("e", "computed"))
+        assert ora.stats()["neval"] == 0                           # nothing was evaluated: every layer the rays need came from the file
+        assert rel_err(got["spectrum"], g.spectrum) < 2e-8
+        assert np.array_equal(got["e"], e_ref)
+        e2 = e_ref.copy(); e2[c_ref != 0] *= 2.0                    # the restored rows are what the rays see
+        ora.restore_extinction(e2, (c_ref != 0).astype(np.uint8))
+        assert rel_err(ora.run(P.atm, P.opts)["spectrum"], g.spectrum) > 1e-3
+        ora.restore_extinction(None)
+        fresh = ora.run(P.atm, P.opts)
+        assert ora.stats()["neval"] > 0 and rel_err(fresh["spectrum"], g.spectrum) < 2e-8
+    finally:
+        ora.close()
+
+
 def _cli(work, *extra):
     exe = build.build_cli() or build.lib_path("transit_hip")
     for f in ("spectrum.dat", "toomuch.dat"):
