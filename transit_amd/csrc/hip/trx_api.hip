@@ -81,6 +81,7 @@ struct trx_handle {
   // isotopes / molecules (host copies)
   int niso = 0, nmol = 0;
   std::vector<double> iso_mass, iso_ratio, mol_mass, mol_radius, mol_pol;
+  std::vector<double> pair_csd, pair_sqrt;          // [niso][nmol]: r_mol + r_iso's molecule, sqrt(1/m_iso + 1/m_mol) (extinction.c:376-380)
   std::vector<int32_t> iso_imol, mol_is_h2;
   std::vector<double> iso_wmin, iso_wmax;          // anchor wavenumber range per isotope
   // Voigt table
@@ -907,11 +908,9 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
     const double florentz = std::sqrt(2 * kKb * temp / kPi / kAmu) / (kAmu * kLs);
     for (int i = 0; i < niso; i++) {
       double al = 0.0;
-      for (int j = 0; j < nmol; j++) {
-        const double csd = h->mol_radius[j] + h->mol_radius[h->iso_imol[i]];
-        al += density[(size_t)j * nr + r] / h->mol_mass[j] * csd * csd *
-              std::sqrt(1 / h->iso_mass[i] + 1 / h->mol_mass[j]);
-      }
+      const double *csd_i = &h->pair_csd[(size_t)i * nmol], *sq_i = &h->pair_sqrt[(size_t)i * nmol];
+      for (int j = 0; j < nmol; j++)       // (the collision diameter and the reduced-mass root of the pair: constants of the handle)
+        al += density[(size_t)j * nr + r] / h->mol_mass[j] * csd_i[j] * csd_i[j] * sq_i[j];
       al *= florentz;
       const double ad = fdoppler / std::sqrt(h->iso_mass[i]);
       const size_t k = (size_t)r * niso + i;
@@ -1495,6 +1494,12 @@ int trx_create(const trx_static *s, trx_handle **out)
   if (s->mol_pol) h->mol_pol.assign(s->mol_pol, s->mol_pol + s->nmol); else h->mol_pol.assign(s->nmol, 0.0);
   if (s->mol_is_h2) h->mol_is_h2.assign(s->mol_is_h2, s->mol_is_h2 + s->nmol); else h->mol_is_h2.assign(s->nmol, 0);
   for (int i = 0; i < s->niso; i++) if (s->iso_imol[i] < 0 || s->iso_imol[i] >= s->nmol) return bail(TRX_E_ARG);
+  h->pair_csd.assign((size_t)s->niso * s->nmol, 0.0); h->pair_sqrt.assign((size_t)s->niso * s->nmol, 0.0);
+  for (int i = 0; i < s->niso; i++)
+    for (int j = 0; j < s->nmol; j++) {
+      h->pair_csd[(size_t)i * s->nmol + j] = h->mol_radius[j] + h->mol_radius[h->iso_imol[i]];
+      h->pair_sqrt[(size_t)i * s->nmol + j] = std::sqrt(1 / h->iso_mass[i] + 1 / h->mol_mass[j]);
+    }
   for (int k = 0; k < s->ncia; k++) {
     const trx_cia &c = s->cia[k];
     if (c.nspec < 1 || c.nspec > 2 || c.nwave < 3 || c.ntemp < 3) return bail(TRX_E_ARG);
