@@ -26,3 +26,18 @@ def test_quotient_rn_is_the_division(tmp_path):
     out = subprocess.run([exe, "20000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "20000000 operands, 0 differ" in out.stdout
+
+
+def test_threaded_grouping_is_the_sequential_loop(tmp_path):
+    """trx_create's co-added groups, cut into pieces and grouped on several threads, and its
+    per-bin counts == the one-thread loops of extinction.c:445-462 (tests/groups_check.cpp:
+    sparse, grid-dense and over-dense lists, many small isotope blocks, ties, lines out of range)."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "groups_check")
+    subprocess.run([gxx, "-O2", "-pthread", "-I", os.path.join(ROOT, "transit_amd", "csrc"),
+                    "-o", exe, os.path.join(ROOT, "tests", "groups_check.cpp")], check=True)
+    out = subprocess.run([exe, "40"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert " 0 differ" in out.stdout

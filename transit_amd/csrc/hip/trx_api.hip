@@ -30,6 +30,7 @@
 #include "trx_kernels.hip.h"
 #include "trx_walk.hip.h"
 #include "trx_rows.hip.h"
+#include "../trx_groups.h"
 
 using namespace trx;
 
@@ -40,22 +41,6 @@ struct DevBuf {
   ~DevBuf() { release(); }
   void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
   template <class T> T *as() const { return (T *)p; }
-};
-
-// host array WITHOUT initialisation (a std::vector of 10^7 doubles spends 10 ms of one thread
-// zeroing what the next loop overwrites; these are written by several threads, first touch included)
-template <class T>
-struct HostBuf {
-  std::unique_ptr<T[]> p; size_t n = 0;
-  void alloc(size_t m) { p.reset(m ? new T[m] : nullptr); n = m; }
-  T *data() { return p.get(); }
-  const T *data() const { return p.get(); }
-  T &operator[](size_t i) { return p[i]; }
-  const T &operator[](size_t i) const { return p[i]; }
-  size_t size() const { return n; }
-  bool empty() const { return n == 0; }
-  T *begin() { return p.get(); }
-  T *end() { return p.get() + n; }
 };
 
 // view into another allocation (same accessors as DevBuf, owns nothing)
@@ -430,43 +415,7 @@ int build_table(trx_handle *h, const trx_static *s)
   return TRX_OK;
 }
 
-// ---- line list preparation --------------------------------------------------
-// The host part of trx_create is linear in the list (10^7 lines: a quarter of a second on one
-// core, 110 ms of it the co-add grouping).  All of it runs on a few host threads:
-int create_threads()
-{
-  if (const char *e = std::getenv("TRX_CREATE_THREADS")) return std::max(1, std::atoi(e));
-  const unsigned hc = std::thread::hardware_concurrency();
-  return (int)std::min<unsigned>(std::max<unsigned>(hc, 1u), 16u);
-}
-
-// f(part, begin, end) over [0, n) cut into `parts` contiguous pieces, one thread each
-template <class F>
-void parallel_parts(int64_t n, int parts, F f)
-{
-  parts = (int)std::max<int64_t>(1, std::min<int64_t>(parts, n / 65536 + 1));     // (small lists: one thread)
-  if (parts == 1) { f(0, (int64_t)0, n); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < parts; t++) th.emplace_back([=]() { f(t, n * t / parts, n * (t + 1) / parts); });
-  for (auto &x : th) x.join();
-}
-
-// cnt[k] = number of the block's groups with key >= k, k = 0..nkey (keys descend along the block)
-template <class Key>
-void count_ge(const int32_t *giown, int g0, int g1, long long nkey, Key key, int32_t *cnt, int nth)
-{
-  parallel_parts(nkey + 1, nth, [&](int, int64_t k0, int64_t k1) {
-    // groups with key >= k1 - 1: found by bisection, then the pointer only moves forward as k falls
-    int a = g0, z = g1;
-    while (a < z) { const int m = (a + z) >> 1; if (key(giown[m]) >= k1 - 1) a = m + 1; else z = m; }
-    int p = a;
-    for (int64_t k = k1 - 1; k >= k0; k--) {
-      while (p < g1 && key(giown[p]) >= k) p++;
-      cnt[k] = p - g0;
-    }
-  });
-}
-
+// ---- line list preparation (the threaded host loops: ../trx_groups.h) -------
 int prepare_lines(trx_handle *h, const trx_static *s)
 {
   const int64_t n = s->nlines;
@@ -474,7 +423,6 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   const int nth = create_threads();
   const double wn0 = s->wn_i, odwn = s->wn_d / s->osamp;
   const double own_last = wn0 + (double)(s->nown - 1) * odwn;
-  auto own = [&](long long k) { return wn0 + (double)k * odwn; };
   if (n > 2000000000LL) return fail(h, TRX_E_UNSUPPORTED, "more than 2^31 lines per handle");
   // the three arrays that go up as they are leave now, on a thread of their own, under the grouping
   const double *elow = s->elow, *gf = s->gf;
@@ -518,78 +466,11 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     if (any & 2) return fail(h, TRX_E_ORDER, "wavelengths are not ascending inside an isotope block");
   }
   T.lap("order check");
-  // Co-added groups (extinction.c:445-462): a greedy chain -- a group's anchor decides which of the
-  // following lines join it, and the line after them is the next anchor -- so it is sequential by
-  // nature.  But a line that starts an isotope block, or lies more than 1.6 fine-grid steps below
-  // its predecessor, can belong to NO earlier group (an anchor's grid point is at most half a step
-  // from it): the chain restarts there whatever came before.  The list is cut at such lines and the
-  // pieces are grouped side by side, each with the reference's own loop; a piece without such a
-  // line nearby (a list much denser than the fine grid) is simply left to the piece before it.
-  HostBuf<int32_t> gfirst, gcount, giown; HostBuf<int16_t> giso; HostBuf<double> gwavn;
-  h->iso_wmin.assign(s->niso, HUGE_VAL); h->iso_wmax.assign(s->niso, 0.0);
-  {
-    int parts = (int)std::max<int64_t>(1, std::min<int64_t>(nth, n / 65536 + 1));
-    std::vector<int64_t> cut;                       // piece p = lines [cut[p], cut[p+1])
-    cut.push_back(0);
-    for (int t = 1; t < parts; t++) {
-      const int64_t from = std::max<int64_t>(n * t / parts, cut.back() + 1), to = std::min<int64_t>(n, from + n / parts / 2);
-      for (int64_t l = from; l < to; l++)
-        if (s->isoid[l] != s->isoid[l-1] || wavn[l-1] - wavn[l] >= 1.6 * odwn) { cut.push_back(l); break; }
-    }
-    cut.push_back(n);
-    parts = (int)cut.size() - 1;
-    struct Piece { std::vector<int32_t> first, count, iown; std::vector<int16_t> iso; std::vector<double> wv; int64_t nadd = 0; std::vector<double> wmin, wmax; };
-    std::vector<Piece> P((size_t)parts);
-    auto work = [&](int p) {
-      Piece &Q = P[(size_t)p];
-      Q.wmin.assign(s->niso, HUGE_VAL); Q.wmax.assign(s->niso, 0.0);
-      const int64_t l0 = cut[(size_t)p], l1 = cut[(size_t)p + 1];
-      const size_t guess = (size_t)(l1 - l0) / 2 + 16;
-      Q.first.reserve(guess); Q.count.reserve(guess); Q.iown.reserve(guess); Q.iso.reserve(guess); Q.wv.reserve(guess);
-      for (int64_t ln = l0; ln < l1; ln++) {
-        if (!inr[ln]) continue;
-        const double w = wavn[ln]; const int iso = s->isoid[ln];
-        int iown = (int)((w - wn0) / odwn);                          // extinction.c:445-447
-        if (std::fabs(w - own(iown + 1)) < std::fabs(w - own(iown))) iown++;
-        const int64_t first = ln;
-        while (ln != n - 1 && s->isoid[ln + 1] == iso) {             // extinction.c:449-462
-          if (std::fabs(wavn[ln + 1] - own(iown)) < odwn) { Q.nadd++; ln++; }
-          else break;
-        }
-        Q.first.push_back((int32_t)first); Q.count.push_back((int32_t)(ln - first + 1));
-        Q.iown.push_back(iown); Q.iso.push_back((int16_t)iso); Q.wv.push_back(w);
-        Q.wmin[iso] = std::min(Q.wmin[iso], w); Q.wmax[iso] = std::max(Q.wmax[iso], w);
-      }
-    };
-    if (parts == 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (int p = 0; p < parts; p++) th.emplace_back(work, p);
-      for (auto &x : th) x.join();
-    }
-    std::vector<size_t> at((size_t)parts + 1, 0);
-    for (int p = 0; p < parts; p++) at[(size_t)p + 1] = at[(size_t)p] + P[(size_t)p].first.size();
-    const size_t ng = at[(size_t)parts];
-    gfirst.alloc(ng); gcount.alloc(ng); giown.alloc(ng); giso.alloc(ng); gwavn.alloc(ng);
-    auto gather = [&](int p) {
-      const Piece &Q = P[(size_t)p]; const size_t o = at[(size_t)p], m = Q.first.size();
-      if (!m) return;
-      std::memcpy(&gfirst[o], Q.first.data(), 4 * m); std::memcpy(&gcount[o], Q.count.data(), 4 * m);
-      std::memcpy(&giown[o], Q.iown.data(), 4 * m); std::memcpy(&giso[o], Q.iso.data(), 2 * m); std::memcpy(&gwavn[o], Q.wv.data(), 8 * m);
-    };
-    if (parts == 1) gather(0);
-    else {
-      std::vector<std::thread> th;
-      for (int p = 0; p < parts; p++) th.emplace_back(gather, p);
-      for (auto &x : th) x.join();
-    }
-    for (int p = 0; p < parts; p++) {
-      h->nadd += P[(size_t)p].nadd;
-      for (int b = 0; b < s->niso; b++) {
-        h->iso_wmin[b] = std::min(h->iso_wmin[b], P[(size_t)p].wmin[b]); h->iso_wmax[b] = std::max(h->iso_wmax[b], P[(size_t)p].wmax[b]);
-      }
-    }
-  }
+  // co-added groups (extinction.c:445-462), grouped in pieces side by side (trx_groups.h)
+  LineGroups LG;
+  group_lines(n, s->isoid, wavn.data(), inr.data(), s->niso, wn0, odwn, nth, LG);
+  HostBuf<int32_t> &gfirst = LG.first, &gcount = LG.count, &giown = LG.iown; HostBuf<int16_t> &giso = LG.iso; HostBuf<double> &gwavn = LG.wavn;
+  h->iso_wmin = LG.iso_wmin; h->iso_wmax = LG.iso_wmax; h->nadd += LG.nadd;
   T.lap("grouping");
   h->nlines = n; h->ngroups = (int64_t)gfirst.size();
   // isotope blocks (groups are in line order: the first group of every isotope by bisection) and
