@@ -74,7 +74,7 @@ def kernel_source_hash():
     """Fingerprint of the kernel sources a committed PMC profile must match to be quoted."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h"):
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h", "trx_tail.hip.h"):
         h.update(open(os.path.join(ROOT, "transit_amd", "csrc", "hip", f), "rb").read())
     return h.hexdigest()[:12]
 

@@ -58,7 +58,7 @@ def kernel_source_hash():
     fingerprint matches the kernel sources of the tree it runs from."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h"):
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h", "trx_tail.hip.h"):
         h.update(open(os.path.join(HERE, "..", "transit_amd", "csrc", "hip", f), "rb").read())
     return h.hexdigest()[:12]
 

@@ -1,0 +1,145 @@
+"""k_ray_tail (trx_tail.hip.h: a hinted eclipse run's combines, optical depths and emission as ONE
+kernel behind its walks) against the step kernels it stands for (TRX_RAY_TAIL=0): the same
+operations on the same values, so the same BITS in every output -- extinction, edited extinction,
+optical depth, stopping heights, intensities, spectrum -- on goldens, on a demo-shaped case (two
+walk steps), on shards, with CIA, and when the atmosphere moves under the remembered depth (rays
+go deeper: the tail's pass is resumed by the step kernels; shallower: a shorter plan)."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import GOLDEN
+from transit_amd import engine, synth
+from transit_amd.engine import Engine
+from transit_amd.host import Problem
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("e", "e_cs", "tau", "last", "intens", "computed", "er")
+
+
+def engines(P):
+    os.environ["TRX_RAY_TAIL"] = "0"
+    try:
+        ref = Engine(P.static)
+    finally:
+        os.environ.pop("TRX_RAY_TAIL", None)
+    return Engine(P.static), ref
+
+
+def assert_same(ra, rb, note=None):
+    sw = ra["computed"].astype(bool) if "computed" in ra else slice(None)
+    assert set(ra) == set(rb)
+    for k in ra:
+        if k in ("e", "e_cs"):
+            assert np.array_equal(ra[k][sw], rb[k][sw]), (k, note)
+        elif k == "er":
+            # (edited extinction: written down to the ray's stopping height only)
+            nl = ra[k].shape[0]
+            used = (nl - 1 - np.arange(nl))[:, None] <= ra["last"][None, :]
+            assert np.array_equal(ra[k][used], rb[k][used]), (k, note)
+        elif k == "tau":
+            # heights a ray never reached hold whatever an earlier run left: compare what the ray used
+            last = ra["last"]
+            used = np.arange(ra[k].shape[1])[None, :] <= last[:, None]
+            assert np.array_equal(ra[k][used], rb[k][used]), (k, note)
+        else:
+            assert np.array_equal(ra[k], rb[k]), (k, note)
+
+
+def tail_runs(msgs):
+    return sum("ray tail over" in m for m in msgs)
+
+
+@pytest.mark.parametrize("case", ["eclipse_small", "coadd_thresh", "multi_species", "many_isotopes", "midres_os4"])
+def test_tail_on_goldens(case):
+    P = Problem.from_cfg(os.path.join(GOLDEN, case, "case.cfg"))
+    if P.opts.solution != 0:
+        pytest.skip("transit geometry: the step kernels")
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    t, r = engines(P)
+    try:
+        for k in range(3):                               # unhinted, hinted with dumps, hinted production
+            dbg = KEYS if k < 2 else None
+            a = t.run(P.atm, P.opts, debug=dbg) if dbg else t.run(P.atm, P.opts)
+            n_tail = tail_runs(msgs)
+            b = r.run(P.atm, P.opts, debug=dbg) if dbg else r.run(P.atm, P.opts)
+            assert tail_runs(msgs) == n_tail             # (the reference engine never takes the tail)
+            assert_same(a, b, (case, k))
+        assert t.stats()["layers_swept"] == r.stats()["layers_swept"]
+    finally:
+        engine.set_log(None)
+        t.close(); r.close()
+
+
+@pytest.mark.parametrize("ncia,nlayers", [(0, 100), (2, 100), (1, 40), (0, 7)])
+def test_tail_demo_shape_moving_atmosphere_and_shards(tmp_path, ncia, nlayers):
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=120_000, wnlow=2500, wnhigh=2800, wndelt=1.0, wnosamp=2160, nlayers=nlayers,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=11, ncia=ncia)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    dens = np.ctypeslib.as_array(P.atm.density, shape=(P.static.nmol * P.nlayer,))
+    base = dens.copy()
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    t, r = engines(P)
+    try:
+        # same atmosphere (hint exact), thinner (rays go deeper: resumed), the same again, denser
+        # (rays stop higher: a shorter plan next time), back
+        for k, sc in enumerate([1.0, 1.0, 1.0, 0.03, 0.03, 0.03, 40.0, 40.0, 1.0, 1.0]):
+            dens[:] = base * sc
+            dbg = KEYS if k % 3 != 2 else None
+            a = t.run(P.atm, P.opts, debug=dbg) if dbg else t.run(P.atm, P.opts)
+            b = r.run(P.atm, P.opts, debug=dbg) if dbg else r.run(P.atm, P.opts)
+            assert_same(a, b, (k, sc))
+            assert t.stats()["layers_swept"] == r.stats()["layers_swept"], (k, sc)
+        assert tail_runs(msgs) >= 6, tail_runs(msgs)
+        dens[:] = base
+        full = t.run(P.atm, P.opts)["spectrum"]
+    finally:
+        dens[:] = base
+        t.close(); r.close()
+    # shards: ragged last block (nsh % 8 != 0), a one-ray shard
+    for lo, hi in [(37, 211), (0, 13), (P.nwn - 1, P.nwn)]:
+        P.set_shard(lo, hi)
+        try:
+            t, r = engines(P)
+            try:
+                for k in range(3):
+                    a, b = t.run(P.atm, P.opts, debug=KEYS), r.run(P.atm, P.opts, debug=KEYS)
+                    assert_same(a, b, (lo, hi, k))
+                assert np.array_equal(a["spectrum"], full[lo:hi]), (lo, hi)
+            finally:
+                t.close(); r.close()
+        finally:
+            P.set_shard(0, P.nwn)
+    engine.set_log(None)
+    assert tail_runs(msgs) >= 12
+
+
+def test_tail_with_copy_commands_instead_of_pinned_outputs(tmp_path):
+    """TRX_TAIL_DIRECT=0: the tail writes spectrum and flags to device memory and copy commands bring
+    them back (the form a run graph or a device-side spectrum uses) -- the same bits, the same depth hint."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=60_000, wnlow=2500, wnhigh=2700, wndelt=1.0, wnosamp=2160, nlayers=90,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=3, ncia=1)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    os.environ["TRX_TAIL_DIRECT"] = "0"
+    try:
+        c = Engine(P.static)
+    finally:
+        os.environ.pop("TRX_TAIL_DIRECT", None)
+    t, r = engines(P)
+    dens = np.ctypeslib.as_array(P.atm.density, shape=(P.static.nmol * P.nlayer,))
+    base = dens.copy()
+    try:
+        for k, sc in enumerate([1.0, 1.0, 0.05, 0.05, 1.0, 1.0]):
+            dens[:] = base * sc
+            a, b, x = t.run(P.atm, P.opts), c.run(P.atm, P.opts), r.run(P.atm, P.opts)
+            assert np.array_equal(a["spectrum"], x["spectrum"]) and np.array_equal(b["spectrum"], x["spectrum"]), (k, sc)
+            assert t.stats()["layers_swept"] == r.stats()["layers_swept"] == c.stats()["layers_swept"], (k, sc)
+    finally:
+        dens[:] = base
+        t.close(); r.close(); c.close()

@@ -30,6 +30,7 @@
 #include "trx_kernels.hip.h"
 #include "trx_walk.hip.h"
 #include "trx_rows.hip.h"
+#include "trx_tail.hip.h"
 #include "../trx_groups.h"
 
 using namespace trx;
@@ -80,6 +81,8 @@ struct trx_handle {
   // the walk's copy: phase-major rows of whole cache lines (walk_row_layout), one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
+  bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
+  bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
@@ -372,6 +375,8 @@ int build_table(trx_handle *h, const trx_static *s)
     h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !std::getenv("TRX_NO_ROW_COPY");      // (the variable: tests of the fallback)
     h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");
     h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");
+    if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;
     if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
     // (run graphs are opt-in: on ROCm 7.2 hipGraphLaunch of this graph -- ~28 nodes on three streams --
     // costs the host as much as queueing them one by one, ~105 us, and the device runs it no faster:
@@ -1584,7 +1589,8 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const bool vertical = o->solution == TRX_SOL_ECLIPSE;
   const int gstride = vertical ? 4 : 4 * (nr / 2 + 1);
   const size_t mw_doubles = vertical ? 0 : (size_t)(nr + 1) * gstride;
-  const size_t n_geom_all = (size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr;
+  const size_t n_geom_all = (size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr +
+                            (vertical ? (size_t)kVertLay * nr : 0);       // (vertical rays: the chain's per-layer constants behind the rest)
   std::vector<double> geom(vertical ? n_geom_all : 1, 0.0);       // (transit: device-built, see below)
   {
     std::vector<double> sx(nr + 1);
@@ -1599,6 +1605,19 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       for (int i = 1; i < 3; i++) sx[i] = sx[i-1] + (r3[i] - r3[i-1]);
       simpson_weights(sx.data(), 3, gw + (size_t)rs * gstride, gh0 + rs);
       for (int k = 0; k + 2 < nr; k++) { double h0; simpson_weights(a->radius + k, 3, pw + 4 * (size_t)k, &h0); }
+      // what the chain of bottom-point parabolas and Simpson sums needs per layer (VertLayer, trx_kernels.hip.h):
+      // the same IEEE operations the kernels used to repeat in every block
+      double *lay = pw + 6 * (size_t)nr;
+      for (int rs = 0; rs < nr; rs++) {
+        double *L = lay + (size_t)kVertLay * rs;
+        if (rs + 1 < nr) {
+          const double step = a->radius[rs + 1] - a->radius[rs];
+          L[0] = step; L[1] = a->radius[rs] / step; L[2] = 2.0 * step * step;
+          L[8] = 1.0 / step; L[9] = 1.0 / L[2]; L[10] = L[1] + 1.5;
+        }
+        for (int q = 0; q < 4; q++) L[3 + q] = pw[4 * (size_t)rs + q];
+        L[7] = a->radius[rs]; L[11] = a->radius[rs] * a->radius[rs];
+      }
     } else {
       // transit geometry: built on the device (k_slant_geometry), nothing to prepare or ship here
     }
@@ -1884,6 +1903,29 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   int flags_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}, status_host[4] = {0, 0, 0, 0};
   std::vector<unsigned long long> counters(3 * (size_t)nr);
   double *d_out = d_spectrum ? (double *)d_spectrum : h->d_spec.as<double>();
+  auto tau_args = [&](TauArgs &T, int r_top_, int nc_) {
+    T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
+    T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
+    T.r_top = r_top_; T.nc = nc_; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
+    T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
+    T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
+    model_args(T);
+    T.flags = h->d_flags.as<int>(); T.eager = eager;
+    T.pw = d_pw; T.acc = h->d_acc.as<double>(); T.lay = vertical ? d_pw + 6 * (size_t)nr : nullptr;
+    T.hrs = d_pw + 4 * (size_t)nr; T.hr0 = T.hrs + nr; T.status = h->d_status.as<int>();
+  };
+  auto emis_args = [&](EmisArgs &E) {
+    E.nr = nr; E.nang = o->nangles; E.nsh = nsh; E.lo = h->lo; E.wn_i = h->wn_i; E.wn_d = h->wn_d; E.wn_fct = o->wn_fct;
+    E.tau = h->d_tau.as<double>(); E.last = h->d_last.as<int>(); E.temp = d_tempk;
+    std::vector<double> grid(o->nangles + 1);                    // eclipse.c:262-269
+    grid[0] = 0.0 * kDeg; grid[o->nangles] = 90.0 * kDeg;
+    for (int i = 1; i < o->nangles; i++) grid[i] = (o->angles_deg[i-1] + o->angles_deg[i]) * kDeg / 2.0;
+    for (int i = 0; i < o->nangles; i++) {
+      E.cosang[i] = std::cos(o->angles_deg[i] * kDeg);
+      E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
+    }
+    E.intens = h->d_intens.as<double>(); E.flux = d_out; E.e2tab = h->d_e2tab.as<double>();
+  };
   struct SideWork { bool active = false, first = false; int r_top = 0, nc = 0, swept = 0; hipStream_t st_tau = nullptr; PendingCombine pc; };
   SideWork pending;
   auto run_side = [&](SideWork &S) -> int {
@@ -1908,15 +1950,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       int nt = std::min(tau_cap, S.nc - done);
       if (S.swept == 0 && done == 0) nt = std::min(S.nc, std::max(nt, 3));
       TauArgs T{};
-      T.nr = nr; T.solution = o->solution; T.nsh = nsh; T.lo = h->lo;
-      T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
-      T.r_top = S.r_top - done; T.nc = nt; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
-      T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
-      T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
-      model_args(T);
-      T.flags = h->d_flags.as<int>(); T.eager = eager;
-      T.pw = d_pw; T.acc = h->d_acc.as<double>();
-      T.hrs = d_pw + 4 * (size_t)nr; T.hr0 = T.hrs + nr; T.status = h->d_status.as<int>();
+      tau_args(T, S.r_top - done, nt);
       if (o->solution == TRX_SOL_ECLIPSE) {
         // small shards: one wave per block spreads the (latency-bound) chains over more CUs
         const bool small = nsh <= 64 * 1024, extras = o->scat_flag != 0 || o->cloud_flag != 0;
@@ -1936,27 +1970,15 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if (prof && spans.end(S.st_tau)) return fail(h, TRX_E_HIP, "event");
     return TRX_OK;
   };
-  bool replay_now = replay;
-  for (;;) {
-  if (replay_now) {
-    // the whole first pass -- inputs, front end, steps, spectrum, copies back -- is one launch
-    if (hipGraphLaunch(gentry->exec, st) != hipSuccess) return fail(h, TRX_E_HIP, "hipGraphLaunch");
-    gentry->used = ++h->graph_clock;
-    r_top = gentry->r_top; nchunks = gentry->nchunks; nwalks = gentry->nwalks;
-    h->stats.walk_steps = gentry->walk_steps; h->stats.walk_records = gentry->walk_records; h->stats.walk_record_lanes = gentry->walk_record_lanes;
-    replay_now = false;
-    lap("graph");
-    t_host_queued = std::chrono::steady_clock::now();
-  } else {
-  for (; r_top >= 0; ) {
-    // Step plan.  Layers still to go: down to the previous spectrum's depth when it is known
-    // (retrieval loops re-run near-identical atmospheres), else to the bottom.  The step takes
-    // the layers of ONE kind from r_top down -- walk or two-kernel form -- up to that kind's cap,
-    // in equal parts when more than one step is needed.
+  // Step plan.  Layers still to go: down to the previous spectrum's depth when it is known
+  // (retrieval loops re-run near-identical atmospheres), else to the bottom.  The step takes
+  // the layers of ONE kind from r_top down -- walk or two-kernel form -- up to that kind's cap,
+  // in equal parts when more than one step is needed.
+  auto plan_step = [&](int r_top, bool stop_at_hint, int &nb, int &nc, bool &last_step) {
     const int swept = nr - 1 - r_top;
     int togo = r_top + 1;
     if (!eager && h->hint_layers > swept) togo = std::min(togo, h->hint_layers - swept);
-    int nb = 0, nc;
+    nb = 0;
     if (h->has_grid) nc = std::min(togo, user_chunk ? user_chunk : kMaxChunk);
     else {
       nb = walk_frame_bins(h, psmax, r_top);
@@ -1991,7 +2013,48 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if (!nb && !h->has_grid && nc > sg_layers) nc = sg_layers;
     // the plan's last step (bottom reached, or the depth the previous spectrum needed): its
     // combine and optical depth stay on the walk's queue
-    const bool last_step = r_top - nc < 0 || (stop_at_hint && nr - 1 - (r_top - nc) >= h->hint_layers);
+    last_step = r_top - nc < 0 || (stop_at_hint && nr - 1 - (r_top - nc) >= h->hint_layers);
+  };
+  // ---- the ray tail (trx_tail.hip.h): a hinted eclipse run whose plan is one or two walk steps from
+  // the top ends in ONE kernel behind its walks -- no side queue, no combine / optical depth /
+  // emission launches.  Decided from the plan, which a hinted run knows beforehand.
+  bool tail_mode = false;
+  TailArgs TA{};
+  if (h->ray_tail && vertical && stop_at_hint_ok && !prof && !extras_on && h->ngroups > 0 && h->saved.empty() &&
+      nsh <= 65536 && h->nwn <= kEmisRowsAbove && nsh < 0x7fffffffLL / kTailRays) {
+    int r = nr - 1, steps = 0; bool ok = true;
+    for (; r >= 0 && ok; ) {
+      int nb_, nc_; bool last_;
+      plan_step(r, true, nb_, nc_, last_);
+      if (!nb_ || ++steps > kTailSteps) ok = false;
+      r -= nc_;
+      if (nr - 1 - r >= h->hint_layers) break;
+    }
+    tail_mode = ok && steps >= 1;
+  }
+  const bool tail_direct = tail_mode && gmode == kQueue && spectrum && !d_spectrum && h->tail_direct;
+  if (tail_direct && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
+    if (h->h_spec) (void)hipHostFree(h->h_spec);
+    h->h_spec = nullptr; h->h_spec_bytes = 0;
+    HIPCHK(h, hipHostMalloc(&h->h_spec, sizeof(double) * (size_t)nsh, hipHostMallocDefault));
+    h->h_spec_bytes = sizeof(double) * (size_t)nsh;
+  }
+  bool replay_now = replay;
+  for (;;) {
+  if (replay_now) {
+    // the whole first pass -- inputs, front end, steps, spectrum, copies back -- is one launch
+    if (hipGraphLaunch(gentry->exec, st) != hipSuccess) return fail(h, TRX_E_HIP, "hipGraphLaunch");
+    gentry->used = ++h->graph_clock;
+    r_top = gentry->r_top; nchunks = gentry->nchunks; nwalks = gentry->nwalks;
+    h->stats.walk_steps = gentry->walk_steps; h->stats.walk_records = gentry->walk_records; h->stats.walk_record_lanes = gentry->walk_record_lanes;
+    replay_now = false;
+    lap("graph");
+    t_host_queued = std::chrono::steady_clock::now();
+  } else {
+  for (; r_top >= 0; ) {
+    const int swept = nr - 1 - r_top;
+    int nb = 0, nc = 0; bool last_step = false;
+    plan_step(r_top, stop_at_hint, nb, nc, last_step);
     hipStream_t st_tau = (pipelined && !last_step) ? st_early : st;
     SideWork S;
     bool step_walked = false;
@@ -2016,7 +2079,18 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       bool all_saved = !h->saved.empty();
       for (int c = 0; c < nc && all_saved; c++) all_saved = h->saved[(size_t)(r_top - c)] != 0;
       if (h->ngroups > 0 && !all_saved) {
-        if (nb) {
+        if (nb && tail_mode && !resumed) {
+          // (no combine of its own: its records wait for the tail, each step in its own buffer)
+          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr, nwalks, nullptr, nullptr, nullptr, nullptr, &S.pc);
+          if (!rc) {
+            TailStep &TS = TA.S[TA.nsteps++];
+            TS.P = S.pc.C.P; TS.part = S.pc.C.part; TS.nc = nc;
+            TA.skip = S.pc.C.last;
+            S.pc.valid = false;
+          }
+          nwalks++;
+        }
+        else if (nb) {
           rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, st_tau != st ? st_tau : nullptr, h->ev_ac[nchunks],
                           nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()], &S.pc);
           nwalks++;
@@ -2032,6 +2106,13 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       }
     }
     lap("sweep");
+    if (tail_mode && !resumed) {
+      // the CIA kernels go to their queue behind the first walk (what the device is waiting for)
+      if (nchunks == 0) { if ((rc = queue_cia())) return rc; lap("cia"); }
+      r_top -= nc; nchunks++;
+      if (nr - 1 - r_top >= h->hint_layers) break;
+      continue;
+    }
     // The rest of the step -- its combine, the CIA kernels ahead of the first optical depth, the
     // optical depth itself -- goes to the side queue for every step but the plan's last, and is
     // QUEUED only after the next step's walk: the walks then sit back to back on the main queue
@@ -2056,18 +2137,27 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (capturing && pipelined && !resumed) early_dirty = true;     // (the side queue joined the capture when it waited for the inputs: it must come back)
   if ((rc = join_early())) return rc;
   if (resumed) HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes the spectrum a second time)
-  if (o->solution == TRX_SOL_ECLIPSE) {
-    EmisArgs E{};
-    E.nr = nr; E.nang = o->nangles; E.nsh = nsh; E.lo = h->lo; E.wn_i = h->wn_i; E.wn_d = h->wn_d; E.wn_fct = o->wn_fct;
-    E.tau = h->d_tau.as<double>(); E.last = h->d_last.as<int>(); E.temp = d_tempk;
-    std::vector<double> grid(o->nangles + 1);                    // eclipse.c:262-269
-    grid[0] = 0.0 * kDeg; grid[o->nangles] = 90.0 * kDeg;
-    for (int i = 1; i < o->nangles; i++) grid[i] = (o->angles_deg[i-1] + o->angles_deg[i]) * kDeg / 2.0;
-    for (int i = 0; i < o->nangles; i++) {
-      E.cosang[i] = std::cos(o->angles_deg[i] * kDeg);
-      E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
+  if (tail_mode && !resumed) {
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+    TA.niso = h->niso; TA.gblock = h->d_gblock.as<int32_t>(); TA.e = h->d_e.as<double>();
+    for (int b = 0; b < h->niso && b < 64; b++) if (h->h_gblock[b] != h->h_gblock[b + 1]) TA.blocks |= 1ull << b;
+    int nct = 0;
+    for (int k = 0; k < TA.nsteps; k++) nct += TA.S[k].nc;
+    tau_args(TA.T, nr - 1, nct);
+    emis_args(TA.E);
+    if (tail_direct) {              // spectrum and flags straight into pinned host memory: no copy commands behind the kernel
+      void *dp = nullptr;
+      HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); TA.E.flux = (double *)dp;
+      HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_small, 0)); TA.host_flags = (int *)dp;
     }
-    E.intens = h->d_intens.as<double>(); E.flux = d_out; E.e2tab = h->d_e2tab.as<double>();
+    const dim3 tgrid((unsigned)((nsh + kTailRays - 1) / kTailRays)), tblock(kTailThreads);
+    if (o->nangles <= 8) hipLaunchKernelGGL(k_ray_tail<8>, tgrid, tblock, 0, st, TA);
+    else                 hipLaunchKernelGGL(k_ray_tail<kMaxAngles>, tgrid, tblock, 0, st, TA);
+    if (lap_on) log_msg(TRX_LOG_DEBUG, "run: ray tail over " + std::to_string(TA.nsteps) + " walk steps, " + std::to_string(nct) + " layers");
+  }
+  else if (o->solution == TRX_SOL_ECLIPSE) {
+    EmisArgs E{};
+    emis_args(E);
     if (h->nwn > kEmisRowsAbove)       // (by the job's grid, not the shard: all shards of a job add in the same order)
       hipLaunchKernelGGL(k_emission_rows, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, E);
     else
@@ -2087,6 +2177,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- results back -----------------------------------------------------------
   const bool staged = gmode != kQueue && spectrum && !resumed;     // graph runs: the spectrum goes through the handle's pinned buffer
+  if (!(tail_direct && !resumed))
   {   // one copy into pinned memory: flags, status and (profiled runs) the counters
     const size_t nb = count ? 128 + 24 * (size_t)nr : 128;
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
@@ -2123,7 +2214,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   t_host_queued = std::chrono::steady_clock::now();
   }   // (not replayed)
   {
-    const bool staged = gmode != kQueue && spectrum && !resumed;
+    const bool staged = (gmode != kQueue || tail_direct) && spectrum && !resumed;
     HIPCHK(h, hipStreamSynchronize(st));
     if (staged) std::memcpy(spectrum, h->h_spec, sizeof(double) * (size_t)nsh);
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));
@@ -2132,7 +2223,9 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     else std::fill(counters.begin(), counters.end(), 0ull);
   }
   // rays still descending below the expected depth (the atmosphere changed): go on from there
-  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) { stop_at_hint = false; resumed = true; h->hint_layers = 0; continue; }
+  if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) {
+    stop_at_hint = false; resumed = true; h->hint_layers = 0; continue;
+  }
   break;
   }
 

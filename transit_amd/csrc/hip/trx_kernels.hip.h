@@ -1076,6 +1076,7 @@ struct TauArgs {
   // {2-hratio, hfactor, 2-1/hratio, hsum} from h_k = rad[k+1]-rad[k], and the running
   // Simpson sums of both parities carried from chunk to chunk
   const double *pw;                  // [nr][4]
+  const double *lay;                 // [nr][kVertLay] per-layer constants of the chain (vertical_stage_layers)
   double *acc;                       // [2][nsh]
   // slant rays only.  The reference hands its ray solution b = h*hfct/rfct (tau.c:274), which its
   // object code evaluates as (h*hfct)*(1/rfct): b comes out on the layer radius it was made from
@@ -1446,6 +1447,63 @@ void k_optical_depth(TauArgs T)
 // done (on this part stores and loads share one in-order counter, so a store in the loop would
 // make every wait for a load wait for the store's round trip too).  The chain itself then runs
 // at arithmetic latency.
+// What a chain of vertical rays needs per layer that does not depend on the wavenumber -- {step, t0,
+// twice_sq (parab3_nodes), pair weights p0..p3, rad[rs], 1/step, 1/twice_sq (parab3_recip), t0 + 1.5,
+// rad[rs]^2 (parab3_chain)}, kVertLay doubles per layer, made by the host once per run (T.lay; the kernels used to repeat these
+// divisions in every block, behind two dependent loads) -- goes to LDS for the step's layers:
+// s_lay[kVertLay*c ...] for layer c of the step (ray bottom rs = r_top - c), and the radii
+// s_rad[j] = rad[r_top + 1 - j].  Read per layer from global memory (the same for every lane, but
+// fetched as vector loads) they put a memory round trip -- ~1 us next to a running walk -- into
+// every step of the chain.  The caller synchronises the block afterwards.
+constexpr int kVertLay = 12;
+__device__ __forceinline__ void vertical_stage_layers(const TauArgs &T, double *s_rad, double *s_lay)
+{
+  const int nr = T.nr;
+  for (int j = threadIdx.x; j < T.nc + 3; j += blockDim.x) {
+    const int r = T.r_top + 1 - j;
+    s_rad[j] = (r >= 0 && r < nr) ? T.rad[r] : 0.0;
+  }
+  for (int k = threadIdx.x; k < (T.nc + 1) * kVertLay; k += blockDim.x) {
+    const int c = k / kVertLay, rs = T.r_top - c;
+    s_lay[k] = (c < T.nc && rs >= 0) ? T.lay[(long long)kVertLay * rs + (k - c * kVertLay)] : 0.0;
+  }
+}
+
+// a ray's state between layers: the (edited) extinction of the two layers above the current bottom,
+// and the running Simpson sums A(rs+1), A(rs+2)
+struct VertRay { double y1, y2, a1, a2; };
+
+// One layer of the chain.  SHORT: the 1- and 2-point rays of the top two layers may occur.
+// The two Simpson forms are selected, not branched on, so that consecutive layers make one
+// straight piece of code.
+template <bool SHORT>
+__device__ __forceinline__ void vertical_layer(const TauArgs &T, const double *s_rad, const double *s_lay, int c,
+                                               double yraw, double ybelow, VertRay &R, double &y0, double &tv)
+{
+  const int rs = T.r_top - c, n = T.nr - rs;
+  const double *L = s_lay + kVertLay * c;
+  y0 = yraw;
+  if (SHORT && n == 1) {
+    tv = 0.0;                                           // eclipse.c:45-46
+  } else if (SHORT && n == 2) {                         // eclipse.c:65, 68-80 (value not kept)
+    // needs the layer below: it belongs to this chunk (the first chunk has >= 3 layers)
+    const double yp = parab3(s_rad[c + 2], s_rad[c + 1], ybelow, yraw, R.y1, s_rad[c + 1]);
+    const double *g = T.gw + (long long)rs * T.gstride;
+    tv = T.rad_fct * (((yp * g[0] + ((R.y1 + yp) / 2.0) * g[1] + R.y1 * g[2]) * g[3]) / 6.0);
+  } else {
+    // (the three divisions of a layer as residual-corrected products, trx_numerics.h: the
+    // chain is one wave issuing ~6 clocks per instruction, a division is 13 of them)
+    y0 = parab3_chain(L[0], L[8], L[1], L[10], L[2], L[9], yraw, R.y1, R.y2, L[7], L[11]);   // kept: eclipse.c:66
+    const double a0 = (y0 * L[3] + R.y1 * L[4] + R.y2 * L[5]) * L[6] + R.a2;
+    const bool odd = n & 1;
+    const double sixth = quotient_rn(odd ? a0 : R.a1, 6.0, 1.0 / 6.0);
+    const double with_first = sixth + L[0] * (y0 + R.y1) / 2;
+    tv = T.rad_fct * (odd ? sixth : with_first);
+    R.a2 = R.a1; R.a1 = a0;
+  }
+  R.y2 = R.y1; R.y1 = y0;
+}
+
 template <bool STAGED, bool EXTRAS>      // EXTRAS: a scattering or cloud model is switched on
 __global__ __launch_bounds__(256)
 void k_optical_depth_vertical(TauArgs T)
@@ -1454,44 +1512,18 @@ void k_optical_depth_vertical(TauArgs T)
   latency_critical();
   __shared__ double s_out[STAGED ? 2 * kMaxChunk * 64 : 1];
   __shared__ double s_in[STAGED ? (kMaxChunk + 1) * 64 : 1];
-  // the chunk's radii and pair weights, staged once: read per layer from global memory (the same
-  // for every lane, but fetched as vector loads) they put a memory round trip -- ~1 us next to a
-  // running walk -- into every step of the chain
-  __shared__ double s_rad[kMaxChunk + 3];                  // s_rad[j] = rad[r_top + 1 - j]
-  // per layer c of the chunk (ray bottom rs = r_top - c), everything the chain needs that does not
-  // depend on the wavenumber: {step, t0, twice_sq (parab3_nodes), pair weights p0..p3, rad[rs],
-  // 1/step, 1/twice_sq (parab3_recip)}
-  constexpr int kLay = 10;
-  __shared__ double s_lay[(kMaxChunk + 1) * kLay];
+  __shared__ double s_rad[kMaxChunk + 3];
+  __shared__ double s_lay[(kMaxChunk + 1) * kVertLay];
   const int nr = T.nr;
-  for (int j = threadIdx.x; j < T.nc + 3; j += blockDim.x) {
-    const int r = T.r_top + 1 - j;
-    s_rad[j] = (r >= 0 && r < nr) ? T.rad[r] : 0.0;
-  }
-  for (int c = threadIdx.x; c <= T.nc; c += blockDim.x) {
-    const int rs = T.r_top - c;
-    double *L = s_lay + kLay * c;
-    for (int q = 0; q < kLay; q++) L[q] = 0.0;
-    if (c < T.nc && rs >= 0) {
-      if (rs + 1 < nr) {                                   // (the 3+ point rays: nodes rad[rs], rad[rs+1])
-        const double step = T.rad[rs + 1] - T.rad[rs];
-        L[0] = step; L[1] = T.rad[rs] / step; L[2] = 2.0 * step * step;
-        L[8] = 1.0 / step; L[9] = 1.0 / L[2];
-      }
-      for (int q = 0; q < 4; q++) L[3 + q] = T.pw[4 * rs + q];
-      L[7] = T.rad[rs];
-    }
-  }
+  vertical_stage_layers(T, s_rad, s_lay);
   __syncthreads();
   int nstill = 0, deep = 0;
   for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < T.nsh; w += (long long)gridDim.x * blockDim.x) {
   if (T.last[w] < 0) {
     bool still = true;
-    double a1 = T.acc[w], a2 = T.acc[T.nsh + w];          // A(rs+1), A(rs+2) on entry of a step
-    // y1, y2: (edited) extinction of the two layers above the current bottom
-    double y1 = 0, y2 = 0;
-    if (T.r_top + 1 < nr) y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
-    if (T.r_top + 2 < nr) y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
+    VertRay R{0.0, 0.0, T.acc[w], T.acc[T.nsh + w]};      // A(rs+1), A(rs+2) on entry of a step
+    if (T.r_top + 1 < nr) R.y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
+    if (T.r_top + 2 < nr) R.y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
     double xfs = 0.0, xfc = 0.0;                           // this ray's wavenumber factors of the two models
     if (EXTRAS) { xfs = T.xf_scat[w]; xfc = T.xf_cloud[w]; }
     auto total_ext = [&](int c) -> double {
@@ -1510,33 +1542,6 @@ void k_optical_depth_vertical(TauArgs T)
       // total extinction of the layers ahead is requested six steps before it is used
       q0 = total_ext(0); q1 = total_ext(1); q2 = total_ext(2); q3 = total_ext(3); q4 = total_ext(4); q5 = total_ext(5);
     }
-    // One layer of the chain.  SHORT: the 1- and 2-point rays of the top two layers may occur.
-    // The two Simpson forms are selected, not branched on, so that consecutive layers make one
-    // straight piece of code.
-    auto layer = [&](auto short_rays, int c, double yraw, double ybelow, double &y0, double &tv) {
-      const int rs = T.r_top - c, n = nr - rs;
-      const double *L = s_lay + kLay * c;
-      y0 = yraw;
-      if (decltype(short_rays)::value && n == 1) {
-        tv = 0.0;                                           // eclipse.c:45-46
-      } else if (decltype(short_rays)::value && n == 2) {   // eclipse.c:65, 68-80 (value not kept)
-        // needs the layer below: it belongs to this chunk (the first chunk has >= 3 layers)
-        const double yp = parab3(s_rad[c + 2], s_rad[c + 1], ybelow, yraw, y1, s_rad[c + 1]);
-        const double *g = T.gw + (long long)rs * T.gstride;
-        tv = T.rad_fct * (((yp * g[0] + ((y1 + yp) / 2.0) * g[1] + y1 * g[2]) * g[3]) / 6.0);
-      } else {
-        // (the three divisions of a layer as residual-corrected products, trx_numerics.h: the
-        // chain is one wave issuing ~6 clocks per instruction, a division is 13 of them)
-        y0 = parab3_recip(L[0], L[8], L[1], L[2], L[9], yraw, y1, y2, L[7]);   // kept: eclipse.c:66
-        const double a0 = (y0 * L[3] + y1 * L[4] + y2 * L[5]) * L[6] + a2;
-        const bool odd = n & 1;
-        const double sixth = quotient_rn(odd ? a0 : a1, 6.0, 1.0 / 6.0);
-        const double with_first = sixth + L[0] * (y0 + y1) / 2;
-        tv = T.rad_fct * (odd ? sixth : with_first);
-        a2 = a1; a1 = a0;
-      }
-      y2 = y1; y1 = y0;
-    };
     int done = 0;
     if constexpr (STAGED) {
       // A ray ends at the first layer whose optical depth passes toomuch (tau.c:277-287, 299-304),
@@ -1547,7 +1552,7 @@ void k_optical_depth_vertical(TauArgs T)
       bool alive = true;
       auto one = [&](auto short_rays, int c) {
         double y0, tv;
-        layer(short_rays, c, s_in[c * 64 + threadIdx.x], s_in[(c + 1) * 64 + threadIdx.x], y0, tv);
+        vertical_layer<decltype(short_rays)::value>(T, s_rad, s_lay, c, s_in[c * 64 + threadIdx.x], s_in[(c + 1) * 64 + threadIdx.x], R, y0, tv);
         s_out[(2 * c) * 64 + threadIdx.x] = y0; s_out[(2 * c + 1) * 64 + threadIdx.x] = tv;
         const int ri = nr - 1 - (T.r_top - c);
         done += alive;                                                    // (no short cuts: no branches)
@@ -1572,12 +1577,12 @@ void k_optical_depth_vertical(TauArgs T)
         const double yraw = q0, ybelow = q1;
         q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6);
         double y0, tv;
-        layer(std::true_type(), c, yraw, ybelow, y0, tv);
+        vertical_layer<true>(T, s_rad, s_lay, c, yraw, ybelow, R, y0, tv);
         T.er[(long long)rs * T.nsh + w] = y0; T.tau[(long long)ri * T.nsh + w] = tv;
         if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
       }
     }
-    T.acc[w] = a1; T.acc[T.nsh + w] = a2;
+    T.acc[w] = R.a1; T.acc[T.nsh + w] = R.a2;
     nstill += still;
   }
   if (T.last[w] >= 0) deep = max(deep, T.last[w] + 1);
@@ -1613,37 +1618,31 @@ __device__ __forceinline__ double planck_from(double num, double x, const double
 // exponentials: 38 us of pure latency at the end of every spectrum.)
 constexpr int kEmisWaves = 4;
 
-__global__ __launch_bounds__(64 * kEmisWaves)
-void k_emission(EmisArgs E)
+// one ray by one wavefront; tau_at(i): optical depth at height i of this ray; s_e2: 2^(j/64) in LDS
+// (NANG: the angles the instantiation holds state for -- 16 of them are 96 registers)
+template <int NANG = kMaxAngles, class TauAt>
+__device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
 {
-  latency_critical();
-  __shared__ double s_e2[64];                 // 2^(j/64) for exp_neg (the kernels' own exponential, ~1.5 ulp)
-  if (threadIdx.x < 64) s_e2[threadIdx.x] = E.e2tab[threadIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const long long w = (long long)blockIdx.x * kEmisWaves + (threadIdx.x >> 6);     // wave-uniform
-  if (w >= E.nsh) return;
   const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
-  const int last = __builtin_amdgcn_readfirstlane(E.last[w]);      // (< 0: the ray is still descending -- provisional spectrum, zero)
   const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
   const double pl_exp = kH * wv * kLs;
-  double sum[kMaxAngles], dt_c[kMaxAngles], dt_last[kMaxAngles];
+  double sum[NANG], dt_c[NANG], dt_last[NANG];
 #pragma unroll
-  for (int a = 0; a < kMaxAngles; a++) { sum[a] = 0.0; dt_c[a] = 0.0; dt_last[a] = 0.0; }
+  for (int a = 0; a < NANG; a++) { sum[a] = 0.0; dt_c[a] = 0.0; dt_last[a] = 0.0; }
   double B_c = 0.0, B_last = 0.0;             // carry: the previous pass's last height
   for (int i0 = 0; i0 <= last; i0 += 64) {
     const int i = i0 + lane;
     const bool have = i <= last;
     double B = 0.0, tv = 0.0;
     if (have) {
-      tv = E.tau[(long long)i * E.nsh + w];
+      tv = tau_at(i);
       B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
     }
     double Bp = __shfl_up(B, 1, 64);
     if (lane == 0) Bp = B_c;
     const int top = min(63, last - i0);        // lane of the pass's last height
 #pragma unroll
-    for (int a = 0; a < kMaxAngles; a++) {
+    for (int a = 0; a < NANG; a++) {
       if (a < E.nang) {
         const double dt = have ? exp_neg(-tv / E.cosang[a], s_e2) : 0.0;
         double dtp = __shfl_up(dt, 1, 64);
@@ -1660,7 +1659,7 @@ void k_emission(EmisArgs E)
   // sum, B_last and dt_last are wave-uniform: lane a writes angle a, lane 0 the flux in angle order
   double fl = 0.0;
 #pragma unroll
-  for (int a = 0; a < kMaxAngles; a++) {
+  for (int a = 0; a < NANG; a++) {
     if (a < E.nang) {
       const double I = B_last * dt_last[a] - 0.5 * sum[a];
       if (lane == a) E.intens[(long long)a * E.nsh + w] = I;
@@ -1668,6 +1667,20 @@ void k_emission(EmisArgs E)
     }
   }
   if (lane == 0) E.flux[w] = fl;
+}
+
+__global__ __launch_bounds__(64 * kEmisWaves)
+void k_emission(EmisArgs E)
+{
+  latency_critical();
+  __shared__ double s_e2[64];                 // 2^(j/64) for exp_neg (the kernels' own exponential, ~1.5 ulp)
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = E.e2tab[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * kEmisWaves + (threadIdx.x >> 6);     // wave-uniform
+  if (w >= E.nsh) return;
+  const int last = __builtin_amdgcn_readfirstlane(E.last[w]);      // (< 0: the ray is still descending -- provisional spectrum, zero)
+  emission_ray(E, w, last, lane, s_e2, [&](int i) { return E.tau[(long long)i * E.nsh + w]; });
 }
 
 // The same for large grids (more than kEmisRowsAbove wavenumbers in the JOB's grid, so that every

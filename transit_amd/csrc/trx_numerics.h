@@ -119,6 +119,19 @@ TRX_HD double parab3_recip(double step, double r_step, double t0, double twice_s
   return at * at * quad + at * lin + cst;
 }
 
+// parab3_recip with the two node-only factors of its polynomial handed in too (t0p = t0 + 1.5,
+// at_sq = at * at: the very sub-expressions of parab3, so the same bits) -- a chain of parabolas,
+// each fed by the one before, issues what is left and nothing else.
+TRX_HD double parab3_chain(double step, double r_step, double t0, double t0p, double twice_sq, double r_twice_sq,
+                           double v0, double v1, double v2, double at, double at_sq)
+{
+  const double bend = v0 + v2 - 2*v1;
+  const double quad = quotient_rn(bend, twice_sq, r_twice_sq);
+  const double lin  = quotient_rn(v2 - v1 - t0p * bend, step, r_step);
+  const double cst  = v0 + t0 * (v2 - 4*v1 + 3*v0 + t0 * bend) / 2.0;
+  return at_sq * quad + at * lin + cst;
+}
+
 // pu/src/spline.c:12-48 + 186-206 (tri / spline_init).  Scratch arrays u, v of
 // length n are supplied by the caller (no allocation: usable in a kernel).
 // Strided access so that a kernel can keep column-major scratch.
