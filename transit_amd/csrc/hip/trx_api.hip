@@ -81,6 +81,7 @@ struct trx_handle {
   // the walk's copy: phase-major rows of whole cache lines (walk_row_layout), one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
+  std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
@@ -697,6 +698,32 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
 
 // Simpson weights of one abscissa (numerical.c:390-425 geth, 486-495 makeh):
 // per interval pair {2-hratio, hfactor, 2-1/hratio, hsum}; h0 = first interval.
+// 1 / d for quotient_rn(x, d, 1/d) in place of x / d -- if that IS the division for this divisor:
+// Markstein's theorem leaves out divisors with a mantissa of all ones, so the product form is
+// compared with the division on a few thousand numerators of every magnitude an optical depth takes,
+// exact multiples and their neighbours among them; any difference: 0 (the kernel divides).  Once per
+// divisor and handle (a run's angles rarely change).
+double checked_reciprocal(trx_handle *h, double d)
+{
+  for (auto &kv : h->recip_ok) if (kv.first == d) return kv.second;
+  double rd = (d > 0 && std::isfinite(d)) ? 1.0 / d : 0.0;
+  if (rd != 0.0) {
+    uint64_t st = 0x9e3779b97f4a7c15ull ^ (uint64_t)(d * 1e15);
+    for (int k = 0; k < 4096 && rd != 0.0; k++) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      const double m = 1.0 + (double)(st >> 11) * 0x1.0p-53;                     // mantissa in [1, 2)
+      const int ex = (int)((st >> 3) % 120) - 100;                                // 2^-100 .. 2^19
+      double x = std::ldexp(m, ex);
+      if (k % 4 == 1) x = std::ldexp((double)(1 + (st >> 40) % 4096), ex) * d;    // (near) exact multiples of the divisor
+      if (k % 4 == 2) x = std::nextafter(std::ldexp((double)(1 + (st >> 40) % 4096), ex) * d, 0.0);
+      if (quotient_rn(-x, d, rd) != -x / d) rd = 0.0;
+    }
+  }
+  if (h->recip_ok.size() >= 64) h->recip_ok.clear();
+  h->recip_ok.emplace_back(d, rd);
+  return rd;
+}
+
 void simpson_weights(const double *x, int n, double *row, double *h0)
 {
   *h0 = (n >= 2) ? x[1] - x[0] : 0.0;
@@ -1923,6 +1950,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     for (int i = 0; i < o->nangles; i++) {
       E.cosang[i] = std::cos(o->angles_deg[i] * kDeg);
       E.area[i] = std::pow(std::sin(grid[i+1]), 2.0) - std::pow(std::sin(grid[i]), 2.0);
+      E.rcos[i] = checked_reciprocal(h, E.cosang[i]);
     }
     E.intens = h->d_intens.as<double>(); E.flux = d_out; E.e2tab = h->d_e2tab.as<double>();
   };
@@ -2032,8 +2060,9 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     }
     tail_mode = ok && steps >= 1;
   }
-  const bool tail_direct = tail_mode && gmode == kQueue && spectrum && !d_spectrum && h->tail_direct;
-  if (tail_direct && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
+  // (flags into the pinned block the host reads; the spectrum into pinned memory too when the caller wants it on the host)
+  const bool tail_direct = tail_mode && gmode == kQueue && h->tail_direct, tail_spec = tail_direct && spectrum && !d_spectrum;
+  if (tail_spec && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
     if (h->h_spec) (void)hipHostFree(h->h_spec);
     h->h_spec = nullptr; h->h_spec_bytes = 0;
     HIPCHK(h, hipHostMalloc(&h->h_spec, sizeof(double) * (size_t)nsh, hipHostMallocDefault));
@@ -2147,7 +2176,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     emis_args(TA.E);
     if (tail_direct) {              // spectrum and flags straight into pinned host memory: no copy commands behind the kernel
       void *dp = nullptr;
-      HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); TA.E.flux = (double *)dp;
+      if (tail_spec) { HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); TA.E.flux = (double *)dp; }
       HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_small, 0)); TA.host_flags = (int *)dp;
     }
     const dim3 tgrid((unsigned)((nsh + kTailRays - 1) / kTailRays)), tblock(kTailThreads);
@@ -2177,11 +2206,10 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   // ---- results back -----------------------------------------------------------
   const bool staged = gmode != kQueue && spectrum && !resumed;     // graph runs: the spectrum goes through the handle's pinned buffer
-  if (!(tail_direct && !resumed))
   {   // one copy into pinned memory: flags, status and (profiled runs) the counters
     const size_t nb = count ? 128 + 24 * (size_t)nr : 128;
-    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
-    if (spectrum) HIPCHK(h, hipMemcpyAsync(staged ? h->h_spec : (void *)spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
+    if (!(tail_direct && !resumed)) HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
+    if (spectrum && !(tail_spec && !resumed)) HIPCHK(h, hipMemcpyAsync(staged ? h->h_spec : (void *)spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
     lap("spectrum+copies");
   }
   if (capturing && !resumed) {
@@ -2214,7 +2242,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   t_host_queued = std::chrono::steady_clock::now();
   }   // (not replayed)
   {
-    const bool staged = (gmode != kQueue || tail_direct) && spectrum && !resumed;
+    const bool staged = (gmode != kQueue || tail_spec) && spectrum && !resumed;
     HIPCHK(h, hipStreamSynchronize(st));
     if (staged) std::memcpy(spectrum, h->h_spec, sizeof(double) * (size_t)nsh);
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));

@@ -1598,10 +1598,18 @@ struct EmisArgs {
   double wn_i, wn_d, wn_fct;
   const double *tau; const int *last; const double *temp;
   double cosang[kMaxAngles], area[kMaxAngles];
+  double rcos[kMaxAngles];           // 1 / cosang where the host has checked that quotient_rn(x, cos, 1/cos) is the division (else 0: divide)
   double *intens;                    // [nang][nsh]
   double *flux;                      // [nsh]
   const double *e2tab;               // [64] 2^(j/64)
 };
+
+// -tau / cos(angle) (eclipse.c:140): the correctly rounded quotient either way -- five multiply-adds
+// with the reciprocal the host has made and checked (trx_numerics.h quotient_rn), or the division
+__device__ __forceinline__ double slant_depth(const EmisArgs &E, int a, double tv)
+{
+  return E.rcos[a] != 0.0 ? quotient_rn(-tv, E.cosang[a], E.rcos[a]) : -tv / E.cosang[a];      // (wave-uniform choice)
+}
 
 // B = num / (e^x - 1) = num e^-x / (1 - e^-x),  x = h nu / k T > 0, with the kernels' own exponential
 __device__ __forceinline__ double planck_from(double num, double x, const double *e2tab)
@@ -1644,7 +1652,7 @@ __device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int
 #pragma unroll
     for (int a = 0; a < NANG; a++) {
       if (a < E.nang) {
-        const double dt = have ? exp_neg(-tv / E.cosang[a], s_e2) : 0.0;
+        const double dt = have ? exp_neg(slant_depth(E, a, tv), s_e2) : 0.0;
         double dtp = __shfl_up(dt, 1, 64);
         if (lane == 0) dtp = dt_c[a];
         const double term = (have && i > 0) ? (dt - dtp) * (B + Bp) : 0.0;
@@ -1712,7 +1720,7 @@ void k_emission_rows(EmisArgs E)
 #pragma unroll
     for (int a = 0; a < kMaxAngles; a++) {
       if (a < E.nang) {
-        const double dt = exp_neg(-tv / E.cosang[a], s_e2);
+        const double dt = exp_neg(slant_depth(E, a, tv), s_e2);
         if (i > 0) sum[a] += (dt - dtp[a]) * (B + Bp);
         dtp[a] = dt;
       }
