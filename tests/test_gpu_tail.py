@@ -1,4 +1,4 @@
-"""k_ray_tail (trx_tail.hip.h: a hinted eclipse run's combines, optical depths and emission as ONE
+"""k_ray_tail (trx_tail.hip.h: a hinted run's combines, optical depths and emission / modulation as ONE
 kernel behind its walks) against the step kernels it stands for (TRX_RAY_TAIL=0): the same
 operations on the same values, so the same BITS in every output -- extinction, edited extinction,
 optical depth, stopping heights, intensities, spectrum -- on goldens, on a demo-shaped case (two
@@ -16,7 +16,7 @@ from transit_amd.host import Problem
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("e", "e_cs", "tau", "last", "intens", "computed", "er")
+KEYS = ("e", "e_cs", "tau", "last", "intens", "computed", "er", "e_scat", "e_cloud")
 
 
 def engines(P):
@@ -32,7 +32,7 @@ def assert_same(ra, rb, note=None):
     sw = ra["computed"].astype(bool) if "computed" in ra else slice(None)
     assert set(ra) == set(rb)
     for k in ra:
-        if k in ("e", "e_cs"):
+        if k in ("e", "e_cs", "e_scat", "e_cloud"):
             assert np.array_equal(ra[k][sw], rb[k][sw]), (k, note)
         elif k == "er":
             # (edited extinction: written down to the ray's stopping height only)
@@ -52,11 +52,10 @@ def tail_runs(msgs):
     return sum("ray tail over" in m for m in msgs)
 
 
-@pytest.mark.parametrize("case", ["eclipse_small", "coadd_thresh", "multi_species", "many_isotopes", "midres_os4"])
+@pytest.mark.parametrize("case", ["eclipse_small", "coadd_thresh", "multi_species", "many_isotopes", "midres_os4", "scat_polar", "qscale_eclipse",
+                                  "transit_small", "cloud_scatter", "resample_transit", "transit_modm1", "dumps_transit"])
 def test_tail_on_goldens(case):
     P = Problem.from_cfg(os.path.join(GOLDEN, case, "case.cfg"))
-    if P.opts.solution != 0:
-        pytest.skip("transit geometry: the step kernels")
     msgs = []
     engine.set_log(lambda lvl, m: msgs.append(m), 5)
     t, r = engines(P)
@@ -74,11 +73,12 @@ def test_tail_on_goldens(case):
         t.close(); r.close()
 
 
-@pytest.mark.parametrize("ncia,nlayers", [(0, 100), (2, 100), (1, 40), (0, 7)])
-def test_tail_demo_shape_moving_atmosphere_and_shards(tmp_path, ncia, nlayers):
+@pytest.mark.parametrize("ncia,nlayers,solution", [(0, 100, "eclipse"), (2, 100, "eclipse"), (1, 40, "eclipse"), (0, 7, "eclipse"),
+                                                   (2, 100, "transit"), (0, 40, "transit"), (1, 9, "transit")])
+def test_tail_demo_shape_moving_atmosphere_and_shards(tmp_path, ncia, nlayers, solution):
     d = str(tmp_path / "c")
     synth.make_case(d, nlines=120_000, wnlow=2500, wnhigh=2800, wndelt=1.0, wnosamp=2160, nlayers=nlayers,
-                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=11, ncia=ncia)
+                    solution=solution, toomuch=10.0, ethresh=1e-50, seed=11, ncia=ncia)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
     dens = np.ctypeslib.as_array(P.atm.density, shape=(P.static.nmol * P.nlayer,))
     base = dens.copy()
@@ -143,3 +143,25 @@ def test_tail_with_copy_commands_instead_of_pinned_outputs(tmp_path):
     finally:
         dens[:] = base
         t.close(); r.close(); c.close()
+
+
+@pytest.mark.parametrize("solution", ["eclipse", "transit"])
+@pytest.mark.parametrize("extra", [{"cloudtop": "-2.0", "scattering": "1.5"}, {"scattering": "polar"}])
+def test_tail_with_cloud_and_scattering_models(tmp_path, extra, solution):
+    """extinction.c:587-693 switched on: the tail adds the layer parts of both models to the line and
+    CIA extinction in the order of tau.c:231-232, like the step kernels."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=60_000, wnlow=2500, wnhigh=2700, wndelt=1.0, wnosamp=2160, nlayers=90,
+                    solution=solution, toomuch=10.0, ethresh=1e-50, seed=3, ncia=1, extra=extra)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    t, r = engines(P)
+    try:
+        for k in range(3):
+            a, b = t.run(P.atm, P.opts, debug=KEYS), r.run(P.atm, P.opts, debug=KEYS)
+            assert_same(a, b, (extra, k))
+    finally:
+        engine.set_log(None)
+        t.close(); r.close()
+    assert tail_runs(msgs) >= 2

@@ -1954,6 +1954,11 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     }
     E.intens = h->d_intens.as<double>(); E.flux = d_out; E.e2tab = h->d_e2tab.as<double>();
   };
+  auto mod_args = [&](ModArgs &M) {
+    M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
+    M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
+    M.ip = d_ipv; M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
+  };
   struct SideWork { bool active = false, first = false; int r_top = 0, nc = 0, swept = 0; hipStream_t st_tau = nullptr; PendingCombine pc; };
   SideWork pending;
   auto run_side = [&](SideWork &S) -> int {
@@ -2048,7 +2053,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // emission launches.  Decided from the plan, which a hinted run knows beforehand.
   bool tail_mode = false;
   TailArgs TA{};
-  if (h->ray_tail && vertical && stop_at_hint_ok && !prof && !extras_on && h->ngroups > 0 && h->saved.empty() &&
+  if (h->ray_tail && stop_at_hint_ok && !prof && h->ngroups > 0 && h->saved.empty() &&
       nsh <= 65536 && h->nwn <= kEmisRowsAbove && nsh < 0x7fffffffLL / kTailRays) {
     int r = nr - 1, steps = 0; bool ok = true;
     for (; r >= 0 && ok; ) {
@@ -2173,15 +2178,23 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     int nct = 0;
     for (int k = 0; k < TA.nsteps; k++) nct += TA.S[k].nc;
     tau_args(TA.T, nr - 1, nct);
-    emis_args(TA.E);
+    if (vertical) emis_args(TA.E); else mod_args(TA.M);
     if (tail_direct) {              // spectrum and flags straight into pinned host memory: no copy commands behind the kernel
       void *dp = nullptr;
-      if (tail_spec) { HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); TA.E.flux = (double *)dp; }
+      if (tail_spec) { HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); (vertical ? TA.E.flux : TA.M.out) = (double *)dp; }
       HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_small, 0)); TA.host_flags = (int *)dp;
     }
     const dim3 tgrid((unsigned)((nsh + kTailRays - 1) / kTailRays)), tblock(kTailThreads);
-    if (o->nangles <= 8) hipLaunchKernelGGL(k_ray_tail<8>, tgrid, tblock, 0, st, TA);
-    else                 hipLaunchKernelGGL(k_ray_tail<kMaxAngles>, tgrid, tblock, 0, st, TA);
+    if (!vertical) {
+      if (extras_on) hipLaunchKernelGGL((k_ray_tail<0, true>), tgrid, tblock, 0, st, TA);
+      else           hipLaunchKernelGGL((k_ray_tail<0, false>), tgrid, tblock, 0, st, TA);
+    } else if (extras_on) {
+      if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, true>), tgrid, tblock, 0, st, TA);
+      else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, true>), tgrid, tblock, 0, st, TA);
+    } else {
+      if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, false>), tgrid, tblock, 0, st, TA);
+      else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, false>), tgrid, tblock, 0, st, TA);
+    }
     if (lap_on) log_msg(TRX_LOG_DEBUG, "run: ray tail over " + std::to_string(TA.nsteps) + " walk steps, " + std::to_string(nct) + " layers");
   }
   else if (o->solution == TRX_SOL_ECLIPSE) {
@@ -2193,9 +2206,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       hipLaunchKernelGGL(k_emission, dim3((unsigned)((nsh + kEmisWaves - 1) / kEmisWaves)), dim3(64 * kEmisWaves), 0, st, E);
   } else {
     ModArgs M{};
-    M.nr = nr; M.modlevel = o->modlevel; M.transparent = o->transparent; M.nsh = nsh; M.toomuch = o->toomuch;
-    M.ip_fct = a->rad_fct; M.srad = o->starrad_cm; M.tau = h->d_tau.as<double>(); M.last = h->d_last.as<int>();
-    M.ip = d_ipv; M.gw = d_mw; M.gstride = gstride; M.gh0 = d_mh0; M.out = d_out; M.status = h->d_status.as<int>();
+    mod_args(M);
     if (h->nwn > kEmisRowsAbove)
       hipLaunchKernelGGL(k_modulation_rows, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, M);
     else

@@ -1273,6 +1273,60 @@ void k_slant_geometry(SlantGeomArgs G)
   }
 }
 
+// The two per-height pieces of a slant ray's optical depth (slantpath.c:55-107), with the total
+// extinction of layer L handed in as er(L) -- global memory, a block's LDS tile, or k_ray_tail's.
+// slantpath.c:55-58: extinction at the closest-approach radius r0, a parabola through the bracket's
+// lowest layer rs (value ylow: what that layer holds at this point of the sweep) and the two above it
+template <class ErOf>
+__device__ __forceinline__ double slant_bottom(const TauArgs &T, int rs, double r0, double ylow, ErOf er)
+{
+  if (T.nr - rs == 2) return parab3(T.rad[rs-1], T.rad[rs], er(rs - 1), ylow, er(rs + 1), r0);
+  return parab3(T.rad[rs], T.rad[rs+1], ylow, er(rs + 1), er(rs + 2), r0);
+}
+// slantpath.c:62-107: Simpson over the point set {r0, rad[rs+1], ...} with the weights of height k
+// (TauArgs.gw/gh0); returns the integral over half the chord (the caller doubles it)
+template <class ErOf>
+__device__ __forceinline__ double slant_integral(const TauArgs &T, int k, int rs, double y0, ErOf er)
+{
+  const int n = T.nr - rs;
+  const double *g = T.gw + (long long)k * T.gstride;            // weights of THIS height's point set
+  double res;
+  if (n == 2) {                                       // slantpath.c:62-74
+    const double y2 = er(rs + 1);
+    const double y1 = (y2 + y0) / 2.0;
+    res = ((y0 * g[0] + y1 * g[1] + y2 * g[2]) * g[3]) / 6.0;
+  } else {
+    const int even = (n % 2 == 0);
+    double acc = 0.0;
+    const int npair = (n - 1) / 2;
+    // four interval pairs per trip: their nine points and sixteen weights are requested together
+    // (pair by pair, every trip waited for its own loads -- ~30 round trips for a deep ray), the
+    // sum keeps the pairs' order
+    double gn[16];                                     // the NEXT trip's weights, requested a trip ahead
+#pragma unroll
+    for (int q = 0; q < 16; q++) gn[q] = g[4 * min(q / 4, npair - 1) + (q & 3)];
+    for (int i0 = 0; i0 < npair; i0 += 4) {
+      const int jb = 2 * i0 + even;
+      double yv[9], gg[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) gg[q] = gn[q];
+      if (i0 + 4 < npair) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) gn[q] = g[4 * min(i0 + 4 + q / 4, npair - 1) + (q & 3)];
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) yv[q] = er(rs + min(jb + q, n - 1));
+      if (jb == 0) yv[0] = y0;
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + u < npair) acc += (yv[2*u] * gg[4*u] + yv[2*u+1] * gg[4*u+1] + yv[2*u+2] * gg[4*u+2]) * gg[4*u+3];
+    }
+    res = acc / 6.0;
+    if (even) res += T.gh0[k] * (y0 + er(rs + 1)) / 2;
+  }
+  return res;
+}
+
 // Heights are visited top-down, a chunk of layers per launch (tau.c:235-290).
 // A 256-thread block owns 256/kTauH wavenumbers x kTauH heights:
 //   phase 1 (one lane per wavenumber): total extinction of the chunk's layers
@@ -1340,15 +1394,12 @@ void k_optical_depth(TauArgs T)
     const int rs = (int)T.hrs[k];
     double y0 = 0.0;
     if (rs >= 0) {
-      const int n = nr - rs;
       const double r0 = T.hr0[k];
-      const double *y = T.er + (long long)rs * T.nsh + w;
       double ylow;
-      if (rs >= r_low) ylow = y[0];
+      if (rs >= r_low) ylow = T.er[(long long)rs * T.nsh + w];
       else if (EXTRAS) ylow = scat_layer(T, rs, T.xf_scat[w]) + cloud_layer(T, rs, T.xf_cloud[w]) + T.ecs[(long long)rs * T.nsh + w];
       else             ylow = T.ecs[(long long)rs * T.nsh + w];
-      if (n == 2) y0 = parab3(T.rad[rs-1], T.rad[rs], T.er[(long long)(rs - 1) * T.nsh + w], ylow, y[T.nsh], r0);
-      else        y0 = parab3(T.rad[rs], T.rad[rs+1], ylow, y[T.nsh], y[2*T.nsh], r0);
+      y0 = slant_bottom(T, rs, r0, ylow, [&](int L) { return T.er[(long long)L * T.nsh + w]; });
     }
     s_y0[c][wi] = y0;
   }
@@ -1364,49 +1415,10 @@ void k_optical_depth(TauArgs T)
     } else if (rs < 0) {
       t = nan(""); *T.status = 3;                         // slantpath.c:39-44: the reference exits here
     } else {
-      const int n = nr - rs;
-      const double *y = T.er + (long long)rs * T.nsh + w;           // y[j*nsh] = er[rs+j][w]
-      const double *g = T.gw + (long long)k * T.gstride;            // weights of THIS height's point set
       const double y0 = s_y0[c][wi];
       double res;
-      if (n == 2) {                                       // slantpath.c:62-74
-        const double y2 = y[T.nsh];
-        const double y1 = (y2 + y0) / 2.0;
-        res = ((y0 * g[0] + y1 * g[1] + y2 * g[2]) * g[3]) / 6.0;
-      } else {
-        const int even = (n % 2 == 0);
-        double acc = 0.0;
-        const int npair = (n - 1) / 2;
-        // four interval pairs per trip: their nine points and sixteen weights are requested together
-        // (pair by pair, every trip waited for its own loads -- ~30 round trips for a deep ray), the
-        // sum keeps the pairs' order
-        double gn[16];                                     // the NEXT trip's weights, requested a trip ahead
-#pragma unroll
-        for (int q = 0; q < 16; q++) gn[q] = g[4 * min(q / 4, npair - 1) + (q & 3)];
-        for (int i0 = 0; i0 < npair; i0 += 4) {
-          const int jb = 2 * i0 + even;
-          double yv[9], gg[16];
-#pragma unroll
-          for (int q = 0; q < 16; q++) gg[q] = gn[q];
-          if (i0 + 4 < npair) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) gn[q] = g[4 * min(i0 + 4 + q / 4, npair - 1) + (q & 3)];
-          }
-          if (staged) {
-#pragma unroll
-            for (int q = 0; q < 9; q++) yv[q] = s_y[max(rs + min(jb + q, n - 1) - r_low, 0)][wi];     // (row rs itself: only as yv[0], replaced below)
-          } else {
-#pragma unroll
-            for (int q = 0; q < 9; q++) yv[q] = y[(long long)min(jb + q, n - 1) * T.nsh];
-          }
-          if (jb == 0) yv[0] = y0;
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (i0 + u < npair) acc += (yv[2*u] * gg[4*u] + yv[2*u+1] * gg[4*u+1] + yv[2*u+2] * gg[4*u+2]) * gg[4*u+3];
-        }
-        res = acc / 6.0;
-        if (even) res += T.gh0[k] * (y0 + y[T.nsh]) / 2;
-      }
+      if (staged) res = slant_integral(T, k, rs, y0, [&](int L) { return s_y[max(L - r_low, 0)][wi]; });      // (row rs itself: only as the first point, replaced by y0)
+      else        res = slant_integral(T, k, rs, y0, [&](int L) { return T.er[(long long)L * T.nsh + w]; });
       t = 2 * res;                                        // slantpath.c:107
     }
     s_tv[c][wi] = T.rad_fct * t;
@@ -1757,43 +1769,39 @@ struct ModArgs {
 // three exponentials each was 40 us of latency at the end of every transmission spectrum.)
 constexpr int kModWaves = 4;
 
-__global__ __launch_bounds__(64 * kModWaves)
-void k_modulation(ModArgs M)
+// one ray by one wavefront; tau_at(i): optical depth at height i of this ray; status codes are
+// raised with an atomic maximum (several rays may raise them at once; k_ray_tail reads the word back)
+template <class TauAt>
+__device__ __forceinline__ void modulation_ray(const ModArgs &M, long long w, int last, int lane, TauAt tau_at)
 {
-  latency_critical();
-  const int lane = threadIdx.x & 63;
-  const long long w = (long long)blockIdx.x * kModWaves + (threadIdx.x >> 6);      // wave-uniform
-  if (w >= M.nsh) return;
   const int nr = M.nr;
-  const int last = __builtin_amdgcn_readfirstlane(M.last[w]);
   // a ray that is still descending (only possible in the provisional spectrum of a run that
   // stopped at the previous run's depth and will go on): nothing to integrate yet
   if (last < 0) { if (lane == 0) M.out[w] = 0.0; return; }
-  const double *tw = M.tau + w;                           // tw[i*nsh] = tau[i][w]
   if (M.modlevel == -1) {
     if (lane != 0) return;
-    const double tl = tw[(long long)last * M.nsh];
-    if (tl < M.toomuch) { M.out[w] = -1; *M.status = 1; return; }
+    const double tl = tau_at(last);
+    if (tl < M.toomuch) { M.out[w] = -1; atomicMax(M.status, 1); return; }
     int ini = last + 1 - 2; if (ini < 0) ini = 0;
     // interp_line(tau+ini, ipv, toomuch), numerical.c:202-211
-    const double x0 = tw[(long long)ini * M.nsh], x1 = tw[(long long)(ini+1) * M.nsh];
+    const double x0 = tau_at(ini), x1 = tau_at(ini + 1);
     const double y0 = M.ip[ini] * M.ip_fct, y1 = M.ip[ini+1] * M.ip_fct;
     const double r = y0 + (M.toomuch - x0) * ((y1 - y0) / (x1 - x0));
     M.out[w] = r * r / (M.srad * M.srad);
     return;
   }
-  const double tlast = readlane_f64(tw[(long long)last * M.nsh], 0);
+  const double tlast = readlane_f64(tau_at(last), 0);
   const double maxtau = tlast > M.toomuch ? tlast : M.toomuch;
   // integrand on ascending radius: index q = 0..cnt-1 maps to height i = cnt-1-q
   int lastp = last + 1; if (lastp > nr - 1) lastp = nr - 1;
   const int cnt = lastp + 1;                               // points, including the zero pad
-  if (cnt < 3) { if (lane == 0) { M.out[w] = nan(""); *M.status = 2; } return; }
+  if (cnt < 3) { if (lane == 0) { M.out[w] = nan(""); atomicMax(M.status, 2); } return; }
   const double *g = M.gw + (long long)cnt * M.gstride;
   auto val = [&](int q) -> double {
     const int i = cnt - 1 - q;
     if (i > last) return 0.0;                              // slantpath.c:383-386
     const double b = M.ip[i] * M.ip_fct;
-    return exp(-tw[(long long)i * M.nsh]) * b;
+    return exp(-tau_at(i)) * b;
   };
   const int even = (cnt % 2 == 0), npair = (cnt - 1) / 2;
   double acc = 0.0;
@@ -1817,6 +1825,18 @@ void k_modulation(ModArgs M)
   }
   res *= 1.0 / (M.srad * M.srad);
   M.out[w] = res;
+}
+
+__global__ __launch_bounds__(64 * kModWaves)
+void k_modulation(ModArgs M)
+{
+  latency_critical();
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * kModWaves + (threadIdx.x >> 6);      // wave-uniform
+  if (w >= M.nsh) return;
+  const int last = __builtin_amdgcn_readfirstlane(M.last[w]);
+  const double *tw = M.tau + w;                           // tw[i*nsh] = tau[i][w]
+  modulation_ray(M, w, last, lane, [&](int i) { return tw[(long long)i * M.nsh]; });
 }
 
 // The same for large grids (like k_emission_rows, by the job's grid): one lane per wavenumber,

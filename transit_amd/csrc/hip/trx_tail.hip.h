@@ -31,7 +31,7 @@
 // events and the waits on them disappear from a hinted run -- the kernels from k_layer_max to the
 // tail then follow each other without a gap; the CIA kernels' event is the one wait left.  Not
 // covered (the step kernels run as before): unhinted and resumed runs, transit geometry,
-// scattering / cloud models, plans of more than two steps or with two-kernel steps, shards of
+// plans of more than two steps or with two-kernel steps, shards of
 // more than 65 536 rays, profiled runs, restored extinction.
 #pragma once
 #include "trx_walk.hip.h"
@@ -54,7 +54,8 @@ struct TailArgs {
   const int *skip;                                            // null, or the rays' `last`: a closed ray's bins are not combined (zero)
   int *host_flags;                                            // null, or pinned host memory: the run's flags [0..7] and status [16..19] land there too (no copy command behind the kernel)
   TauArgs T;                                                  // r_top: the first step's; nc: all layers of the plan
-  EmisArgs E;
+  EmisArgs E;                                                 // eclipse geometry (NANG > 0)
+  ModArgs M;                                                  // transit geometry (NANG == 0)
 };
 
 // Where the records of bin j (wave-uniform) are: per step the ranges [wa, wz) of the isotope block
@@ -107,13 +108,15 @@ __device__ __forceinline__ double tail_add_records(const TailStep &S, const Tail
   return sum;
 }
 
-template <int NANG>                                         // angles of the emission (8: half the state of 16)
+template <int NANG, bool EXTRAS>                            // angles of the emission (8: half the state of 16; 0: slant rays and the modulation of a transit); a scattering or cloud model is on
 __global__ __launch_bounds__(kTailThreads, 4)                // (two blocks per CU: a demo-sized run is 358 blocks on 256 CUs -- one round, not two)
 void k_ray_tail(TailArgs A)
 {
   const TauArgs &T = A.T;
+  constexpr bool SLANT = NANG == 0;
   latency_critical();
   __shared__ double s_x[kTailLayers + 1][kTailRays];          // total extinction e + e_cs (tau.c:231-232); row nct: zeros
+  __shared__ double s_cs[SLANT ? kTailLayers : 1][kTailRays];  // slant rays: the layer's extinction without its lines (what an unswept layer holds, tau.c:231-232)
   __shared__ double s_p[kTailLayers][kTailRays];              // the Simpson term of the pair that starts at the layer
   __shared__ double s_a[kTailLayers][kTailRays];              // running Simpson sums A(layer)
   __shared__ double s_er[kTailLayers][kTailRays], s_tau[kTailLayers][kTailRays];
@@ -147,11 +150,16 @@ void k_ray_tail(TailArgs A)
         }
     }
     // (what the emission needs of the inputs, requested here: used long after)
-    const double r_e2 = wv == 1 ? A.E.e2tab[lane] : 0.0;
-    auto put = [&](int s, int c0) {                           // this bin's layers of step s: e to memory, e + e_cs to the chain
+    const double r_e2 = (!SLANT && wv == 1) ? A.E.e2tab[lane] : 0.0;
+    double xfs = 0.0, xfc = 0.0;                              // this ray's wavenumber factors of the two models
+    if (EXTRAS && wv < nrays) { xfs = T.xf_scat[w0 + wv]; xfc = T.xf_cloud[w0 + wv]; }
+    auto put = [&](int s, int c0) {                           // this bin's layers of step s: e to memory, the total extinction (tau.c:231-232) to the chain
       if (lane < A.S[s].nc) {
-        if (wv < nrays) A.e[(long long)(T.r_top - c0 - lane) * T.nsh + w0 + wv] = sum[s];
-        s_x[c0 + lane][wv] = sum[s] + ecs[s];
+        const int rs = T.r_top - c0 - lane;
+        if (wv < nrays) A.e[(long long)rs * T.nsh + w0 + wv] = sum[s];
+        if (EXTRAS) s_x[c0 + lane][wv] = sum[s] + scat_layer(T, rs, xfs) + cloud_layer(T, rs, xfc) + ecs[s];
+        else        s_x[c0 + lane][wv] = sum[s] + ecs[s];
+        if (SLANT) s_cs[c0 + lane][wv] = EXTRAS ? scat_layer(T, rs, xfs) + cloud_layer(T, rs, xfc) + ecs[s] : ecs[s];
       }
     };
     auto empty = [&](int b) { return b < 64 ? !((A.blocks >> b) & 1ull) : A.gblock[b] == A.gblock[b + 1]; };   // no group of this isotope block in range
@@ -179,18 +187,22 @@ void k_ray_tail(TailArgs A)
   } else {
     // ---- the chain wave: the layers' and rays' scalars into LDS, then down the first step's layers
     // behind X1 while the other waves fetch the second step's records
-    for (int k = lane; k < (nct + 1) * kVertLay; k += 64) {
-      const int c = k / kVertLay, rs = T.r_top - c;
-      s_lay[k] = (c < nct && rs >= 0) ? T.lay[(long long)kVertLay * rs + (k - c * kVertLay)] : 0.0;
+    if (!SLANT) {
+      for (int k = lane; k < (nct + 1) * kVertLay; k += 64) {
+        const int c = k / kVertLay, rs = T.r_top - c;
+        s_lay[k] = (c < nct && rs >= 0) ? T.lay[(long long)kVertLay * rs + (k - c * kVertLay)] : 0.0;
+      }
+      for (int k = lane; k < nct + 3; k += 64) { const int r = T.r_top + 1 - k; s_rad[k] = (r >= 0 && r < nr) ? T.rad[r] : 0.0; }
     }
-    for (int k = lane; k < nct + 3; k += 64) { const int r = T.r_top + 1 - k; s_rad[k] = (r >= 0 && r < nr) ? T.rad[r] : 0.0; }
     if (lane < kTailRays) {
       double a1 = 0, a2 = 0, y1 = 0, y2 = 0; int last = 0;
       if (lane < nrays) {
         const long long w = w0 + lane;
-        a1 = T.acc[w]; a2 = T.acc[T.nsh + w];
-        if (T.r_top + 1 < nr) y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
-        if (T.r_top + 2 < nr) y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
+        if (!SLANT) {
+          a1 = T.acc[w]; a2 = T.acc[T.nsh + w];
+          if (T.r_top + 1 < nr) y1 = T.er[(long long)(T.r_top + 1) * T.nsh + w];
+          if (T.r_top + 2 < nr) y2 = T.er[(long long)(T.r_top + 2) * T.nsh + w];
+        }
         last = T.last[w];
       }
       s_ray[0][lane] = a1; s_ray[1][lane] = a2; s_ray[2][lane] = y1; s_ray[3][lane] = y2;
@@ -229,12 +241,54 @@ void k_ray_tail(TailArgs A)
       if (c + 1 < cz) one(c + 1, a1, true);
       if (c + 2 < cz) one(c + 2, fetch(c + 2), true);
     };
-    down(0, A.nsteps > 1 ? nc0 : nct);
+    if (!SLANT) down(0, A.nsteps > 1 ? nc0 : nct);
     __syncthreads();                                            // X2
-    if (A.nsteps > 1) down(nc0, nct);
+    if (!SLANT && A.nsteps > 1) down(nc0, nct);
   }
   __syncthreads();                                              // X3: er of all layers
 
+  if constexpr (SLANT) {
+  // ---- slant rays (slantpath.c:29-107; k_optical_depth's arithmetic: slant_bottom, slant_integral):
+  // every (height, ray) pair is on its own -- the parabola at the closest approach, then Simpson
+  // over the layers above with the height's weights.  What a layer of the NEXT step holds while a
+  // step's heights are integrated is its extinction without lines (the reference sweeps lazily,
+  // tau.c:231-232): s_cs, as the step kernels read it.
+  const int r_bottom = T.r_top - nct + 1;
+  for (int k = tid; k < nct * kTailRays; k += kTailThreads) {
+    const int c = k / kTailRays, t = k % kTailRays;
+    const int kl = T.r_top - c;                                  // the height's own layer
+    const int rs = (int)T.hrs[kl];
+    double y0 = 0.0;
+    if (t < nrays && s_last[t] < 0 && rs >= 0) {
+      const int r_low = (A.nsteps > 1 && c < nc0) ? T.r_top - nc0 + 1 : r_bottom;      // lowest layer swept when this height's step is integrated
+      double ylow;
+      if (rs >= r_low) ylow = s_x[T.r_top - rs][t];
+      else if (rs >= r_bottom) ylow = s_cs[T.r_top - rs][t];
+      else if (EXTRAS) ylow = scat_layer(T, rs, T.xf_scat[w0 + t]) + cloud_layer(T, rs, T.xf_cloud[w0 + t]) + T.ecs[(long long)rs * T.nsh + w0 + t];
+      else             ylow = T.ecs[(long long)rs * T.nsh + w0 + t];
+      y0 = slant_bottom(T, rs, T.hr0[kl], ylow, [&](int L) { return s_x[T.r_top - L][t]; });
+    }
+    s_p[c][t] = y0;
+  }
+  __syncthreads();
+  for (int k = tid; k < nct * kTailRays; k += kTailThreads) {
+    const int c = k / kTailRays, t = k % kTailRays;
+    if (t < nrays && s_last[t] < 0) {
+      const int kl = T.r_top - c;
+      const int rs = (int)T.hrs[kl];
+      double tv;
+      if (rs == -1) tv = 0.0;                                    // slantpath.c:37-38: the outermost layer
+      else if (rs < 0) { tv = nan(""); atomicMax(T.status, 3); } // slantpath.c:39-44: the reference exits here
+      else tv = 2 * slant_integral(T, kl, rs, s_p[c][t], [&](int L) { return s_x[T.r_top - L][t]; });      // slantpath.c:107
+      tv = T.rad_fct * tv;
+      s_tau[c][t] = tv;
+      const int ri = nr - 1 - kl;
+      if ((tv > T.toomuch) | (ri == nr - 1)) atomicMin(&s_stop[t], c);       // tau.c:277-287, 299-304
+      s_er[c][t] = s_x[c][t];                                    // (transit geometry leaves the total extinction in er as it is)
+    }
+  }
+  __syncthreads();
+  } else {
   // ---- the rest of k_optical_depth_vertical's arithmetic (vertical_layer), taken off the chain:
   // the Simpson terms (B2), the division and the stopping test (B4) are one (layer, ray) pair per
   // thread, and the running sums between them (B3) one addition per layer.
@@ -287,9 +341,11 @@ void k_ray_tail(TailArgs A)
   }
   __syncthreads();
 
+  }
+
   // ---- results.  Waves 0..6: the emission of their ray (k_emission: lanes = heights; this run's
   // optical depths from LDS); the chain wave: the rays' state and the run's flags; everybody: er and tau.
-  int my_done = 0;                                                    // layers of ray `wv` / lane (chain wave) that count
+  int pub_still = 0, pub_deep = 0;                                    // (chain wave) what this block adds to the run's flags
   auto outcome = [&](int t, int &last, int &done, bool &still) {      // of ray t, from the first stopping layer
     last = s_last[t]; done = 0; still = false;
     if (last < 0) {
@@ -306,34 +362,13 @@ void k_ray_tail(TailArgs A)
       outcome(lane, last, done, still);
       if (was_open) {
         if (!still) T.last[w0 + lane] = last;
-        T.acc[w0 + lane] = s_acc[0][lane]; T.acc[T.nsh + w0 + lane] = s_acc[1][lane];
+        if (!SLANT) { T.acc[w0 + lane] = s_acc[0][lane]; T.acc[T.nsh + w0 + lane] = s_acc[1][lane]; }
       }
       nstill = still; if (last >= 0) deep = last + 1;
     }
-    // the run's flags as the step kernels' tau_publish leaves them after the plan's last step (the
-    // last block to arrive publishes the totals) -- next to the other waves' emission, not before it
     nstill = (int)wave_sum_ll(nstill);
     deep = wave_max_i(deep);
-    if (lane == 0) {
-      if (nstill) atomicAdd(&T.flags[1], nstill);
-      if (deep) atomicMax(&T.flags[4], deep);
-      __threadfence();
-      const int ticket = atomicAdd(&T.flags[3], 1);
-      if (ticket == (int)gridDim.x - 1) {
-        __threadfence();
-        const int act = atomicAdd(&T.flags[1], 0), dp = atomicAdd(&T.flags[4], 0);
-        const int swept = T.flags[2] + nct;                    // layers swept so far
-        T.flags[2] = swept; T.flags[1] = 0; T.flags[3] = 0;
-        __threadfence();
-        atomicExch(&T.flags[0], act);
-        if (A.host_flags) {
-          volatile int *hf = A.host_flags;
-          hf[0] = act; hf[1] = 0; hf[2] = swept; hf[3] = 0; hf[4] = dp; hf[5] = 0; hf[6] = 0; hf[7] = 0;
-          hf[16] = 0; hf[17] = 0; hf[18] = 0; hf[19] = 0;      // (status: vertical rays raise none)
-          __threadfence_system();
-        }
-      }
-    }
+    pub_still = nstill; pub_deep = deep;
   }
   for (int k = tid; k < nct * kTailRays; k += kTailThreads) {
     const int c = k / kTailRays, t = k % kTailRays;
@@ -345,17 +380,47 @@ void k_ray_tail(TailArgs A)
       T.tau[(long long)(nr - 1 - rs) * T.nsh + w0 + t] = s_tau[c][t];
     }
   }
+  // The run's flags as the step kernels' tau_publish leaves them after the plan's last step (the
+  // last block to arrive publishes the totals), into device memory and into the pinned block the
+  // host reads.  Vertical rays: next to the other waves' emission, not behind it; slant rays: behind
+  // the block's modulation, which may raise a status.
+  auto publish = [&]() {
+    if (pub_still) atomicAdd(&T.flags[1], pub_still);
+    if (pub_deep) atomicMax(&T.flags[4], pub_deep);
+    __threadfence();
+    const int ticket = atomicAdd(&T.flags[3], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      __threadfence();
+      const int act = atomicAdd(&T.flags[1], 0), dp = atomicAdd(&T.flags[4], 0);
+      const int status = SLANT ? atomicAdd(T.status, 0) : 0;     // (vertical rays raise none)
+      const int swept = T.flags[2] + nct;                    // layers swept so far
+      T.flags[2] = swept; T.flags[1] = 0; T.flags[3] = 0;
+      __threadfence();
+      atomicExch(&T.flags[0], act);
+      if (A.host_flags) {
+        volatile int *hf = A.host_flags;
+        hf[0] = act; hf[1] = 0; hf[2] = swept; hf[3] = 0; hf[4] = dp; hf[5] = 0; hf[6] = 0; hf[7] = 0;
+        hf[16] = status; hf[17] = 0; hf[18] = 0; hf[19] = 0;
+        __threadfence_system();
+      }
+    }
+  };
+  if (!SLANT && chain_wave && lane == 0) publish();
   if (!chain_wave && wv < nrays) {
-    const EmisArgs &E = A.E;
     const long long w = w0 + wv;
     int last, done; bool still;
     outcome(wv, last, done, still);
-    last = __builtin_amdgcn_readfirstlane(last); my_done = __builtin_amdgcn_readfirstlane(done);
+    last = __builtin_amdgcn_readfirstlane(last); done = __builtin_amdgcn_readfirstlane(done);
     const int i_first = nr - 1 - T.r_top;                  // heights above it: earlier steps (global memory)
-    const int i_end = i_first + my_done;                   // (a ray that was closed on entry left nothing in LDS)
-    emission_ray<NANG>(E, w, last, lane, s_e2, [&](int i) {
-      return (i >= i_first && i < i_end) ? s_tau[i - i_first][wv] : E.tau[(long long)i * E.nsh + w];
-    });
+    const int i_end = i_first + done;                      // (a ray that was closed on entry left nothing in LDS)
+    const double *tau_g = T.tau;
+    auto tau_at = [&](int i) { return (i >= i_first && i < i_end) ? s_tau[i - i_first][wv] : tau_g[(long long)i * T.nsh + w]; };
+    if constexpr (SLANT) modulation_ray(A.M, w, last, lane, tau_at);
+    else                 emission_ray<(NANG > 0 ? NANG : 1)>(A.E, w, last, lane, s_e2, tau_at);
+  }
+  if (SLANT) {
+    __syncthreads();
+    if (chain_wave && lane == 0) publish();
   }
 }
 
