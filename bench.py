@@ -531,7 +531,13 @@ def main():
                        "ms_create_voigt_table_kernels": stats["ms_create_table"],
                        "ms_kernels": {k: round(v, 4) for k, v in kern.items()},
                        "ms_kernels_source": "HIP events on the kernels' own streams over a repeat of the timed region "
-                                            "(%d runs, %.4f ms per step with the events in)" % (runs, ev["ms_per_step_with_events"]),
+                                            "(%d runs, %.4f ms per step with the events in).  The walks are the production "
+                                            "launches; what follows them in the timed region is ONE kernel, k_ray_tail "
+                                            "(combines, optical depths, spectrum) -- the event-bracketed repeat runs the step "
+                                            "kernels it stands for, k_walk_combine among them, on their side queue"
+                                            % (runs, ev["ms_per_step_with_events"]),
+                       "after_the_walks": "k_ray_tail (hinted plans of one or two walk steps; profiles/*_kernel_stats.csv)"
+                                          if walked and launches <= 2 else "step kernels (combine, optical depth, spectrum)",
                        "ms_tau": ev["ms_tau"] / runs, "ms_run_device": ev["ms_run_total"] / runs,
                        "ms_host_cia": stats["ms_cia"], "ms_host_total_profiled_run": stats["ms_host_total"],
                        "b_alg_run_bytes": b_alg_run, "b_min_run_bytes": b_min_run,
