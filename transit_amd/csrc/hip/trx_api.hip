@@ -82,6 +82,7 @@ struct trx_handle {
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
+  bool shard_frames = true;                              // a shard's frames sized for the lines that can reach it (TRX_SHARD_FRAMES=0: for the whole list's)
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
@@ -378,6 +379,7 @@ int build_table(trx_handle *h, const trx_static *s)
     h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");
     if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;
     if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TRX_SHARD_FRAMES")) h->shard_frames = std::atoi(e) != 0;
     if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
     // (run graphs are opt-in: on ROCm 7.2 hipGraphLaunch of this graph -- ~28 nodes on three streams --
     // costs the host as much as queueing them one by one, ~105 us, and the device runs it no faster:
@@ -534,9 +536,16 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     // the WHOLE list, not from what reaches this shard: the range size is part of the order of the
     // sums, and a shard's spectrum must be the same bits as the unsharded one.  (Shorter ranges for
     // small shards were measured: 1/8 of the demo 0.267 -> 0.259 ms with 32, slower with 16.)
+    // Lists of more than a million groups get MORE ranges of 64 groups, not longer ones (up to 2^17
+    // ranges: their partial records are ~50 MB per step and buffer): a rank of an N-way job walks 1/N
+    // of them, and a range is one wave's serial work -- with 512-group ranges one shard of eight of an
+    // 8*10^6-line list had 1 700 waves for 1 024 SIMDs (its 2-bin walk 226 us instead of 108).
     int ngw = 32;
     if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
-    else while (ngw < 512 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;
+    else {
+      while (ngw < 64 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;
+      while (ngw < 512 && (int64_t)gfirst.size() / ngw > 131072) ngw *= 2;
+    }
     h->ngw = ngw;
     h->h_wbase.assign(s->niso + 1, 0);
     for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
@@ -841,6 +850,25 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       }
       int32_t pm = 0;
       for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
+      // A shard sizes its frames for the lines that can reach IT.  Doppler widths grow with the
+      // wavenumber: on a job whose band spans a factor of ten, the widest profile of the list is
+      // several times the widest one near a low-wavenumber shard.  The lines that can reach the shard
+      // lie within the reach of the widest profile (pm, a cell to spare) of its bins; if all of them
+      // refresh their Doppler index (anchor wavenumber >= wcut: no sticky index, which is a property
+      // of lines anywhere in the block), their profiles are those of their own wavenumbers' indices.
+      if (h->windowed() && h->shard_frames && h->iso_wmax[i] > 0) {
+        const double reach = ((double)pm + h->osamp) * (h->wn_d / h->osamp) + h->wn_d;
+        const double wA = h->wn_i + (double)h->lo * h->wn_d - reach, wB = h->wn_i + (double)(h->hi - 1) * h->wn_d + reach;
+        if (wA >= wcut[k]) {
+          const double wa = std::max(wA, h->iso_wmin[i]), wb = std::min(wB, h->iso_wmax[i]);
+          int32_t pw = 0;
+          if (wa <= wb) {
+            const int i0 = nearest_index(h->adop.data(), ad * wa, 0, h->ndop), i1 = nearest_index(h->adop.data(), ad * wb, 0, h->ndop);
+            for (int d = std::min(i0, i1); d <= std::max(i0, i1); d++) pw = std::max(pw, h->psize[(size_t)d * h->nlor + ilor[k]]);
+          }
+          pm = std::min(pm, pw);
+        }
+      }
       psmax[k] = pm;
       {   // groups of the block that refresh the Doppler index: wavn >= wcut (descending order)
         const double *gb = h->h_gwavn.data() + h->h_gblock[i], *ge = h->h_gwavn.data() + h->h_gblock[i + 1];
