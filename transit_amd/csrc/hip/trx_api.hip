@@ -83,6 +83,7 @@ struct trx_handle {
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
   bool shard_frames = true;                              // a shard's frames sized for the lines that can reach it (TRX_SHARD_FRAMES=0: for the whole list's)
+  bool cia_window = true;                                // the CIA spline solved for the table rows a run needs, not the whole table (TRX_CIA_WINDOW=0)
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
@@ -379,6 +380,7 @@ int build_table(trx_handle *h, const trx_static *s)
     h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");
     if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;
     if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TRX_CIA_WINDOW")) h->cia_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("TRX_SHARD_FRAMES")) h->shard_frames = std::atoi(e) != 0;
     if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
     // (run graphs are opt-in: on ROCm 7.2 hipGraphLaunch of this graph -- ~28 nodes on three streams --
@@ -696,6 +698,18 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     J.C = CiaDev{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>(),
                  c.d_zt.as<double>(), c.d_uw.as<double>(), c.d_ruw.as<double>(), c.d_rh.as<double>()};
     J.fj = fj; J.lj = lj; J.fi = fi; J.li = li;
+    {   // table rows the wavenumber spline is solved for: those the run's wavenumbers bracket, a margin to spare (k_cia_layers)
+      const int nw = (int)c.wn.size();
+      J.ia = 0; J.iz = nw - 1;
+      if (h->cia_window && nw > 4 * kCiaMargin) {
+        const double xa = wn_at(fi), xb = wn_at(li - 1);
+        const int ra = (int)(std::upper_bound(c.wn.begin(), c.wn.end(), xa) - c.wn.begin()) - 1;      // last row at or below the first wavenumber
+        const int rb = (int)(std::lower_bound(c.wn.begin(), c.wn.end(), xb) - c.wn.begin());          // first row at or above the last one
+        const int ia = ra - 2 - kCiaMargin, iz = rb + 2 + kCiaMargin;
+        if (ia >= 3) J.ia = ia;
+        if (iz <= nw - 4) J.iz = iz;
+      }
+    }
     J.mid = h->d_cia_ws.as<double>() + 3 * nwmax * (size_t)nr * (size_t)B.n; J.z2 = J.mid + nwmax * nr; J.v = J.z2 + nwmax * nr;
     J.dens = d_dens + n * nr;
     if (++B.n == kCiaBatch) flush(false);

@@ -915,6 +915,7 @@ constexpr int kCiaBatch = 4;
 struct CiaJob {
   CiaDev C;
   int fj, lj; long long fi, li;      // layers / wavenumbers inside the table (crosssec.c:376-393)
+  int ia, iz;                        // table rows the wavenumber spline is solved for (0, nwave-1: all of them; see k_cia_layers)
   double *mid, *z2, *v;              // [nwave][nr] each
   const double *dens;                // [nr] density product
 };
@@ -929,7 +930,7 @@ void k_cia_rows(CiaBatch B, int nr, const double *__restrict__ tlay)
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)C.nwave * nr) return;
   const int i = (int)(idx / nr), j = (int)(idx - (long long)i * nr);
-  if (j < fj || j >= lj) return;
+  if (j < fj || j >= lj || i < B.J[blockIdx.y].ia || i > B.J[blockIdx.y].iz) return;
   mid[idx] = spline_eval_pt(C.zt + (long long)i * C.ntemp, C.ntemp, C.temp, C.cs + (long long)i * C.ntemp, tlay[j]);
 }
 
@@ -943,6 +944,7 @@ void k_cia_rows(CiaBatch B, int nr, const double *__restrict__ tlay)
 // spacings) are multiplications by reciprocals made at create: the chain is mul-fma
 // (e_cs agrees with the oracle to 1e-13).  z2/v are [nwave][nr].
 constexpr int kCiaChunk = 16;
+constexpr int kCiaMargin = 128;          // rows solved beyond the ones a run's wavenumbers bracket (k_cia_layers)
 
 __global__ __launch_bounds__(64)
 void k_cia_layers(CiaBatch B, int nr)
@@ -955,54 +957,73 @@ void k_cia_layers(CiaBatch B, int nr)
   if (j >= lj) return;
   latency_critical();
   const long n = C.nwave;
+  // The rows ia..iz of the table: all of them, or -- where the run's wavenumbers lie inside a small
+  // part of a long table (a shard of a wide band; a band inside a 20-10000 cm-1 table) -- the rows
+  // around them with kCiaMargin to spare on either side, the sweeps started from zero there.  What
+  // a sweep carries from row to row shrinks by the pivots' ratio (< 0.3) every row: after the margin
+  // a different start is 10^-60 of the value, the doubles inside are those of the whole table's
+  // sweeps (tests/test_gpu_cia_window.py: bit for bit against them).
+  const long ia = B.J[blockIdx.y].ia, iz = B.J[blockIdx.y].iz;
   const double *__restrict__ x = C.wn, *__restrict__ ru = C.ruw, *__restrict__ rh = C.rh;
   const double *y = mid + j; double *z = z2 + j, *vv = v + j;
   double vp = 0;
-  if (n > 2) {
-    const double h0 = x[1] - x[0], h1 = x[2] - x[1];
-    const double b0 = (y[1L*nr] - y[0]) / h0, b1 = (y[2L*nr] - y[1L*nr]) / h1;
-    vp = 6 * (b1 - b0);
-    vv[1L*nr] = vp;
+  long i0 = 2;                                             // first row of the forward recurrence
+  double yi, bim;
+  if (ia == 0) {
+    if (n > 2) {
+      const double h0 = x[1] - x[0], h1 = x[2] - x[1];
+      const double b0 = (y[1L*nr] - y[0]) / h0, b1 = (y[2L*nr] - y[1L*nr]) / h1;
+      vp = 6 * (b1 - b0);
+      vv[1L*nr] = vp;
+    }
+    yi = n > 2 ? y[2L*nr] : 0.0; bim = n > 2 ? (yi - y[1L*nr]) / (x[2] - x[1]) : 0.0;
+  } else {
+    i0 = ia + 1;                                           // (ia >= 3: trx_api.hip)
+    yi = y[i0 * nr]; bim = (yi - y[(i0 - 1) * nr]) * rh[i0 - 1];
+    vv[ia * nr] = 0.0;
   }
+  const long iend = iz == n - 1 ? n - 1 : iz;              // the recurrence runs for rows i0 .. iend-1
   if (n > 3) {
     // forward: v[i] = 6 (b[i] - b[i-1]) - v[i-1] h[i-1] / u[i-1],  b[i] = (y[i+1] - y[i]) / h[i]
-    double yi = y[2L*nr], bim = (yi - y[1L*nr]) / (x[2] - x[1]);
-    for (long base = 2; base < n - 1; base += kCiaChunk) {
+    for (long base = i0; base < iend; base += kCiaChunk) {
       double yb[kCiaChunk], vo[kCiaChunk];
 #pragma unroll
       for (int k = 0; k < kCiaChunk; k++) { const long i = base + k + 1; yb[k] = y[(i < n ? i : n - 1) * nr]; }     // y[i+1] of step i
 #pragma unroll
       for (int k = 0; k < kCiaChunk; k++) {
         const long i = base + k;
-        if (i < n - 1) {
+        if (i < iend) {
           const double bi = (yb[k] - yi) * rh[i];
           const double vn = 6*(bi - bim) - vp * (x[i] - x[i-1]) * ru[i-1];
           vo[k] = vn; vp = vn; bim = bi; yi = yb[k];
         }
       }
 #pragma unroll
-      for (int k = 0; k < kCiaChunk; k++) if (base + k < n - 1) vv[(base + k) * nr] = vo[k];
+      for (int k = 0; k < kCiaChunk; k++) if (base + k < iend) vv[(base + k) * nr] = vo[k];
     }
   }
-  z[0] = 0; z[(n-1)*nr] = 0;
+  if (ia == 0) z[0] = 0;
+  z[iz * nr] = 0;                                          // (row n-1 of the table, or the window's pretended end)
   if (n > 2) {
     // backward: z[i] = (v[i] - h[i] z[i+1]) / u[i]
     double zn = 0;
-    for (long top = n - 2; top > 0; top -= kCiaChunk) {
+    const long ibot = ia == 0 ? 1 : ia + 1;               // lowest row the recurrence gives
+    for (long top = iz - 1; top >= ibot; top -= kCiaChunk) {
       double vb[kCiaChunk], zo[kCiaChunk];
 #pragma unroll
-      for (int k = 0; k < kCiaChunk; k++) { const long i = top - k; vb[k] = vv[(i > 0 ? i : 1) * nr]; }
+      for (int k = 0; k < kCiaChunk; k++) { const long i = top - k; vb[k] = vv[(i >= ibot ? i : ibot) * nr]; }
 #pragma unroll
       for (int k = 0; k < kCiaChunk; k++) {
         const long i = top - k;
-        if (i > 0) {
+        if (i >= ibot) {
           const double zi = (vb[k] - (x[i+1] - x[i]) * zn) * ru[i];
           zo[k] = zi; zn = zi;
         }
       }
 #pragma unroll
-      for (int k = 0; k < kCiaChunk; k++) if (top - k > 0) z[(top - k) * nr] = zo[k];
+      for (int k = 0; k < kCiaChunk; k++) if (top - k >= ibot) z[(top - k) * nr] = zo[k];
     }
+    if (ia != 0) z[ia * nr] = 0.0;
   }
 }
 
