@@ -39,7 +39,23 @@ def test_shard_frames_do_not_move_the_numbers(tmp_path, solution):
         e = Engine(P.static)
         full = e.run(P.atm, P.opts, debug=KEYS)
         e.close()
+        f_tight = frames_of(msgs)
+        os.environ["TRX_SHARD_FRAMES"] = "0"
+        try:
+            e = Engine(P.static)
+        finally:
+            os.environ.pop("TRX_SHARD_FRAMES", None)
+        del msgs[:]
+        loose = e.run(P.atm, P.opts, debug=KEYS)
+        e.close()
         f_full = frames_of(msgs)
+        # the unsharded run: frames sized for the indices its lines can take against frames sized for
+        # the isotopes' whole wavenumber range
+        assert all(x <= y or y == 0 for x, y in zip(f_tight, f_full)), (f_tight, f_full)
+        assert np.array_equal(full["last"], loose["last"])
+        assert np.allclose(full["spectrum"], loose["spectrum"], rtol=1e-11, atol=0)
+        if all((x == 0) == (y == 0) for x, y in zip(f_tight, f_full)):
+            assert np.array_equal(full["spectrum"], loose["spectrum"])
         narrower = 0
         parts, lasts = [], []
         for k, (lo, hi) in enumerate(all_bounds(P.nwn, 6)):

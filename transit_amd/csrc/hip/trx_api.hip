@@ -82,7 +82,7 @@ struct trx_handle {
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
-  bool shard_frames = true;                              // a shard's frames sized for the lines that can reach it (TRX_SHARD_FRAMES=0: for the whole list's)
+  bool shard_frames = true;                              // frames sized for the Doppler indices the lines in reach can take (TRX_SHARD_FRAMES=0: for the isotope's whole wavenumber range)
   bool cia_window = true;                                // the CIA spline solved for the table rows a run needs, not the whole table (TRX_CIA_WINDOW=0)
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
@@ -864,24 +864,38 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       }
       int32_t pm = 0;
       for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
-      // A shard sizes its frames for the lines that can reach IT.  Doppler widths grow with the
-      // wavenumber: on a job whose band spans a factor of ten, the widest profile of the list is
-      // several times the widest one near a low-wavenumber shard.  The lines that can reach the shard
-      // lie within the reach of the widest profile (pm, a cell to spare) of its bins; if all of them
-      // refresh their Doppler index (anchor wavenumber >= wcut: no sticky index, which is a property
-      // of lines anywhere in the block), their profiles are those of their own wavenumbers' indices.
-      if (h->windowed() && h->shard_frames && h->iso_wmax[i] > 0) {
-        const double reach = ((double)pm + h->osamp) * (h->wn_d / h->osamp) + h->wn_d;
-        const double wA = h->wn_i + (double)h->lo * h->wn_d - reach, wB = h->wn_i + (double)(h->hi - 1) * h->wn_d + reach;
-        if (wA >= wcut[k]) {
-          const double wa = std::max(wA, h->iso_wmin[i]), wb = std::min(wB, h->iso_wmax[i]);
-          int32_t pw = 0;
-          if (wa <= wb) {
-            const int i0 = nearest_index(h->adop.data(), ad * wa, 0, h->ndop), i1 = nearest_index(h->adop.data(), ad * wb, 0, h->ndop);
-            for (int d = std::min(i0, i1); d <= std::max(i0, i1); d++) pw = std::max(pw, h->psize[(size_t)d * h->nlor + ilor[k]]);
-          }
-          pm = std::min(pm, pw);
+      // The bound is then tightened to the Doppler indices a line of this isotope can actually TAKE in
+      // this layer, among the lines that can reach this handle's bins (all of the block, or -- a
+      // shard -- those within the reach of the widest profile, pm, a cell to spare):
+      //   * anchor >= wcut ("own", extinction.c:480-483): the index of its own wavenumber;
+      //   * anchor < wcut: the sticky index -- the block's index at wn_i, or that of SOME anchor >= wcut
+      //     anywhere in the block (k_sticky_index) -- whatever the window.
+      // Doppler widths grow with the wavenumber: on a band that spans a factor of ten the widest
+      // profile of the list is several times the widest one a low-wavenumber shard meets, and in the
+      // deep layers (no anchor reaches wcut) every line takes the ONE profile of the index at wn_i.
+      if (h->shard_frames && h->iso_wmax[i] > 0) {
+        double lo_w = h->iso_wmin[i], hi_w = h->iso_wmax[i];
+        if (h->windowed()) {
+          const double reach = ((double)pm + h->osamp) * (h->wn_d / h->osamp) + h->wn_d;
+          lo_w = std::max(lo_w, h->wn_i + (double)h->lo * h->wn_d - reach);
+          hi_w = std::min(hi_w, h->wn_i + (double)(h->hi - 1) * h->wn_d + reach);
         }
+        const double wc = wcut[k];
+        auto widest = [&](double wa, double wb) {
+          const int i0 = nearest_index(h->adop.data(), ad * wa, 0, h->ndop), i1 = nearest_index(h->adop.data(), ad * wb, 0, h->ndop);
+          int32_t m = 0;
+          for (int d = std::min(i0, i1); d <= std::max(i0, i1); d++) m = std::max(m, h->psize[(size_t)d * h->nlor + ilor[k]]);
+          return m;
+        };
+        int32_t pw = 0;
+        if (lo_w <= hi_w) {
+          if (hi_w >= wc) pw = std::max(pw, widest(std::max(lo_w, wc), hi_w));                 // own indices of the lines in reach
+          if (lo_w < wc) {                                                                       // some line in reach takes the sticky index
+            pw = std::max(pw, h->psize[(size_t)idop0[k] * h->nlor + ilor[k]]);
+            if (h->iso_wmax[i] >= wc) pw = std::max(pw, widest(std::max(h->iso_wmin[i], wc), h->iso_wmax[i]));
+          }
+        }
+        pm = std::min(pm, pw);
       }
       psmax[k] = pm;
       {   // groups of the block that refresh the Doppler index: wavn >= wcut (descending order)
