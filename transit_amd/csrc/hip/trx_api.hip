@@ -1237,7 +1237,8 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
     const bool with_init = init && r0 == 0;
     RunInit R{}; R.nsh = -1;
     if (with_init) { R = *init; *init_done = true; }
-    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines)), ny + (with_init ? 1u : 0u)), dim3(64), sizeof(double) * (size_t)kLayerMaxGroup * (size_t)std::max(h->niso, 1), st,
+    // (at most kLayerMaxWaves waves per group of layers: beyond that a wave takes several chunks of candidates)
+    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)std::min<long long>((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines), kLayerMaxWaves), ny + (with_init ? 1u : 0u)), dim3(64), sizeof(double) * (size_t)kLayerMaxGroup * (size_t)std::max(h->niso, 1), st,
                        h->L, Yr, h->niso, nr, pruned ? h->d_candrec.as<CandLine>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
                        (unsigned long long *)(kmax + (size_t)r0 * nmx), R, with_init ? (int)ny : -1);
   }

@@ -163,6 +163,7 @@ void k_cand_pack(int n, const int32_t *__restrict__ cand, const double *__restri
 // patterns, zeroed beforehand.
 constexpr int kLayerMaxGroup = 8;
 constexpr int kLayerMaxLines = 4;
+constexpr int kLayerMaxWaves = 128;   // waves per group of layers at most (each takes every gridDim.x-th chunk of 256 candidates)
 
 __global__ __launch_bounds__(64)
 void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__restrict__ cand, long long ncand,
@@ -176,15 +177,46 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__res
   __shared__ double s_e2[64];
   s_e2[threadIdx.x] = e2tab[threadIdx.x];
   __builtin_amdgcn_wave_barrier();
-  double gf[kLayerMaxLines], elow[kLayerMaxLines], wavn[kLayerMaxLines]; int iso[kLayerMaxLines];
+  if ((long long)gridDim.x * 64 * kLayerMaxLines >= ncand) {      // one chunk per wave (lists of up to 128 chunks of candidates): the straight form
+    double gf[kLayerMaxLines], elow[kLayerMaxLines], wavn[kLayerMaxLines]; int iso[kLayerMaxLines];
 #pragma unroll
-  for (int u = 0; u < kLayerMaxLines; u++) {
-    const long long t = ((long long)blockIdx.x * kLayerMaxLines + u) * 64 + threadIdx.x;
-    gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
-    if (t < ncand) {
-      if (cand) { const CandLine c = cand[t]; gf[u] = c.gf; elow[u] = c.elow; wavn[u] = c.wavn; iso[u] = c.iso; }
-      else if (L.inrange[t]) { gf[u] = L.gf[t]; elow[u] = L.elow[t]; wavn[u] = L.wavn[t]; iso[u] = L.iso[t]; }
+    for (int u = 0; u < kLayerMaxLines; u++) {
+      const long long t = ((long long)blockIdx.x * kLayerMaxLines + u) * 64 + threadIdx.x;
+      gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
+      if (t < ncand) {
+        if (cand) { const CandLine c = cand[t]; gf[u] = c.gf; elow[u] = c.elow; wavn[u] = c.wavn; iso[u] = c.iso; }
+        else if (L.inrange[t]) { gf[u] = L.gf[t]; elow[u] = L.elow[t]; wavn[u] = L.wavn[t]; iso[u] = L.iso[t]; }
+      }
     }
+    const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
+    // the wave's layer scalars in LDS, one round trip for all of them (read per layer from global
+    // memory they were a dependent round trip per layer of this one-wave chain)
+    __shared__ double s_ct[kLayerMaxGroup];
+    extern __shared__ double s_f[];                      // [kLayerMaxGroup][niso] (dynamic: the launch sizes it)
+    for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64) s_f[t] = Y.strength_f[r0 * niso + t];
+    if ((int)threadIdx.x < r1 - r0) s_ct[threadIdx.x] = Y.negc_over_t[r0 + threadIdx.x];
+    __builtin_amdgcn_wave_barrier();
+    for (int r = r0; r < r1; r++) {
+      const double ct = s_ct[r - r0];
+      double best = 0.0;
+#pragma unroll
+      for (int u = 0; u < kLayerMaxLines; u++) {
+        const double s = gf[u] * exp_neg(ct * elow[u], s_e2) * (1 - exp_neg(ct * wavn[u], s_e2));
+        const double k = s * s_f[(r - r0) * niso + iso[u]];
+        if (nmx == 1) best = fmax(best, k);
+        else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
+          unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso[u]]];
+          const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
+          if (kb > *slot) atomicMax(slot, kb);
+        }
+      }
+      if (nmx == 1) {
+        const double m = wave_max(best);
+        if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(m));
+      }
+    }
+
+    return;
   }
   const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
   // the wave's layer scalars in LDS, one round trip for all of them (read per layer from global
@@ -194,23 +226,50 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__res
   for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64) s_f[t] = Y.strength_f[r0 * niso + t];
   if ((int)threadIdx.x < r1 - r0) s_ct[threadIdx.x] = Y.negc_over_t[r0 + threadIdx.x];
   __builtin_amdgcn_wave_barrier();
-  for (int r = r0; r < r1; r++) {
-    const double ct = s_ct[r - r0];
-    double best = 0.0;
+  // A wave takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ... of 256 candidates and keeps its
+  // layers' running maxima over all of them: one atomic per layer and WAVE, not per chunk (a list of
+  // 8*10^6 lines has 1.2*10^5 candidates: 488 chunks' atomics on the same hundred words took 100 us).
+  double best[kLayerMaxGroup];
+#pragma unroll
+  for (int q = 0; q < kLayerMaxGroup; q++) best[q] = 0.0;
+  const long long nchunk = (ncand + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines);
+  for (long long chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+    double gf[kLayerMaxLines], elow[kLayerMaxLines], wavn[kLayerMaxLines]; int iso[kLayerMaxLines];
 #pragma unroll
     for (int u = 0; u < kLayerMaxLines; u++) {
-      const double s = gf[u] * exp_neg(ct * elow[u], s_e2) * (1 - exp_neg(ct * wavn[u], s_e2));
-      const double k = s * s_f[(r - r0) * niso + iso[u]];
-      if (nmx == 1) best = fmax(best, k);
-      else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
-        unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso[u]]];
-        const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
-        if (kb > *slot) atomicMax(slot, kb);
+      const long long t = (chunk * kLayerMaxLines + u) * 64 + threadIdx.x;
+      gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
+      if (t < ncand) {
+        if (cand) { const CandLine c = cand[t]; gf[u] = c.gf; elow[u] = c.elow; wavn[u] = c.wavn; iso[u] = c.iso; }
+        else if (L.inrange[t]) { gf[u] = L.gf[t]; elow[u] = L.elow[t]; wavn[u] = L.wavn[t]; iso[u] = L.iso[t]; }
       }
     }
-    if (nmx == 1) {
-      const double m = wave_max(best);
-      if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(m));
+#pragma unroll
+    for (int q = 0; q < kLayerMaxGroup; q++) {
+      const int r = r0 + q;
+      if (r < r1) {
+        const double ct = s_ct[q];
+#pragma unroll
+        for (int u = 0; u < kLayerMaxLines; u++) {
+          const double s = gf[u] * exp_neg(ct * elow[u], s_e2) * (1 - exp_neg(ct * wavn[u], s_e2));
+          const double k = s * s_f[q * niso + iso[u]];
+          if (nmx == 1) best[q] = fmax(best[q], k);
+          else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
+            unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso[u]]];
+            const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
+            if (kb > *slot) atomicMax(slot, kb);
+          }
+        }
+      }
+    }
+  }
+  if (nmx == 1) {
+#pragma unroll
+    for (int q = 0; q < kLayerMaxGroup; q++) {
+      if (r0 + q < r1) {
+        const double m = wave_max(best[q]);
+        if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r0 + q], (unsigned long long)__double_as_longlong(m));
+      }
     }
   }
 }
