@@ -660,7 +660,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     if (B.n == 0 && !(first && last)) return;
     int nwave = 0, fj0 = nr, lj1 = 0, fjl = nr, ljl = 0; long long fi0 = nsh, li1 = 0;
     for (int t = 0; t < B.n; t++) {
-      nwave = std::max(nwave, B.J[t].C.nwave);
+      nwave = std::max(nwave, B.J[t].iz - B.J[t].ia + 1);      // (rows of the widest window)
       fj0 = std::min(fj0, B.J[t].fj); lj1 = std::max(lj1, B.J[t].lj);
       fi0 = std::min(fi0, B.J[t].fi); li1 = std::max(li1, B.J[t].li);
     }

@@ -927,10 +927,12 @@ void k_cia_rows(CiaBatch B, int nr, const double *__restrict__ tlay)
   const CiaDev &C = B.J[blockIdx.y].C;
   const int fj = B.J[blockIdx.y].fj, lj = B.J[blockIdx.y].lj;
   double *__restrict__ mid = B.J[blockIdx.y].mid;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)C.nwave * nr) return;
-  const int i = (int)(idx / nr), j = (int)(idx - (long long)i * nr);
-  if (j < fj || j >= lj || i < B.J[blockIdx.y].ia || i > B.J[blockIdx.y].iz) return;
+  // (the launch covers the rows ia..iz of the widest window of the batch: k_cia_layers)
+  const int ia = B.J[blockIdx.y].ia, iz = B.J[blockIdx.y].iz;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int i = ia + (int)(t / nr), j = (int)(t % nr);
+  if (i > iz || j < fj || j >= lj) return;
+  const long long idx = (long long)i * nr + j;
   mid[idx] = spline_eval_pt(C.zt + (long long)i * C.ntemp, C.ntemp, C.temp, C.cs + (long long)i * C.ntemp, tlay[j]);
 }
 
