@@ -119,8 +119,15 @@ void splinterp(const std::vector<double> &xi, const std::vector<double> &yi,
   std::vector<double> z(n), u(n), v(n);
   trx::spline_second_derivs(z.data(), xi.data(), yi.data(), n, u.data(), v.data());
   yo.resize(xo.size());
+  // Resampling onto the spline's own abscissa (a retrieval loop: the layers' radii are the
+  // atmosphere's): at a node below the last one spline3 takes the interval that starts there, the
+  // distance is +0, both powers are +0 and every term it adds to y[k] is a zero: y[k] itself (a
+  // negative zero aside, which no temperature, pressure, density or abundance is).  The last node is
+  // reached from the interval before it and goes through the polynomial.
+  const bool same = xo.size() == xi.size() && n >= 2 && std::equal(xo.begin(), xo.end(), xi.begin());
   for (size_t k = 0; k < xo.size(); k++)
-    yo[k] = trx::spline_eval_pow(z.data(), n, xi.data(), yi.data(), xo[k]);
+    yo[k] = (same && (long)k < n - 1 && !(yi[k] == 0.0 && std::signbit(yi[k])))
+              ? yi[k] : trx::spline_eval_pow(z.data(), n, xi.data(), yi.data(), xo[k]);
 }
 
 struct CiaTable { int nspec = 0; int mol[2] = {0, 0}; std::vector<double> wn, temp, cs; };
@@ -151,6 +158,7 @@ struct trh_problem {
   struct Db { std::string name, molname; std::vector<double> T; int first = 0, niso = 0; };
   std::vector<Db> dbs;
   std::vector<std::vector<double>> iso_z;               // [niso][nT(db)]
+  std::vector<std::vector<double>> iso_z2;              // second derivatives of the partition-function splines (make_layer_sampling)
   double tli_tmin = 0, tli_tmax = 70000;
   // sampled layers (makeradsample)
   std::vector<double> rad, t, p, mm, dens, q, zpart, t_k;
@@ -645,9 +653,24 @@ void make_layer_sampling(trh_problem &P)
   const size_t ni = P.iso_name.size();
   P.zpart.resize(ni * nr);
   std::vector<double> tmp;
-  for (size_t i = 0; i < ni; i++) {                        // makesample.c:534-544 (T without tfct)
-    splinterp(P.dbs[P.iso_db[i]].T, P.iso_z[i], P.t, tmp);
-    std::copy(tmp.begin(), tmp.end(), P.zpart.begin() + i * nr);
+  // makesample.c:534-544 (T without tfct): splinterp of every isotope's partition function onto the
+  // layer temperatures.  The spline's second derivatives depend on the TLI's table alone: they are
+  // made once per isotope and kept (a retrieval loop calls this for every spectrum; four tridiagonal
+  // sweeps over ~2000 temperatures were 80 of its ~100 us) -- the same doubles as splinterp's.
+  if (P.iso_z2.size() != ni) {
+    P.iso_z2.assign(ni, std::vector<double>());
+    for (size_t i = 0; i < ni; i++) {
+      const std::vector<double> &T = P.dbs[P.iso_db[i]].T;
+      const long n = (long)T.size();
+      std::vector<double> u(n), v(n);
+      P.iso_z2[i].resize(n);
+      trx::spline_second_derivs(P.iso_z2[i].data(), T.data(), P.iso_z[i].data(), n, u.data(), v.data());
+    }
+  }
+  for (size_t i = 0; i < ni; i++) {
+    const std::vector<double> &T = P.dbs[P.iso_db[i]].T;
+    for (size_t r = 0; r < nr; r++)
+      P.zpart[i * nr + r] = trx::spline_eval_pow(P.iso_z2[i].data(), (long)T.size(), T.data(), P.iso_z[i].data(), P.t[r]);
   }
   P.t_k.resize(nr);
   for (size_t r = 0; r < nr; r++) P.t_k[r] = P.t[r] * P.t_fct;

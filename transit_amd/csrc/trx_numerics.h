@@ -226,7 +226,10 @@ TRX_HD double spline_eval_pow(const double *z, long n, const double *x, const do
   const double h = x[k+1] - x[k];
   const double B = (y[k+1] - y[k]) / h - h/6 * (z[k+1] + 2 * z[k]);
   const double d = xo - x[k];
-  return y[k] + d * B + pow(d, 2) * 0.5*z[k] + pow(d, 3) * (z[k+1] - z[k]) / (6*h);
+  // (at a node -- a retrieval loop resamples its atmosphere onto its own radii -- the two powers are
+  // +0 without asking the library: pow(+0, 2) and pow(+0, 3) are exactly that)
+  const double d2 = d == 0.0 ? 0.0 : pow(d, 2), d3 = d == 0.0 ? 0.0 : pow(d, 3);
+  return y[k] + d * B + d2 * 0.5*z[k] + d3 * (z[k+1] - z[k]) / (6*h);
 }
 
 }  // namespace trx
