@@ -28,5 +28,21 @@ int main(int argc, char **argv)
     if (memcmp(&a, &b, 8) != 0 && !(a == 0 && b == 0)) { if (bad < 5) printf("x %a d %a: %a vs %a\n", x, d, a, b); bad++; }
   }
   printf("%ld operands, %ld differ\n", n, bad);
-  return bad != 0;
+  // the three forms of the bottom-point parabola must be the same bits: parab3 (the reference's
+  // operations, pu/src/numerical.c:182-195), parab3_recip (its two divisions as residual-corrected
+  // products) and parab3_chain (the node-only factors handed in as well: the chain of k_ray_tail and
+  // k_optical_depth_vertical)
+  long pbad = 0, pn = n / 20;
+  for (long i = 0; i < pn; i++) {
+    const double r0 = ldexp(mant(), 29 + (int)(rnd() % 5)), step = ldexp(mant(), 18 + (int)(rnd() % 8));      // radii ~1e9..1e10 cm, layers ~3..500 km
+    const double r1 = r0 + step;
+    const double v0 = ldexp(mant(), -40 + (int)(rnd() % 50)), v1 = v0 * (0.5 + mant() / 2), v2 = v1 * (0.25 + mant() / 2);
+    const double st = r1 - r0, t0 = r0 / st, tw = 2.0 * st * st;
+    const double a = trx::parab3(r0, r1, v0, v1, v2, r0);
+    const double b = trx::parab3_recip(st, 1.0 / st, t0, tw, 1.0 / tw, v0, v1, v2, r0);
+    const double c = trx::parab3_chain(st, 1.0 / st, t0, t0 + 1.5, tw, 1.0 / tw, v0, v1, v2, r0, r0 * r0);
+    if (memcmp(&a, &b, 8) != 0 || memcmp(&a, &c, 8) != 0) { if (pbad < 5) printf("parabola: %a %a %a\n", a, b, c); pbad++; }
+  }
+  printf("%ld parabolas, %ld differ\n", pn, pbad);
+  return bad != 0 || pbad != 0;
 }

@@ -26,6 +26,7 @@ def test_quotient_rn_is_the_division(tmp_path):
     out = subprocess.run([exe, "20000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "20000000 operands, 0 differ" in out.stdout
+    assert "1000000 parabolas, 0 differ" in out.stdout      # parab3 == parab3_recip == parab3_chain, bit for bit
 
 
 def test_threaded_grouping_is_the_sequential_loop(tmp_path):
