@@ -124,7 +124,7 @@ void k_ray_tail(TailArgs A)
   __shared__ double s_lay[(kTailLayers + 1) * kVertLay];
   __shared__ double s_ray[4][kTailRays];                       // a1, a2, y1, y2 on entry
   __shared__ double s_acc[2][kTailRays];                       // a1, a2 on exit
-  __shared__ int s_last[kTailRays], s_done[kTailRays], s_stop[kTailRays];
+  __shared__ int s_last[kTailRays], s_stop[kTailRays];       // where the ray stopped before this run (-1: open); first layer of the plan that stops it
   __shared__ double s_e2[64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nr = T.nr, nct = T.nc;
@@ -206,7 +206,7 @@ void k_ray_tail(TailArgs A)
         last = T.last[w];
       }
       s_ray[0][lane] = a1; s_ray[1][lane] = a2; s_ray[2][lane] = y1; s_ray[3][lane] = y2;
-      s_last[lane] = last; s_done[lane] = 0; s_stop[lane] = nct;
+      s_last[lane] = last; s_stop[lane] = nct;
       s_x[nct][lane] = 0.0;
     }
     __syncthreads();                                            // X1
