@@ -165,3 +165,24 @@ def test_tail_with_cloud_and_scattering_models(tmp_path, extra, solution):
         engine.set_log(None)
         t.close(); r.close()
     assert tail_runs(msgs) >= 2
+
+
+def test_tail_with_twelve_angles(tmp_path):
+    """More than eight emission angles: the instantiation that keeps state for all 16 (k_ray_tail<16>)."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=40_000, wnlow=2500, wnhigh=2650, wndelt=1.0, wnosamp=2160, nlayers=70,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=9, ncia=1,
+                    raygrid="0 7 14 21 28 35 42 49 56 63 70 77")
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    assert P.opts.nangles == 12
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    t, r = engines(P)
+    try:
+        for k in range(3):
+            a, b = t.run(P.atm, P.opts, debug=KEYS), r.run(P.atm, P.opts, debug=KEYS)
+            assert_same(a, b, k)
+    finally:
+        engine.set_log(None)
+        t.close(); r.close()
+    assert tail_runs(msgs) >= 2
