@@ -1,0 +1,94 @@
+"""k_line_walk_lanes (steps of at most 32 layers with frames of 8+ bins: lanes = LINES for the strengths,
+blocks of groups that share a cell for the accumulation; trx_lanes.hip.h) against k_line_walk /
+k_line_walk_packed: the same lines in the same order, the same base points of the rebased exponential,
+the same frame and the same partial records -- so the same BITS in extinction, optical depth and
+spectrum.  Goldens (forced on their sparse lists: single-group blocks, frames that jump), demo-shaped
+atmospheres whose deep step has 17 layers, a shard, lists with long co-added groups and several
+isotopes, and every S (ranges per wave)."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import GOLDEN
+from transit_amd import engine, synth
+from transit_amd.engine import Engine
+from transit_amd.host import Problem
+
+pytestmark = pytest.mark.gpu
+
+
+def both(P, runs=2, debug=("e", "tau", "last", "computed"), env=None):
+    out, used = [], 0
+    for val in ("2", "0"):                 # lanes form wherever it applies (also on sparse lists) / never
+        msgs = []
+        engine.set_log(lambda lvl, m: msgs.append(m), 5)
+        os.environ["TRX_LANES_WALK"] = val
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        try:
+            e = Engine(P.static)
+        finally:
+            os.environ.pop("TRX_LANES_WALK", None)
+            for k in (env or {}):
+                os.environ.pop(k, None)
+        res = [e.run(P.atm, P.opts, debug=debug) for _ in range(runs)]      # unhinted, then hinted (another step plan)
+        res.append(e.run(P.atm, P.opts))                                      # and a production run (range skipping on)
+        res.append(e.run(P.atm, P.opts))
+        e.close()
+        engine.set_log(None)
+        if val == "2":
+            used = sum("walk: lanes = lines" in m for m in msgs)
+        else:
+            assert not any("walk: lanes = lines" in m for m in msgs)
+        out.append(res)
+    return out[0], out[1], used
+
+
+def assert_same(a, b):
+    for ra, rb in zip(a, b):
+        sw = ra["computed"].astype(bool) if "computed" in ra else slice(None)
+        for k in ra:
+            if k == "e":
+                assert np.array_equal(ra[k][sw], rb[k][sw]), k
+            else:
+                assert np.array_equal(ra[k], rb[k]), k
+
+
+@pytest.mark.parametrize("case", ["eclipse_small", "transit_small", "coadd_thresh", "cloud_scatter", "multi_species",
+                                  "many_isotopes", "resample_transit", "midres_os4", "qscale_eclipse"])
+def test_lanes_walk_on_goldens(case):
+    P = Problem.from_cfg(os.path.join(GOLDEN, case, "case.cfg"))
+    a, b, _ = both(P)
+    assert_same(a, b)
+
+
+@pytest.mark.parametrize("nlayers,solution,S", [(100, "eclipse", "0"), (100, "transit", "3"), (100, "eclipse", "1"), (100, "eclipse", "8"),
+                                                (24, "transit", "5"), (31, "eclipse", "2")])
+def test_lanes_walk_demo_shape(tmp_path, nlayers, solution, S):
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=120_000, wnlow=2500, wnhigh=2800, wndelt=1.0, wnosamp=2160, nlayers=nlayers,
+                    solution=solution, toomuch=10.0, ethresh=1e-50, seed=11, ncia=2 if solution == "transit" else 1)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    a, b, used = both(P, env={"TRX_LANES_S": S})
+    assert used > 0, "the lanes form was never taken: the test compares nothing"
+    assert_same(a, b)
+    P.set_shard(37, 211)                       # a shard: only the ranges that reach it are launched
+    try:
+        sa, sb, used = both(P, runs=1, env={"TRX_LANES_S": S})
+    finally:
+        P.set_shard(0, P.nwn)
+    assert used > 0
+    assert_same(sa, sb)
+    assert np.array_equal(sa[-1]["spectrum"], a[-1]["spectrum"][37:211])
+
+
+def test_lanes_walk_threshold_and_coadding(tmp_path):
+    """A coarse fine grid (wnosamp 400: 2.5 lines per fine-grid point, co-added groups of up to ~10 lines)
+    and a threshold that drops groups."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=60_000, wnlow=2500, wnhigh=2560, wndelt=1.0, wnosamp=400, nlayers=60,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-4, seed=5)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    a, b, used = both(P)
+    assert_same(a, b)

@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 CXX = os.environ.get("CXX") or "g++"
 
 HIP_SOURCES = ["hip/trx_api.hip"]
-HIP_DEPS = ["hip/trx_kernels.hip.h", "hip/trx_walk.hip.h", "hip/trx_rows.hip.h", "hip/trx_tail.hip.h", "hip/trx_device.h", "trx_numerics.h", "trx_groups.h"]
+HIP_DEPS = ["hip/trx_kernels.hip.h", "hip/trx_walk.hip.h", "hip/trx_rows.hip.h", "hip/trx_tail.hip.h", "hip/trx_lanes.hip.h", "hip/trx_device.h", "trx_numerics.h", "trx_groups.h"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
              "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
 

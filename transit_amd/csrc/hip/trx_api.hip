@@ -31,6 +31,7 @@
 #include "trx_walk.hip.h"
 #include "trx_rows.hip.h"
 #include "trx_tail.hip.h"
+#include "trx_lanes.hip.h"
 #include "../trx_groups.h"
 
 using namespace trx;
@@ -87,6 +88,9 @@ struct trx_handle {
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
+  // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
+  // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
+  bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
@@ -383,6 +387,8 @@ int build_table(trx_handle *h, const trx_static *s)
     if (const char *e = std::getenv("TRX_CIA_WINDOW")) h->cia_window = std::atoi(e) != 0;
     if (const char *e = std::getenv("TRX_SHARD_FRAMES")) h->shard_frames = std::atoi(e) != 0;
     if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
+    if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }
+    if (const char *e = std::getenv("TRX_LANES_S")) h->lanes_s = std::max(0, std::min(kLanesMaxS, std::atoi(e)));
     // (run graphs are opt-in: on ROCm 7.2 hipGraphLaunch of this graph -- ~28 nodes on three streams --
     // costs the host as much as queueing them one by one, ~105 us, and the device runs it no faster:
     // 0.43 against 0.36 ms per spectrum, 0.218 against 0.210 for one shard of eight)
@@ -572,11 +578,21 @@ int prepare_lines(trx_handle *h, const trx_static *s)
   L.giown = h->d_giown.as<int32_t>(); L.giso = h->d_giso.as<int16_t>(); L.gwavn = h->d_gwavn.as<double>();
   L.gblock = h->d_gblock.as<int32_t>(); L.cnt_ge = h->d_cntge.as<int32_t>();
   if (h->walk_ok) {   // the walk's records (trx_walk.hip.h), built where the arrays already are
-    if ((rc = ensure(h, h->d_walk, sizeof(WalkLine) * ((size_t)n + 1)))) return rc;
+    if ((rc = ensure(h, h->d_walk, sizeof(WalkLine) * ((size_t)n + 1))) || (rc = ensure(h, h->d_linebase, sizeof(double) * ((size_t)n + 1)))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_linebase.p, 0, sizeof(double) * ((size_t)n + 1), h->stream));
+    {
+      std::vector<int> mg((size_t)nth + 1, 0);
+      parallel_parts((int64_t)h->h_gcount.size(), nth, [&](int t, int64_t g0, int64_t g1) {
+        int m = 0;
+        for (int64_t g = g0; g < g1; g++) m = std::max(m, (int)h->h_gcount[(size_t)g]);
+        mg[t] = m;
+      });
+      h->max_gcount = *std::max_element(mg.begin(), mg.end());
+    }
     hipLaunchKernelGGL(k_walk_records, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, h->stream, (long long)n, L.wavn, L.elow, L.gf,
                        L.lgroup, L.giown, s->osamp, h->d_walk.as<WalkLine>());
     hipLaunchKernelGGL(k_walk_marks, dim3((unsigned)((h->nwaves + 63) / 64)), dim3(64), 0, h->stream, h->nwaves, h->ngw, s->niso,
-                       h->d_wbase.as<int32_t>(), L.gblock, L.gfirst, L.gcount, h->d_walk.as<WalkLine>());
+                       h->d_wbase.as<int32_t>(), L.gblock, L.gfirst, L.gcount, h->d_walk.as<WalkLine>(), h->d_linebase.as<double>());
   }
   h->stats.nlines_inrange = h->ninrange; h->stats.ngroups = h->ngroups; h->stats.nadd = h->nadd;
   // ---- candidates for the layer maximum: lines no other line of their isotope dominates
@@ -1086,9 +1102,26 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     nw = (unsigned)cum;
     if (ns == 0) { A.nseg = 1; A.seg_w0[0] = 0; A.seg_cum[0] = 0; A.seg_cum[1] = 0; }     // nothing reaches: no wave does anything
   }
+  // steps of few layers with wide frames on a dense list: lanes = lines for the strengths (trx_lanes.hip.h)
+  const bool lanes = nw > 0 && !M.prof && A.tabw != nullptr && nb >= 8 && nc <= kLanesMaxLayers && h->lanes_walk &&
+                     h->max_gcount <= kLanesMaxGroup && (h->ngroups >= 8 * h->nwn || h->lanes_force);
   // steps of few layers: several ranges per wave (k_line_walk_packed: an instruction serves S lines)
-  const bool packed = nw > 0 && !M.prof && A.tabw != nullptr && nc <= h->packed_max_layers && h->packed_walk;
-  if (packed) {
+  const bool packed = !lanes && nw > 0 && !M.prof && A.tabw != nullptr && nc <= h->packed_max_layers && h->packed_walk;
+  if (lanes) {
+    // ranges per wave: one (measured at the demo size: 1, 2, 3, 4 ranges per wave 0.239 / 0.257 / 0.283 / 0.276 ms for
+    // the spectrum's two walks -- the last lines of a run already get lanes = (line, 4 or 8 layer sets))
+    int S = h->lanes_s;
+    if (S <= 0) S = 1;
+    LanesExtra X{h->d_linebase.as<double>(), S};
+    if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG)
+      log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames, " + std::to_string(S) + " ranges per wave");
+    const unsigned lw = (nw + (unsigned)S - 1) / (unsigned)S;
+    const dim3 grid((lw + kLanesWaves - 1) / kLanesWaves), block(64 * kLanesWaves);
+    const size_t lds = lanes_lds_bytes(nc);
+    if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 4>), grid, block, lds, st, A, X);
+    else         hipLaunchKernelGGL((k_line_walk_lanes<16, 4>), grid, block, lds, st, A, X);
+  }
+  else if (packed) {
     const int S = 64 / nc;
     const unsigned pw = (nw + (unsigned)S - 1) / (unsigned)S;
     const dim3 grid((pw + kWalkWaves - 1) / kWalkWaves), block(64 * kWalkWaves);

@@ -418,19 +418,25 @@ void k_walk_records(long long n, const double *__restrict__ wavn, const double *
 // one lane per line range: last members of the groups, base points of the rebased exponential
 __global__ __launch_bounds__(64)
 void k_walk_marks(int nwaves, int ngw, int niso, const int32_t *__restrict__ wbase, const int32_t *__restrict__ gblock,
-                  const int32_t *__restrict__ gfirst, const int32_t *__restrict__ gcount, WalkLine *__restrict__ out)
+                  const int32_t *__restrict__ gfirst, const int32_t *__restrict__ gcount, WalkLine *__restrict__ out,
+                  double *__restrict__ linebase /* [nlines]: wavenumber of every line's base point (k_line_walk_lanes) */)
 {
   const int w = blockIdx.x * 64 + threadIdx.x;
   if (w >= nwaves) return;
   int b = 0;
   while (b + 1 < niso && w >= wbase[b + 1]) b++;
   const int g0 = gblock[b] + (w - wbase[b]) * ngw, g1 = min(g0 + ngw, gblock[b + 1]);
-  for (int g = g0; g < g1; g++) out[gfirst[g] + gcount[g] - 1].meta |= 2;
+  for (int g = g0; g < g1; g++) {
+    const int la = gfirst[g], lz = la + gcount[g] - 1;
+    out[lz].meta |= 2;
+    for (int l = la + 1; l <= lz; l++) out[l].cell = out[la].cell;      // (members carry their group's cell: k_line_walk_lanes cuts its blocks where the cell changes)
+  }
   const int l0 = gfirst[g0], l1 = gfirst[g1 - 1] + gcount[g1 - 1];
   double w0 = HUGE_VAL;
   for (int l = l0; l < l1; l++) {
     const double wv = out[l].wavn;
     if (l == l0 || w0 - wv > kRebaseSpan) { out[l].meta |= 4; w0 = wv; }
+    linebase[l] = w0;
   }
 }
 
