@@ -40,7 +40,7 @@ constexpr int kLanesMaxS = 8;          // ranges per wave at most
 constexpr int kLanesMaxGroup = 16;     // members of the longest co-added group this kernel takes
 constexpr int kLanesMaxLayers = 32;
 constexpr int kLanesLayK = 12;         // doubles per layer record
-constexpr int kLanesBases = 8;         // base points of the rebased exponential a batch's table holds (more: computed per line)
+constexpr int kLanesBases = 5;         // base points of the rebased exponential a batch's table holds (more: computed per line)
 
 struct LanesExtra {
   const double *wbase;                 // [nlines] wavenumber of the line's base point (rebased exponential)
@@ -48,7 +48,8 @@ struct LanesExtra {
 };
 
 // per wave: kk [32][nc] doubles, at [32][nc] words, the layers' records (nc rounded up to even)
-__host__ __device__ inline int lanes_wave_doubles(int nc) { const int ne = (nc + 1) & ~1; return (kLanesBatch + 2) * ne + (kLanesBatch + 2) * ne / 2 + kLanesLayK * ne + kLanesBases * ne; }
+__host__ __device__ inline int lanes_at_doubles(int ne) { return (((kLanesBatch + 1) * ne / 2) + 1) & ~1; }      // (the offsets' words, a whole number of 16-byte units)
+__host__ __device__ inline int lanes_wave_doubles(int nc) { const int ne = (nc + 1) & ~1; return (kLanesBatch + 1) * ne + lanes_at_doubles(ne) + kLanesLayK * ne + kLanesBases * ne; }
 __host__ __device__ inline size_t lanes_lds_bytes(int nc) { return (size_t)kLanesWaves * 8 * (size_t)lanes_wave_doubles(nc); }
 
 // lane i <- lane i + 1 of the wave (DPP wave_shl:1; lane 63 keeps `old`)
@@ -66,18 +67,17 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   constexpr int Rc = NB / 2 - 1, NS = NB / 2, LPL = 2, BL = kLanesBatch;
   static_assert(NB == 8 || NB == 16, "frames of 8 or 16 bins");
   if (!A.eager && A.flags[0] == 0) return;
-  __shared__ double s_thr[kMaxDop + 1];
+  const double *s_thr = A.dthr;                              // (the steps of the Doppler index: read where a run starts and where the index steps -- from memory)
   __shared__ double s_e2[64];
   extern __shared__ double s_dyn[];
-  for (int i = threadIdx.x; i <= A.ndop; i += 64 * kLanesWaves) s_thr[i] = A.dthr[i];
   if (threadIdx.x < 64) s_e2[threadIdx.x] = A.e2tab[threadIdx.x];
   __syncthreads();                                           // (the only workgroup barrier: from here the waves are on their own)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nc = A.nc, ne = (nc + 1) & ~1;                   // (ne: layers rounded up to even -- a lane pair of phase 1 takes two)
   double *s_kk = s_dyn + (size_t)wv * lanes_wave_doubles(nc);                // [BL lines + 1][ne]
-  uint32_t *s_at = (uint32_t *)(s_kk + (BL + 2) * ne);                        // [BL lines + 1][ne]
-  double (*LK)[kLanesLayK] = (double (*)[kLanesLayK])(s_kk + (BL + 2) * ne + (BL + 2) * ne / 2);     // [ne] the layers' records
-  double *s_E0 = s_kk + (BL + 2) * ne + (BL + 2) * ne / 2 + kLanesLayK * ne;              // [kLanesBases][ne] exp(ct * base point)
+  uint32_t *s_at = (uint32_t *)(s_kk + (BL + 1) * ne);                        // [BL lines + 1][ne]
+  double (*LK)[kLanesLayK] = (double (*)[kLanesLayK])(s_kk + (BL + 1) * ne + lanes_at_doubles(ne));     // [ne] the layers' records
+  double *s_E0 = s_kk + (BL + 1) * ne + lanes_at_doubles(ne) + kLanesLayK * ne;              // [kLanesBases][ne] exp(ct * base point)
 
   // ---- the wave's ranges: launched indices L0 .. L0 + nq - 1, lane q holds range q's numbers
   const int nlaunch = A.nseg > 0 ? A.seg_cum[A.nseg] : A.P.nwaves;
