@@ -2274,6 +2274,19 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (tail_spec) { HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); (vertical ? TA.E.flux : TA.M.out) = (double *)dp; }
       HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_small, 0)); TA.host_flags = (int *)dp;
     }
+    // Every address the tail reads or writes, checked on the host before the launch: a null or stale one
+    // here is a wild access of a whole grid (round 3's one memory fault -- a work-in-progress tail storing
+    // the spectrum through a pinned buffer that no branch had allocated yet -- was exactly this kind).
+    {
+      bool ok = TA.nsteps >= 1 && TA.nsteps <= kTailSteps && nct >= 3 && nct <= kTailLayers && TA.gblock && TA.e &&
+                TA.T.ecs && TA.T.er && TA.T.tau && TA.T.last && TA.T.flags && TA.T.status && TA.T.rad &&
+                (vertical ? (TA.T.acc && TA.T.lay && TA.T.gw && TA.E.flux && TA.E.intens && TA.E.temp && TA.E.e2tab)
+                          : (TA.T.hrs && TA.T.hr0 && TA.T.gw && TA.M.out && TA.M.ip && TA.M.gw && TA.M.gh0 && TA.M.status)) &&
+                (!extras_on || (TA.T.xf_scat && TA.T.xf_cloud)) && (!tail_direct || TA.host_flags);
+      for (int k = 0; k < TA.nsteps && ok; k++)
+        ok = TA.S[k].part && TA.S[k].nc >= 1 && TA.S[k].nc <= kWalkLayers && TA.S[k].P.blo && TA.S[k].P.bhi && TA.S[k].P.off && TA.S[k].P.wbase;
+      if (!ok) return fail(h, TRX_E_HIP, "internal: incomplete arguments for the ray tail (not launched)");
+    }
     const dim3 tgrid((unsigned)((nsh + kTailRays - 1) / kTailRays)), tblock(kTailThreads);
     if (!vertical) {
       if (extras_on) hipLaunchKernelGGL((k_ray_tail<0, true>), tgrid, tblock, 0, st, TA);
