@@ -55,11 +55,11 @@ def parse():
     ap.add_argument("--layer-chunk", type=int, default=0)
     ap.add_argument("--solution", choices=("eclipse", "transit"), default="eclipse")
     ap.add_argument("--ncia", type=int, default=1)
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak",
-                    help="N>1 headline: weak = every GPU gets its own demo-sized slice of a band and line list grown "
-                         "N-fold (the wavenumber axis partitions with no exchange inside the data path: per-GPU work is "
-                         "what stays fixed); strong = the ONE CH4-demo run split N ways (2501 rays are too few for 8 "
-                         "GPUs: DESIGN.md section 5).  The other mode rides along as config.<mode>")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N>1 headline: strong = the ONE CH4 2-4 um demo run split N ways -- BASELINE.json's metric "
+                         "(wall-clock of that run at 1/2/4/8 GPUs; 2501 rays are too few to fill 8 GPUs: DESIGN.md "
+                         "section 5); weak = every GPU gets its own demo-sized slice of a band and line list grown "
+                         "N-fold.  The other mode rides along as config.<mode>")
     ap.add_argument("--no-extras", action="store_true",
                     help="N>1: skip the secondary measurements (weak scaling; BASELINE configs[4] split N ways)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,7 +76,7 @@ def kernel_source_hash():
     """Fingerprint of the kernel sources a committed PMC profile must match to be quoted."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h", "trx_tail.hip.h"):
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h", "trx_tail.hip.h", "trx_lanes.hip.h"):
         h.update(open(os.path.join(ROOT, "transit_amd", "csrc", "hip", f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -84,7 +84,7 @@ def kernel_source_hash():
 def production_launches(kernels, kernel, launch_key):
     """{name: launches} of the PRODUCTION instantiations of `kernel` in a profile summary that belong to
     the bench's step plan.  Names carry their template arguments -- trx::k_line_walk<NB, PROF, LPL>,
-    trx::k_accumulate_rows<COUNT, M> -- and the second-to-first boolean is the counting switch: those
+    trx::k_line_walk_lanes<NB, D>, trx::k_accumulate_rows<COUNT, M> -- and a boolean is the counting switch: those
     with it on (instrumented variants, one launch per bench run) are left out by PARSING the arguments.
     The plan's kernels are the ones every timed run launches; an instantiation that only the first,
     unhinted run of a handle meets (a frame size on the way down) has a handful of launches in the
@@ -92,12 +92,15 @@ def production_launches(kernels, kernel, launch_key):
     prod = {}
     for name, k in kernels.items():
         m = re.match(r"(?:void )?trx::(\w+)(?:<([^>]*)>)?", name)
-        if not m or (m.group(1) != kernel and not (kernel == "k_line_walk" and m.group(1) == "k_line_walk_packed")):
+        if not m or (m.group(1) != kernel and not (kernel == "k_line_walk" and m.group(1) in ("k_line_walk_packed", "k_line_walk_lanes"))):
             continue
         targs = [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
         if "true" in targs:            # PROF / COUNT
             continue
-        prod[name] = float(k[launch_key])
+        # weights: the launches of the TRACE run (bench.py at its default steps -- the step plan's own mix
+        # of kernels) where the summary has them; a PMC pass is three steps behind two warm-ups, whose first,
+        # unhinted run launches other instantiations
+        prod[name] = float(k.get("trace_calls") or k[launch_key])
     if not prod:
         return {}
     top = max(prod.values())
@@ -354,16 +357,22 @@ def main():
                     dist.all_gather_into_tensor(gathered, spec_local.cpu())
 
         ms_step = time_steps(step, fence, warmup, steps, reduce_max if world > 1 else None)
+        # rider: the same step timed over at least 200 more steps right behind the timed region (no further
+        # warm-up).  The headline keeps the driver's K and W; with K = 20 its 7 ms sit on a device whose
+        # clocks are still on their way up (5 warm-up steps are 2 ms of GPU work): 0.362 ms per step
+        # against 0.345 over 200 and 0.341 over 2000 steps, same box, same build (round 4, gpurun_out/r4_base_*).
+        steady_steps = max(200, steps) if steps < 2000 else 0
+        ms_steady = time_steps(step, fence, 0, steady_steps, reduce_max if world > 1 else None) if steady_steps else ms_step
         # the same steps once more with the production kernels bracketed by HIP events on the
         # streams they are launched on (profile 1): every launch counts, sum / launches is what
         # a kernel trace reports as the average
         opts.profile = 1
-        ev = {"ms_k_sweep": 0.0, "ms_k_accum": 0.0, "ms_tau": 0.0, "ms_run_total": 0.0, "sweep_launches": 0, "runs": 0}
+        ev = {"ms_k_sweep": 0.0, "ms_k_walk": 0.0, "ms_k_accum": 0.0, "ms_tau": 0.0, "ms_run_total": 0.0, "sweep_launches": 0, "runs": 0}
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.run_device(P.atm, opts, spec_local.data_ptr())
             s1 = eng.stats()
-            for k in ("ms_k_sweep", "ms_k_accum", "ms_tau", "ms_run_total", "sweep_launches"):
+            for k in ("ms_k_sweep", "ms_k_walk", "ms_k_accum", "ms_tau", "ms_run_total", "sweep_launches"):
                 ev[k] += s1[k]
             ev["runs"] += 1
         ev["ms_per_step_with_events"] = 1e3 * (time.perf_counter() - t0) / max(steps, 1)
@@ -379,16 +388,17 @@ def main():
             full = np.concatenate([g[k * mpad: k * mpad + (h - l)] for k, (l, h) in enumerate(bounds)])
         else:
             full = spec_local[: hi - lo].cpu().numpy()
-        out = dict(P=P, eng=eng, stats=stats, ms_step=ms_step, layers_needed=layers_needed, full=full, nwn=nwn,
+        out = dict(P=P, eng=eng, stats=stats, ms_step=ms_step, ms_steady=ms_steady, steady_steps=steady_steps or steps,
+                   layers_needed=layers_needed, full=full, nwn=nwn,
                    bounds=bounds, t_first_create=t_first_create, opts=opts, dir=d, static=st)
         if not keep:
             eng.close()
             out["eng"] = None
         return out
 
-    # ---- headline: the CH4-demo run.  N>1: weak scaling -- one demo-sized slice per GPU, the band
-    # and the line list grown N-fold -- unless --scaling strong (the one demo split N ways; either
-    # way the other mode is measured too and reported under config).
+    # ---- headline: the CH4-demo run.  N>1: that ONE run split N ways (BASELINE.json's metric: strong
+    # scaling) unless --scaling weak (one demo-sized slice per GPU, the band and the line list grown
+    # N-fold); either way the other mode is measured too and reported under config.
     grow = world if (args.scaling == "weak" and world > 1) else 1
     wnhigh = args.wnlow + grow * (args.wnhigh - args.wnlow)
     d = shared_case("demo", grow * args.lines, wnhigh=wnhigh)
@@ -472,25 +482,33 @@ def main():
     if rank == 0:
         L, R, nang = stats["nlines_inrange"], stats["layers_swept"], int(opts.nangles)
         launches = max(int(stats["sweep_launches"]), 1)
-        walked = int(stats["walk_steps"]) == launches
-        mixed = 0 < int(stats["walk_steps"]) < launches      # upper layers walked, deep ones in the two-kernel form
-        line_k = "k_line_walk" if walked else "k_group_sweep"
-        acc_k = "k_walk_combine" if walked else "k_accumulate"
+        wsteps = int(stats["walk_steps"]); ssteps = launches - wsteps           # walk steps / two-kernel steps of a run
+        walked = wsteps == launches
+        mixed = 0 < wsteps < launches            # upper layers walked, deep ones in the two-kernel form
         ev = stats["events"]
         runs = max(ev["runs"], 1)
-        # per run, from the event-timed repeat of the timed region (production kernels)
-        kern = {line_k: ev["ms_k_sweep"] / runs, acc_k: ev["ms_k_accum"] / runs}
-        dom = max(kern, key=kern.get)
         nbins = hi - lo
-        # Bytes the dominant kernel's data flow must move per launch.  The walk reads one 32-byte
-        # record per line, 4 bytes per accumulated bin (table) and writes its partial records
-        # (8 B per layer of the step); the combine reads those and writes e.  Two-kernel form: see DESIGN.md.
-        if walked:
-            alg = {line_k: 32.0 * L * launches + 4.0 * stats["sum_bins"] + 8.0 * stats["walk_record_lanes"],
-                   acc_k: 8.0 * stats["walk_record_lanes"] + 8.0 * R * nbins}
-        else:
-            G = stats["ngroups"]
-            alg = {line_k: 27.0 * L * launches + 9.0 * G * R, acc_k: 13.0 * G * R + 4.0 * stats["sum_bins"] + 8.0 * R * nbins}
+        G = stats["ngroups"]
+        Rw = int(stats["walk_layers"]); Rs = R - Rw                               # layers swept by walk steps / by two-kernel steps
+        bins_w = stats["sum_bins_walk"]; bins_s = stats["sum_bins"] - bins_w
+        # Per run, from the event-timed repeat of the timed region (production kernels), each kernel family with
+        # ITS launches and ITS bytes.  The walk reads one 32-byte record per line and step, 4 bytes per accumulated
+        # bin (table) and writes its partial records (8 B per layer of the step); the combine reads those and
+        # writes e.  Two-kernel form: 27 B per line and step + 9 B per group and layer written (strength, Doppler
+        # index), then 13 B per group and layer read back + 4 B per accumulated bin + e.
+        acc_name = "k_walk_combine" if walked else ("k_accumulate" if wsteps == 0 else "k_walk_combine + k_accumulate")
+        kern, alg, nlaunch = {}, {}, {}
+        if wsteps:
+            kern["k_line_walk"] = ev["ms_k_walk"] / runs; nlaunch["k_line_walk"] = wsteps
+            alg["k_line_walk"] = 32.0 * L * wsteps + 4.0 * bins_w + 8.0 * stats["walk_record_lanes"]
+        if ssteps:
+            kern["k_group_sweep"] = ev["ms_k_sweep"] / runs; nlaunch["k_group_sweep"] = ssteps
+            alg["k_group_sweep"] = 27.0 * L * ssteps + 9.0 * G * Rs
+        kern[acc_name] = ev["ms_k_accum"] / runs; nlaunch[acc_name] = launches
+        alg[acc_name] = (8.0 * stats["walk_record_lanes"] + 8.0 * Rw * nbins) + (13.0 * G * Rs + 4.0 * bins_s + 8.0 * Rs * nbins)
+        dom = max(kern, key=kern.get)
+        line_k = "k_line_walk" if wsteps else "k_group_sweep"
+        dlaunch = max(nlaunch[dom], 1)
         ach = alg[dom] / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
         # whole run against SURVEY 8(d): B_alg follows the reference's flow (two scans of the 26-byte
         # line record per layer), B_min is the layer-fused minimum (lines once, 4 B per bin, the
@@ -500,9 +518,9 @@ def main():
         # the roof this kernel is actually near: vector-instruction issue.  A wave64 instruction holds
         # its SIMD's 16 lanes for 4 clocks; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock.
         wkey = "%d x %d x %d" % (nwn, nlayer, int(st.nlines))
-        prof_k = "k_accumulate_rows" if (dom == "k_accumulate" and args.wnosamp == 1) else dom     # (the kernel's name in a trace)
+        prof_k = "k_accumulate_rows" if ("k_accumulate" in dom and args.wnosamp == 1) else dom.split(" ")[0]     # (the kernel's name in a trace)
         valu = measured_valu(prof_k, wkey) if world == 1 else None
-        valu_frac = (valu * 4.0 / (kern[dom] / launches * 1e-3 * 1024 * 2.4e9)) if (valu and kern[dom] > 0) else None
+        valu_frac = (valu * 4.0 / (kern[dom] / dlaunch * 1e-3 * 1024 * 2.4e9)) if (valu and kern[dom] > 0) else None
         tr_pair, traffic_file = measured_traffic(prof_k, wkey) if world == 1 else (None, None)
         traffic, traffic_raw = tr_pair if tr_pair else (None, None)
         out = {
@@ -510,6 +528,7 @@ def main():
             "value": nwn * layers_needed / (ms_step * 1e-3),
             "unit": "wavenumber-points*layers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "ms_per_step_steady": M["ms_steady"], "steady_steps": M["steady_steps"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]%s): %g-%g cm-1 @%g cm-1, wnosamp %d, "
@@ -526,9 +545,9 @@ def main():
                            world, [h - l for l, h in M["bounds"]]) if world > 1 else "one GPU",
                        "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps (<= 64 layers where "
                                                           "the line walk applies, one lane per layer)",
-                       "steps_per_run": launches, "walk_steps_per_run": int(stats["walk_steps"]),
-                       "line_kernel": "k_line_walk (%d steps) + k_group_sweep (%d steps): ms_kernels sums both under the "
-                                      "second name" % (int(stats["walk_steps"]), launches - int(stats["walk_steps"])) if mixed else line_k,
+                       "steps_per_run": launches, "walk_steps_per_run": wsteps,
+                       "line_kernel": "k_line_walk (%d steps, %d layers) + k_group_sweep (%d steps, %d layers): each with its own "
+                                      "time and bytes in ms_kernels / roofline" % (wsteps, Rw, ssteps, Rs) if mixed else line_k,
                        "depth_hint": "step plan ends at the previous run's deepest layer (retrieval-loop reuse; "
                                      "warm-up runs provide it); a run that needs more goes on from there",
                        "ms_create_voigt_table_kernels": stats["ms_create_table"],
@@ -551,9 +570,9 @@ def main():
                          "traffic": traffic, "traffic_uncorrected": traffic_raw, "traffic_source": traffic_file,
                          "bmin_frac": frac_or_none(b_min_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS),
                          "balg_frac": frac_or_none(b_alg_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                         "alg_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": kern[dom] / launches,
+                         "alg_bytes_per_launch": alg[dom] / dlaunch, "avg_launch_ms": kern[dom] / dlaunch,
                          "binding_roof": "fp64-rate vector-instruction issue", "valu_issue_frac": valu_frac,
-                         "launches": launches,
+                         "launches": dlaunch,
                          "note": "achieved = bytes the dominant kernel's data flow must move (32 B per line record, 4 B "
                                  "per accumulated bin, its partial records) / its measured time (HIP events on its own "
                                  "stream).  bmin_frac / balg_frac = the whole spectrum against SURVEY 8(d)'s layer-fused "
@@ -565,19 +584,19 @@ def main():
                                  "(launch time x 1024 SIMDs x 2.4 GHz); counters and probes in profiles/, DESIGN.md section 4"},
         }
         out["config"].update(extras)
-        if dom == "k_accumulate" and ach > HBM_PEAK_GBS:
+        if "k_accumulate" in dom and ach > HBM_PEAK_GBS:
             # wide-profile regime (fine grids): neighbouring lines read the same profile rows, staged in
             # LDS once per run of lines (k_accumulate_rows) or served by L1 (k_accumulate_wide) -- the
             # 4 B per accumulated bin never reach HBM.  The kernel is bound by the fp64 vector pipe:
             # one fused multiply-add per bin (2 flop) at one instruction per 4 clocks and SIMD, next to
             # the three lane reads and the address add every (line, tile) pair costs.
             # peak = MI355X vector fp64 spec.  Beside it: the LDS read roof (256 B per clock and CU).
-            tf = 2.0 * stats["sum_bins"] / (kern[dom] * 1e-3) / 1e12
+            tf = 2.0 * bins_s / (kern[dom] * 1e-3) / 1e12
             lds_peak = 256 * 256 * 2.4                        # GB/s: 256 CUs x 256 B/clk x 2.4 GHz
             out["roofline"].update(bound="fp64-valu", achieved=tf, peak=FP64_VALU_TFLOPS, unit="TFLOP/s",
                                    frac=tf / FP64_VALU_TFLOPS, binding_roof="fp64-rate vector-instruction issue",
-                                   lds_read_GBs=8.0 * stats["sum_bins"] / (kern[dom] * 1e-3) / 1e9, lds_peak_GBs=lds_peak,
-                                   lds_frac=8.0 * stats["sum_bins"] / (kern[dom] * 1e-3) / 1e9 / lds_peak,
+                                   lds_read_GBs=8.0 * bins_s / (kern[dom] * 1e-3) / 1e9, lds_peak_GBs=lds_peak,
+                                   lds_frac=8.0 * bins_s / (kern[dom] * 1e-3) / 1e9 / lds_peak,
                                    note="profile rows staged in LDS (reused by neighbouring lines): no HBM fraction is "
                                         "quoted for this kernel.  achieved = 2 flop per accumulated bin / launch time; "
                                         "lds_frac = 8 B per accumulated bin (the staged doubles) / launch time against "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRX_ABI_VERSION 2
+#define TRX_ABI_VERSION 3
 
 typedef enum {
   TRX_OK            =  0,
@@ -209,9 +209,9 @@ typedef struct {
   double  ms_create_table;/* device time of the Voigt-table build              */
   double  ms_run_total;   /* device time of the last run, first to last kernel (profiled runs, trx_opts.profile; else 0) */
   double  ms_sweep;       /* line-sweep kernels (profile >= 1; as ms_k_* and ms_tau) */
-  double  ms_k_sweep;      /* sum over launches of the line kernel (k_line_walk, or k_group_sweep where profiles are wide) */
-  double  ms_k_sticky;     /* unused (the sticky Doppler index is computed once per run)  */
-  double  ms_k_accum;     /* sum over launches of k_walk_combine / k_accumulate  */
+  double  ms_k_sweep;      /* sum over launches of k_group_sweep (the steps whose profiles are wider than the walk's widest frame) */
+  double  ms_k_walk;       /* sum over launches of the walk kernels (k_line_walk, k_line_walk_lanes, k_line_walk_packed)      */
+  double  ms_k_accum;     /* sum over launches of k_walk_combine and k_accumulate(_wide/_rows) */
   int64_t sweep_launches; /* launches of each sweep kernel (gated no-op ones too) */
   double  ms_tau;         /* optical-depth kernels                             */
   double  ms_cia;         /* host wall time of queueing the CIA kernels          */
@@ -224,6 +224,8 @@ typedef struct {
   int64_t walk_records;   /* partial-sum records (64 lane slots each) those steps wrote   */
   int64_t walk_record_lanes; /* lane slots of them actually written and read: sum over steps of
                              records x layers of the step (8 bytes each)                 */
+  int64_t walk_layers;    /* layers of the last run swept by walk steps (the rest of layers_swept: two-kernel steps) */
+  int64_t sum_bins_walk;  /* the part of sum_bins accumulated by walk steps (counting runs)                          */
 } trx_stats;
 
 typedef struct trx_handle trx_handle;

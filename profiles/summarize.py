@@ -58,7 +58,7 @@ def kernel_source_hash():
     fingerprint matches the kernel sources of the tree it runs from."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h", "trx_tail.hip.h"):
+    for f in ("trx_walk.hip.h", "trx_kernels.hip.h", "trx_rows.hip.h", "trx_tail.hip.h", "trx_lanes.hip.h"):
         h.update(open(os.path.join(HERE, "..", "transit_amd", "csrc", "hip", f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -74,6 +74,20 @@ def workload_key(src):
         return None
 
 
+def trace_calls(d):
+    """{kernel: launches} of the TRACE run (bench.py at its default steps: the step plan's own mix of
+    kernels, which is what bench.py weights per-launch averages with)."""
+    try:
+        out = {}
+        with open(find(d, "kernel_stats.csv", "trace")) as f:
+            for row in csv.DictReader(f):
+                if "trx::" in row["Name"]:
+                    out[short(row["Name"])] = int(row["Calls"])
+        return out
+    except (SystemExit, Exception):
+        return {}
+
+
 def counter_pass(d, tag, prefix, names, suffix, what, key):
     """One PMC pass (its own rocprofv3 run) -> profiles/<tag>_<suffix>.json: per kernel and counter the
     average per launch (summed over the XCD instances the CSV reports) and the number of launches."""
@@ -86,6 +100,9 @@ def counter_pass(d, tag, prefix, names, suffix, what, key):
                     out[k]["launches"] = len(v)
         except SystemExit:
             return
+    calls = trace_calls(d)
+    for k in out:
+        out[k]["trace_calls"] = calls.get(k, 0)
     dst = os.path.join(HERE, tag + "_" + suffix + ".json")
     json.dump({"source": "rocprofv3 --kernel-trace --pmc " + " ".join(names) + " (own pass)", "what": what,
                "workload_key": key, "kernel_sources": kernel_source_hash(), "kernels": out},
@@ -151,6 +168,10 @@ def main():
                 "WRITE_SIZE_KB_avg_active_launch": sum(wa) / len(wa),
                 "hbm_bytes_per_active_launch": (2.0 * sum(fa) / len(fa) + sum(wa) / len(wa)) * 1024.0,
             }
+        if a.src:
+            calls = trace_calls(a.src)
+            for k in kernels:
+                kernels[k]["trace_calls"] = calls.get(k, 0)
         doc = {
             "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + a.cmd,
             "workload": a.workload, "workload_key": workload_key(a.src) if a.src else None,

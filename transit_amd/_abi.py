@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_double_p = C.POINTER(C.c_double)
 c_int16_p = C.POINTER(C.c_int16)
@@ -81,10 +81,11 @@ class TrxStats(C.Structure):
         ("layers_swept", C.c_int64), ("neval", C.c_int64), ("nskip", C.c_int64),
         ("sum_bins", C.c_int64), ("table_floats", C.c_int64),
         ("ms_create_table", C.c_double), ("ms_run_total", C.c_double), ("ms_sweep", C.c_double),
-        ("ms_k_sweep", C.c_double), ("ms_k_sticky", C.c_double), ("ms_k_accum", C.c_double),
+        ("ms_k_sweep", C.c_double), ("ms_k_walk", C.c_double), ("ms_k_accum", C.c_double),
         ("sweep_launches", C.c_int64),
         ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_host_total", C.c_double),
         ("ms_spectrum", C.c_double), ("ncandidates", C.c_int64), ("walk_steps", C.c_int64), ("walk_records", C.c_int64), ("walk_record_lanes", C.c_int64),
+        ("walk_layers", C.c_int64), ("sum_bins_walk", C.c_int64),
     ]
 
     def as_dict(self):

@@ -934,7 +934,7 @@ void layer_dev(const double *df, const int32_t *di, const LayerHost &LH, int nr,
 
 // ---- per-kernel timing of a profiled run: (start, end) event pairs on the stream of the kernel ----
 struct Spans {
-  enum Kind { kSweep = 0, kSticky = 1, kAccum = 2, kTau = 3 };
+  enum Kind { kSweep = 0, kWalk = 1, kAccum = 2, kTau = 3 };
   struct Span { hipEvent_t a, b; int kind; };
   std::vector<Span> v;
   int begin(int kind, hipStream_t st) {
@@ -1068,7 +1068,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   }
   // this buffer's previous records (two steps ago) must have been combined
   if (ev_reuse) HIPCHK(h, hipStreamWaitEvent(st, ev_reuse, 0));
-  if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
+  if (sp && sp->begin(Spans::kWalk, st)) return fail(h, TRX_E_HIP, "event");
   WalkArgs A{};
   A.lines = h->d_walk.as<WalkLine>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
   A.gblock = h->d_gblock.as<int32_t>(); A.P = P;
@@ -2009,6 +2009,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (prof) HIPCHK(h, hipEventRecord(ev.a, st));
 
   h->stats.walk_steps = 0; h->stats.walk_records = 0; h->stats.walk_record_lanes = 0;
+  std::vector<uint8_t> layer_walked((size_t)nr, 0);         // layers swept by walk steps (stats)
   if (!h->has_grid && log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
     std::string ln = "run: walk frame (bins) per layer, top first; 0 = two-kernel form:";
     for (int r = nr - 1; r >= 0; r--) ln += " " + std::to_string(walk_frame_bins(h, psmax, r));
@@ -2223,6 +2224,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         if (rc) return rc;
         walked = nb != 0;
         step_walked = walked;
+        if (walked) for (int c = 0; c < nc; c++) layer_walked[(size_t)(r_top - c)] = 1;
       }
       if (st_tau != st && !walked) {     // the optical depth of this step follows its extinction
         HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], st));
@@ -2376,8 +2378,11 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   trx_stats &S = h->stats;
   S.layers_swept = flags_host[2];
   h->hint_layers = flags_host[4];
-  S.neval = S.nskip = S.sum_bins = 0;
-  for (int r = 0; r < nr; r++) { S.sum_bins += (int64_t)counters[3*r]; S.neval += (int64_t)counters[3*r+1]; S.nskip += (int64_t)counters[3*r+2]; }
+  S.neval = S.nskip = S.sum_bins = S.sum_bins_walk = S.walk_layers = 0;
+  for (int r = 0; r < nr; r++) {
+    S.sum_bins += (int64_t)counters[3*r]; S.neval += (int64_t)counters[3*r+1]; S.nskip += (int64_t)counters[3*r+2];
+    if (layer_walked[(size_t)r]) { S.walk_layers++; S.sum_bins_walk += (int64_t)counters[3*r]; }
+  }
   float ms = 0; if (prof) (void)hipEventElapsedTime(&ms, ev.a, ev.b); S.ms_run_total = ms;
   S.ms_cia = ms_cia;
   S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
@@ -2389,15 +2394,15 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                   1e3 * (S.ms_host_total - std::chrono::duration<double, std::milli>(t_host_queued - t_host0).count()));
     log_msg(TRX_LOG_DEBUG, std::string(b) + "; queueing by phase (us):" + laps);
   }
-  S.ms_k_sweep = S.ms_k_sticky = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
+  S.ms_k_sweep = S.ms_k_walk = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
   if (prof) {
     // every launch counts (also the ~4 us gated ones after all rays stopped), so that
     // sum / launches is the average a kernel trace reports
     double t[4] = {0, 0, 0, 0};
     spans.sum(t);
-    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_sticky = t[Spans::kSticky]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
+    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_walk = t[Spans::kWalk]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
     S.sweep_launches = nchunks;
-    S.ms_sweep = S.ms_k_sweep + S.ms_k_sticky + S.ms_k_accum;
+    S.ms_sweep = S.ms_k_sweep + S.ms_k_walk + S.ms_k_accum;
   }
 
   if (dbg) {
