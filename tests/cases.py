@@ -9,7 +9,8 @@ from transit_amd.host import Problem
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["eclipse_small", "transit_small", "coadd_thresh", "cloud_scatter", "transit_modm1",
          "highres_fine", "midres_os4", "multi_species", "scat_polar", "qscale_eclipse", "dumps_transit",
-         "resample_radius", "resample_transit", "many_isotopes", "saveext_transit"]
+         "resample_radius", "resample_transit", "many_isotopes", "saveext_transit",
+         "cloud_opa", "cloud_b17", "cloud_f18", "cloud_p19"]
 
 
 class Golden:

@@ -23,6 +23,9 @@ from transit_amd import synth  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "transit")
 REF_REENTRY = os.path.join(ROOT, "oracle", "_ref", "transit_reentry")   # oracle/ref_reentry_main.c
+# the same reference with tau.c (unmodified) compiled by clang -ftrivial-auto-var-init=zero (oracle/Makefile):
+# defined output for the cloud models that read tau.c's uninitialised mean_dens[] (cloud flags 2-5)
+REF_ZINIT = os.path.join(ROOT, "oracle", "_ref", "transit_zinit")
 
 KEEP = ["case.cfg", "case.atm", "case.tli", "molecules.dat", "cia_h2h2.dat", "cia_h2he.dat",
         "spectrum.dat", "toomuch.dat", "tau.dat", "mol_extion.dat", "CIA.dat", "intens.dat",
@@ -49,10 +52,19 @@ CASES = {
     "cloud_scatter": dict(nlines=2000, wnlow=3000, wnhigh=3040, nlayers=40, solution="transit",
                           seed=7, line_margin=3.0,
                           extra={"cloudtop": "-2.0", "scattering": "1.5"}),
+    # The parametrised cloud types opa/B17/F18/P19 (cloud flags 2-5, extinction.c:630-693): the reference accumulates
+    # their mean density into an uninitialised array (tau.c:129,203) and its gcc build returns NaN for all four;
+    # `transit_zinit` is the same sources with tau.c compiled by clang -ftrivial-auto-var-init=zero (for `--cloud ext`
+    # the two builds agree to the last printed digit in both geometries)
+    "cloud_opa": dict(nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution="eclipse", seed=7, zinit=True, keep_dumps3=True,
+                      extra={"cloud": "opa,1e-3,-3.0,0.5"}),
+    "cloud_b17": dict(nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution="transit", seed=7, zinit=True, keep_dumps3=True,
+                      extra={"cloud": "B17,1e-7,-3.0,0.5,-1.5"}),
+    "cloud_f18": dict(nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution="eclipse", seed=7, zinit=True, keep_dumps3=True,
+                      extra={"cloud": "F18,1e-7,-3.0,0.5,2.0,0.8,1e-5"}),
+    "cloud_p19": dict(nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution="transit", seed=7, zinit=True, keep_dumps3=True,
+                      extra={"cloud": "P19,1e-9,-3.0,0.5,-2.0,1e-22,3000.0"}),
     # polarizability scattering (scattering flag 2, extinction.c:617-621) in emission geometry.
-    # (The parametrised cloud types opa/B17/F18/P19 -- cloud flags 2-5 -- cannot be pinned: the
-    # reference accumulates their mean density into an uninitialised array, tau.c:129,203, and
-    # this build of it returns NaN for all four.)
     "scat_polar": dict(nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution="eclipse", seed=8,
                        extra={"scattering": "polar"}),
     # opaque-disc modulation level and a transparent planet, odd layer count
@@ -155,6 +167,9 @@ def main():
         extra.update({"savefiles": "yes"})
         reentry = kw.pop("reentry", False)
         keep3 = kw.pop("keep_dumps3", False)
+        exe = REF_ZINIT if kw.pop("zinit", False) else REF
+        if not os.path.exists(exe):
+            sys.exit("%s is missing: run `make -C oracle ref` first" % exe)
         if reentry:
             import numpy as np
             atm = synth.demo_atmosphere(kw["nlayers"])
@@ -186,7 +201,7 @@ def main():
                                  capture_output=True, text=True)
             if log.returncode != 0:
                 sys.exit("reference re-entry driver failed:\n%s\n%s" % (log.stdout[-2000:], log.stderr[-2000:]))
-        log = subprocess.run([REF, "-c", "case.cfg"], cwd=tmp, capture_output=True, text=True)
+        log = subprocess.run([exe, "-c", "case.cfg"], cwd=tmp, capture_output=True, text=True)
         if log.returncode != 0:
             sys.exit("reference failed on %s:\n%s\n%s" % (name, log.stdout[-2000:], log.stderr[-2000:]))
         shutil.rmtree(d, ignore_errors=True)

@@ -330,9 +330,10 @@ def test_messages_go_to_the_callback():
                                    "F18,1e-7,-3.0,0.5,2.0,0.8,1e-5", "P19,1e-9,-3.0,0.5,-2.0,1e-22,3000.0"])
 @pytest.mark.parametrize("solution", ["eclipse", "transit"])
 def test_cloud_models_against_oracle(tmp_path, cloud, solution):
-    """The five cloud parametrisations of extinction.c:630-693 (--cloud type,ext,top,bot,...).
-    Only `ext` and the cloudtop shortcut can be pinned on the reference (DESIGN.md section 6:
-    its build returns NaN for the others); here the kernels are held to the CPU restatement."""
+    """The five cloud parametrisations of extinction.c:630-693 (--cloud type,ext,top,bot,...) in both
+    geometries against the CPU restatement.  (The reference itself pins them too since round 4: goldens
+    cloud_opa / cloud_b17 / cloud_f18 / cloud_p19 from its build with tau.c's mean_dens[] zero-initialised,
+    DESIGN.md section 6 -- tests/test_oracle_golden.py, tests/test_gpu_parity.py.)"""
     d = str(tmp_path / "cl")
     synth.make_case(d, nlines=1500, wnlow=3000, wnhigh=3030, nlayers=30, solution=solution, seed=7,
                     extra={"cloud": cloud})

@@ -301,7 +301,7 @@ def check_savefiles(got_dir, case, tol):
         assert rel_err(gv, rv) < tol, name
 
 
-@pytest.mark.parametrize("case", ["qscale_eclipse", "dumps_transit"])
+@pytest.mark.parametrize("case", ["qscale_eclipse", "dumps_transit", "cloud_opa", "cloud_b17", "cloud_f18", "cloud_p19"])
 def test_savefiles_writers_on_the_oracle_arrays(workdir, case):
     """tau.dat, CIA.dat, mol/total/cloud/scatt_extion.dat (tau.c:180-190, 293-335, 386-515) from
     the oracle's intermediates: pins the writers -- including the reference's lazily swept rows
