@@ -91,6 +91,7 @@ struct trx_handle {
   // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
   // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
   bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
+  bool no_row_copy = false;
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
@@ -131,12 +132,6 @@ struct trx_handle {
   std::vector<double> og_temp; std::vector<int32_t> og_molidx; DevBuf d_og_o, d_og_layer, d_og_itemp, d_iso_mx, d_pm, d_kmaxpm;
   trx_stats stats{};
   int hint_layers = 0;       // layers the previous run needed (deepest toomuch crossing + 1)
-  // A hinted run as ONE graph launch (run_once): everything a spectrum queues -- the copy of its
-  // inputs, ~25 kernels on three streams, the copies back -- captured the second time a run with the
-  // same plan signature comes by, replayed from then on.  What changes from run to run travels
-  // through the pinned input block, whose address the graph holds.
-  struct RunGraph { uint64_t sig = 0; hipGraphExec_t exec = nullptr; int r_top = 0, nchunks = 0, nwalks = 0; int64_t walk_steps = 0, walk_records = 0, walk_record_lanes = 0; uint64_t used = 0; };
-  std::vector<RunGraph> graphs; uint64_t last_sig[2] = {0, 0}, graph_clock = 0; bool graph_off = false;   // (last_sig: per half of the alternating layer maxima)
   DevBuf d_e_saved; std::vector<uint8_t> saved;          // trx_restore_extinction: [nlayer][nsh] and the flags (empty: none)
   void *h_spec = nullptr; size_t h_spec_bytes = 0;     // pinned staging of the spectrum (trx_run hands over pageable memory)
 };
@@ -280,6 +275,25 @@ int plan_table(trx_handle *h, const trx_static *s, std::vector<ProfileJob> &jobs
   return TRX_OK;
 }
 
+// Environment variables read at trx_create -- ALL of them, in one place.  Each selects between two forms
+// of the same computation that give the same bits (the tests named compare them side by side); none is
+// needed in production, none changes a result.  (The A/B switches of forms that lost -- run graphs, the
+// range size, tile-size tuning beyond what a test forces -- are gone with those forms.)
+void test_switches(trx_handle *h)
+{
+  h->no_row_copy = std::getenv("TRX_NO_ROW_COPY") != nullptr;              // wide frames without the row copy (test_gpu_properties)
+  h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");                      // k_accumulate_wide instead of k_accumulate_rows (test_gpu_rows)
+  if (const char *v = std::getenv("TRX_ROWS_M8_FROM")) h->row_m8_from = std::atoll(v);      // ... and its tile size per layer (test_gpu_rows)
+  h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");                      // k_line_walk_packed never / for steps of up to N layers (test_gpu_packed)
+  if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
+  if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }      // k_line_walk_lanes never / also on sparse lists (test_gpu_lanes)
+  if (const char *e = std::getenv("TRX_LANES_S")) h->lanes_s = std::max(0, std::min(kLanesMaxS, std::atoi(e)));                       // ... ranges per wave
+  if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;            // the step kernels instead of k_ray_tail (test_gpu_tail)
+  if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;      // ... copy commands instead of stores into pinned memory
+  if (const char *e = std::getenv("TRX_CIA_WINDOW")) h->cia_window = std::atoi(e) != 0;        // the CIA spline over the whole table (test_gpu_cia_window)
+  if (const char *e = std::getenv("TRX_SHARD_FRAMES")) h->shard_frames = std::atoi(e) != 0;    // a shard with the list's frames (test_gpu_shard_frames)
+}
+
 int build_table(trx_handle *h, const trx_static *s)
 {
   std::vector<ProfileJob> jobs;
@@ -379,21 +393,8 @@ int build_table(trx_handle *h, const trx_static *s)
       int front, stride; walk_row_layout((jobs[j].nv - 1) / s->osamp + 1, front, stride);
       joffW[j] = totW; totW += (long long)s->osamp * stride;
     }
-    h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !std::getenv("TRX_NO_ROW_COPY");      // (the variable: tests of the fallback)
-    h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");
-    h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");
-    if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TRX_CIA_WINDOW")) h->cia_window = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TRX_SHARD_FRAMES")) h->shard_frames = std::atoi(e) != 0;
-    if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
-    if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }
-    if (const char *e = std::getenv("TRX_LANES_S")) h->lanes_s = std::max(0, std::min(kLanesMaxS, std::atoi(e)));
-    // (run graphs are opt-in: on ROCm 7.2 hipGraphLaunch of this graph -- ~28 nodes on three streams --
-    // costs the host as much as queueing them one by one, ~105 us, and the device runs it no faster:
-    // 0.43 against 0.36 ms per spectrum, 0.218 against 0.210 for one shard of eight)
-    h->graph_off = std::getenv("TRX_RUN_GRAPH") == nullptr;
-    if (const char *v = std::getenv("TRX_ROWS_M8_FROM")) h->row_m8_from = std::atoll(v);
+    test_switches(h);
+    h->tabw_ok = 4 * (totW + 2 * (long long)kTabPad) < (1LL << 32) && !h->no_row_copy;
     if (h->tabw_ok) {
       std::vector<WalkProfile> desc((size_t)s->ndop * s->nlor);
       size_t j = 0;
@@ -549,11 +550,8 @@ int prepare_lines(trx_handle *h, const trx_static *s)
     // of them, and a range is one wave's serial work -- with 512-group ranges one shard of eight of an
     // 8*10^6-line list had 1 700 waves for 1 024 SIMDs (its 2-bin walk 226 us instead of 108).
     int ngw = 32;
-    if (const char *e = std::getenv("TRX_WALK_GROUPS")) ngw = std::max(1, std::atoi(e));
-    else {
-      while (ngw < 64 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;
-      while (ngw < 512 && (int64_t)gfirst.size() / ngw > 131072) ngw *= 2;
-    }
+    while (ngw < 64 && (int64_t)gfirst.size() / ngw > 16384) ngw *= 2;
+    while (ngw < 512 && (int64_t)gfirst.size() / ngw > 131072) ngw *= 2;
     h->ngw = ngw;
     h->h_wbase.assign(s->niso + 1, 0);
     for (int b = 0; b < s->niso; b++) h->h_wbase[b + 1] = h->h_wbase[b] + (gblock[b + 1] - gblock[b] + ngw - 1) / ngw;
@@ -1577,7 +1575,6 @@ void trx_destroy(trx_handle *h)
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_in) (void)hipHostFree(h->h_in);
   if (h->h_spec) (void)hipHostFree(h->h_spec);
-  for (auto &g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   delete h;
 }
 
@@ -1614,34 +1611,7 @@ int trx_width_grids(const trx_handle *h, double *adop, double *alor)
 namespace {
 }  // namespace
 
-static uint64_t fnv1a(uint64_t hsh, const void *p, size_t n)
-{
-  const unsigned char *b = (const unsigned char *)p;
-  for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 0x100000001b3ull; }
-  return hsh;
-}
-#define SIG_ADD(x) sig = fnv1a(sig, &(x), sizeof(x))
-
-constexpr int kRetryWithoutGraph = -1000;      // run_once: a capture or an instantiation failed; nothing of the run was executed
-
-static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum,
-                    trx_debug *dbg, bool allow_graph);
-
-static int run_impl(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum,
-                    trx_debug *dbg)
-{
-  if (!h) return TRX_E_ARG;
-  const int parity = h->kmax_parity; const bool clean = h->kmax_clean;
-  int rc = run_once(h, a, o, spectrum, d_spectrum, dbg, !h->graph_off);
-  if (rc == kRetryWithoutGraph) {                // (logged there; the handle goes on without graphs)
-    h->graph_off = true; h->kmax_parity = parity; h->kmax_clean = clean;
-    rc = run_once(h, a, o, spectrum, d_spectrum, dbg, false);
-  }
-  return rc;
-}
-
-static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum,
-                    trx_debug *dbg, bool allow_graph)
+static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum, trx_debug *dbg)
 {
   if (!h || !a || !o) return TRX_E_ARG;
   const auto t_host0 = std::chrono::steady_clock::now();
@@ -1789,51 +1759,6 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     cia_densities(h, a, hin + off_cd);
     std::memcpy(hin + off_i32, LH.i32.data(), 4 * n_i32);
   }
-  // ---- one graph launch for the whole run?  Only hinted production runs (the plan is then a
-  // function of what the signature holds); captured the second time the same signature comes by.
-  enum { kQueue, kCapture, kReplay } gmode = kQueue;
-  trx_handle::RunGraph *gentry = nullptr;
-  uint64_t sig = 0xcbf29ce484222325ull;
-  {
-    const bool kmax_reset = h->d_kmax.bytes < sizeof(double) * 2 * (size_t)nr || !h->kmax_clean || h->kmax_nr != nr;
-    const bool ok = allow_graph && pipelined && stop_at_hint_ok && !prof && !dbg && !eager && h->ngroups > 0 && !kmax_reset && h->saved.empty();
-    if (ok) {
-      SIG_ADD(nr); sig = fnv1a(sig, psmax, sizeof(int32_t) * nli);
-      SIG_ADD(h->kmax_parity); SIG_ADD(h->hint_layers); SIG_ADD(h->walk_temp_ok); SIG_ADD(in_bytes);
-      SIG_ADD(o->solution); SIG_ADD(o->toomuch); SIG_ADD(o->ethresh); SIG_ADD(o->wn_fct); SIG_ADD(o->nangles);
-      if (o->solution == TRX_SOL_ECLIPSE) sig = fnv1a(sig, o->angles_deg, sizeof(double) * (size_t)o->nangles);
-      SIG_ADD(o->starrad_cm); SIG_ADD(o->transparent); SIG_ADD(o->modlevel); SIG_ADD(o->cloud_flag);
-      SIG_ADD(o->cloud_ext); SIG_ADD(o->cloud_top); SIG_ADD(o->cloud_bot); SIG_ADD(o->cloud_gamma); SIG_ADD(o->cloud_Q);
-      SIG_ADD(o->cloud_r); SIG_ADD(o->cloud_sig); SIG_ADD(o->cloud_refwn); SIG_ADD(o->scat_flag); SIG_ADD(o->scat_logext);
-      SIG_ADD(o->layer_chunk); SIG_ADD(a->rad_fct); SIG_ADD(d_spectrum); const bool to_host = spectrum != nullptr; SIG_ADD(to_host);
-      bool pruned = h->ncand > 0;                           // (as layer_maxima_and_sticky decides)
-      for (int r = 0; r < nr && pruned; r++) if (kExpCte * kTliEfct * h->wn_i / a->temp[r] < 1e-5) pruned = false;
-      SIG_ADD(pruned);
-      for (auto &c : h->cia) {                              // the CIA tables' temperature windows (cia_device)
-        const double fx2 = c.temp.front(), lx2 = c.temp.back();
-        const bool skip = a->temp[0] > lx2 || a->temp[nr - 1] < fx2;
-        int fj = 0, lj = nr;
-        if (!skip) { while (fj < nr && a->temp[fj] < fx2) fj++; for (int j = 0; j < lj; j++) if (a->temp[j] > lx2) lj = j; }
-        SIG_ADD(skip); SIG_ADD(fj); SIG_ADD(lj);
-      }
-      for (auto &g : h->graphs) if (g.sig == sig && g.exec) gentry = &g;
-      if (gentry) gmode = kReplay;
-      else if (h->last_sig[h->kmax_parity & 1] == sig) gmode = kCapture;
-      h->last_sig[h->kmax_parity & 1] = sig;
-      if (gmode != kQueue && spectrum && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
-        if (h->h_spec) (void)hipHostFree(h->h_spec);
-        h->h_spec = nullptr; h->h_spec_bytes = 0;
-        HIPCHK(h, hipHostMalloc(&h->h_spec, sizeof(double) * (size_t)nsh, hipHostMallocDefault));
-        h->h_spec_bytes = sizeof(double) * (size_t)nsh;
-      }
-    } else h->last_sig[h->kmax_parity & 1] = 0;
-  }
-  const bool replay = gmode == kReplay, capturing = gmode == kCapture;
-  // (an error return while capturing must end the capture: the stream would stay in capture mode)
-  struct CaptureGuard {
-    hipStream_t st; bool active = false;
-    ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); } }
-  } cap_guard{st};
   // the whole front end of a run goes to the stream the line sweep runs on (the main stream
   // joins it at the first optical depth): no cross-stream hop before the first sweep kernel
   // Streams.  The front end (inputs, layer maxima), the walks and everything that follows the
@@ -1859,14 +1784,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     char b[64]; std::snprintf(b, sizeof b, " %s %.0f", what, 1e3 * std::chrono::duration<double, std::milli>(n - t_lap).count());
     laps += b; t_lap = n;
   };
-  if (capturing) {
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      log_msg(TRX_LOG_WARN, "stream capture refused: this handle goes on without run graphs");
-      return kRetryWithoutGraph;
-    }
-    cap_guard.active = true;
-  }
-  if (!replay) HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep));
+  HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep));
   lap("h2d");
   // With lines, every element of e the path reads is written first (the accumulation kernels
   // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
@@ -1934,17 +1852,15 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     ~Drain() { if (armed) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->stream); } }
   } drain{h};
   // ---- inputs are on their way: release the other streams --------------------------------
-  if (!replay) {
   HIPCHK(h, hipEventRecord(h->ev_inputs, st_sweep));
   HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
   if (pipelined) HIPCHK(h, hipStreamWaitEvent(st_early, h->ev_inputs, 0));
-  }
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
   bool init_done = false;
   // (the start-up pass rides along with k_layer_max only where it is small next to it: a few
   // thousand threads striding over 10^7 rays took 20 ms at configs[4])
   const bool ride_along = nsh <= 65536;
-  if (!replay) {
+  {
   if (!ride_along) {
     hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
     init_done = true;
@@ -2157,25 +2073,15 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     tail_mode = ok && steps >= 1;
   }
   // (flags into the pinned block the host reads; the spectrum into pinned memory too when the caller wants it on the host)
-  const bool tail_direct = tail_mode && gmode == kQueue && h->tail_direct, tail_spec = tail_direct && spectrum && !d_spectrum;
+  const bool tail_direct = tail_mode && h->tail_direct, tail_spec = tail_direct && spectrum && !d_spectrum;
   if (tail_spec && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
     if (h->h_spec) (void)hipHostFree(h->h_spec);
     h->h_spec = nullptr; h->h_spec_bytes = 0;
     HIPCHK(h, hipHostMalloc(&h->h_spec, sizeof(double) * (size_t)nsh, hipHostMallocDefault));
     h->h_spec_bytes = sizeof(double) * (size_t)nsh;
   }
-  bool replay_now = replay;
   for (;;) {
-  if (replay_now) {
-    // the whole first pass -- inputs, front end, steps, spectrum, copies back -- is one launch
-    if (hipGraphLaunch(gentry->exec, st) != hipSuccess) return fail(h, TRX_E_HIP, "hipGraphLaunch");
-    gentry->used = ++h->graph_clock;
-    r_top = gentry->r_top; nchunks = gentry->nchunks; nwalks = gentry->nwalks;
-    h->stats.walk_steps = gentry->walk_steps; h->stats.walk_records = gentry->walk_records; h->stats.walk_record_lanes = gentry->walk_record_lanes;
-    replay_now = false;
-    lap("graph");
-    t_host_queued = std::chrono::steady_clock::now();
-  } else {
+  {
   for (; r_top >= 0; ) {
     const int swept = nr - 1 - r_top;
     int nb = 0, nc = 0; bool last_step = false;
@@ -2260,7 +2166,6 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (pending.active) { if ((rc = run_side(pending))) return rc; pending.active = false; }
 
   // ---- spectrum ---------------------------------------------------------------
-  if (capturing && pipelined && !resumed) early_dirty = true;     // (the side queue joined the capture when it waited for the inputs: it must come back)
   if ((rc = join_early())) return rc;
   if (resumed) HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes the spectrum a second time)
   if (tail_mode && !resumed) {
@@ -2321,44 +2226,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (prof) HIPCHK(h, hipEventRecord(ev.b, st));
 
   // ---- results back -----------------------------------------------------------
-  const bool staged = gmode != kQueue && spectrum && !resumed;     // graph runs: the spectrum goes through the handle's pinned buffer
   {   // one copy into pinned memory: flags, status and (profiled runs) the counters
     const size_t nb = count ? 128 + 24 * (size_t)nr : 128;
     if (!(tail_direct && !resumed)) HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
-    if (spectrum && !(tail_spec && !resumed)) HIPCHK(h, hipMemcpyAsync(staged ? h->h_spec : (void *)spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
+    if (spectrum && !(tail_spec && !resumed)) HIPCHK(h, hipMemcpyAsync((void *)spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
     lap("spectrum+copies");
   }
-  if (capturing && !resumed) {
-    // ---- the pass is recorded, not run: make it a graph and launch that
-    hipGraph_t g = nullptr;
-    cap_guard.active = false;
-    hipError_t e1 = hipStreamEndCapture(st, &g);
-    hipGraphExec_t ex = nullptr;
-    if (e1 == hipSuccess && g) e1 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    if (g) (void)hipGraphDestroy(g);
-    if (e1 != hipSuccess || !ex) {
-      (void)hipGetLastError();
-      log_msg(TRX_LOG_WARN, std::string("run graph not built (") + hipGetErrorString(e1) + "): this handle goes on without run graphs");
-      drain.armed = false;                       // nothing of this run was queued
-      return kRetryWithoutGraph;
-    }
-    if (h->graphs.size() >= 8) {                 // the least recently used one makes room
-      size_t v = 0;
-      for (size_t k = 1; k < h->graphs.size(); k++) if (h->graphs[k].used < h->graphs[v].used) v = k;
-      (void)hipGraphExecDestroy(h->graphs[v].exec);
-      h->graphs.erase(h->graphs.begin() + (long)v);
-    }
-    trx_handle::RunGraph G;
-    G.sig = sig; G.exec = ex; G.r_top = r_top; G.nchunks = nchunks; G.nwalks = nwalks; G.used = ++h->graph_clock;
-    G.walk_steps = h->stats.walk_steps; G.walk_records = h->stats.walk_records; G.walk_record_lanes = h->stats.walk_record_lanes;
-    h->graphs.push_back(G);
-    if (hipGraphLaunch(ex, st) != hipSuccess) return fail(h, TRX_E_HIP, "hipGraphLaunch");
-    log_msg(TRX_LOG_DEBUG, "run: captured as a graph (" + std::to_string(h->graphs.size()) + " kept)");
-  }
   t_host_queued = std::chrono::steady_clock::now();
-  }   // (not replayed)
+  }
   {
-    const bool staged = (gmode != kQueue || tail_spec) && spectrum && !resumed;
+    const bool staged = tail_spec && spectrum && !resumed;       // the tail stored the spectrum into the handle's pinned buffer
     HIPCHK(h, hipStreamSynchronize(st));
     if (staged) std::memcpy(spectrum, h->h_spec, sizeof(double) * (size_t)nsh);
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));
@@ -2499,13 +2376,13 @@ int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double
 int trx_run(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, trx_debug *dbg)
 {
   if (!spectrum) return TRX_E_ARG;
-  return run_impl(h, a, o, spectrum, nullptr, dbg);
+  return run_once(h, a, o, spectrum, nullptr, dbg);
 }
 
 int trx_run_device(trx_handle *h, const trx_atm *a, const trx_opts *o, void *d_spectrum, trx_debug *dbg)
 {
   if (!d_spectrum) return TRX_E_ARG;
-  return run_impl(h, a, o, nullptr, d_spectrum, dbg);
+  return run_once(h, a, o, nullptr, d_spectrum, dbg);
 }
 
 }  // extern "C"
