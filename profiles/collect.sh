@@ -5,8 +5,8 @@
 # (arguments after the tag go to bench.py: the workload)
 # Three separate runs (kernel trace; PMC FETCH_SIZE; PMC WRITE_SIZE -- never combined, as
 # MI355X_MICROARCH.md prescribes), plus one SQ instruction-mix pass for the walk kernels.  The raw
-# CSVs land in gpurun_out/<tag>/; `python profiles/summarize.py --tag <tag> --from gpurun_out/<tag>`
-# then writes the summaries that are committed here.
+# CSVs are summarised on the GPU box (profiles/summarize.py) into gpurun_out/<tag>_summary/: copy those
+# files into profiles/ to commit them.
 TAG=${1:-r03}
 shift
 WORKLOAD="$@"
@@ -29,4 +29,7 @@ STEPS="--steps 3 --warmup 2" run sq --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_
 STEPS="--steps 3 --warmup 2" run wait --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE &&
 STEPS="--steps 3 --warmup 2" run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT &&
 grep -h '"metric"' $OUT/trace.log | tail -1 > $OUT/bench_line_under_trace.json
-ls -la $OUT
+# summarised where the data is; the raw per-dispatch counter CSVs (tens of MB per pass) stay behind
+python3 $ROOT/profiles/summarize.py --from $OUT --tag $TAG --dest $ROOT/gpurun_out/${TAG}_summary --cmd "$BENCH" --workload "${WORKLOAD:-bench.py defaults (CH4-demo shape)}" &&
+rm -f $OUT/*_counter_collection.csv
+ls -la $OUT $ROOT/gpurun_out/${TAG}_summary

@@ -25,6 +25,7 @@ import json
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+HERE_OUT = HERE
 
 
 def find(d, suffix, prefix=""):
@@ -103,7 +104,7 @@ def counter_pass(d, tag, prefix, names, suffix, what, key):
     calls = trace_calls(d)
     for k in out:
         out[k]["trace_calls"] = calls.get(k, 0)
-    dst = os.path.join(HERE, tag + "_" + suffix + ".json")
+    dst = os.path.join(HERE_OUT, tag + "_" + suffix + ".json")
     json.dump({"source": "rocprofv3 --kernel-trace --pmc " + " ".join(names) + " (own pass)", "what": what,
                "workload_key": key, "kernel_sources": kernel_source_hash(), "kernels": out},
               open(dst, "w"), indent=1)
@@ -128,15 +129,19 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--from", dest="src", help="directory written by profiles/collect.sh (trace/fetch/write/sq CSVs)")
     ap.add_argument("--tag", required=True)
+    ap.add_argument("--dest", default=None, help="where the summaries go (default: this directory); collect.sh summarises on the GPU box into gpurun_out/ and drops the raw counter CSVs, which run to tens of MB per pass")
     ap.add_argument("--cmd", default="python3 bench.py --steps 3 --warmup 1")
     ap.add_argument("--workload", default="CH4-demo shape, 1e6 lines, 2501 wn, 100 layers (bench.py defaults)")
     a = ap.parse_args()
+    global HERE_OUT
+    HERE_OUT = a.dest or HERE
+    os.makedirs(HERE_OUT, exist_ok=True)
     if a.src:
         a.trace = a.fetch = a.write = a.src
 
     if a.trace:
         src = find(a.trace, "kernel_stats.csv", "trace" if a.src else "")
-        dst = os.path.join(HERE, a.tag + "_kernel_stats.csv")
+        dst = os.path.join(HERE_OUT, a.tag + "_kernel_stats.csv")
         with open(src) as f, open(dst, "w", newline="") as g:
             r = csv.reader(f)
             w = csv.writer(g, quoting=csv.QUOTE_ALL)
@@ -183,7 +188,7 @@ def main():
                           "Infinity-Cache hits are counted by these counters, not excluded.",
             "kernels": kernels,
         }
-        dst = os.path.join(HERE, a.tag + "_pmc_traffic.json")
+        dst = os.path.join(HERE_OUT, a.tag + "_pmc_traffic.json")
         json.dump(doc, open(dst, "w"), indent=1)
         print("wrote", dst)
     if a.src:
@@ -191,7 +196,7 @@ def main():
         line = os.path.join(a.src, "bench_line_under_trace.json")
         if os.path.exists(line):
             import shutil
-            shutil.copy(line, os.path.join(HERE, a.tag + "_bench_line_under_trace.json"))
+            shutil.copy(line, os.path.join(HERE_OUT, a.tag + "_bench_line_under_trace.json"))
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <functional>
 
 #include <algorithm>
 #include <chrono>
@@ -1611,13 +1612,11 @@ int trx_width_grids(const trx_handle *h, double *adop, double *alor)
 namespace {
 }  // namespace
 
-static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum, trx_debug *dbg)
+// ---- a run in three parts: what it is given (run_check, run_host_inputs), what it queues (run_once),
+// ---- what it hands back (run_finish)
+static int run_check(trx_handle *h, const trx_atm *a, const trx_opts *o)
 {
-  if (!h || !a || !o) return TRX_E_ARG;
-  const auto t_host0 = std::chrono::steady_clock::now();
-  auto t_host_queued = t_host0;
-  const int nr = a->nlayer, nmol = h->nmol;
-  const int64_t nsh = h->nsh;
+  const int nr = a->nlayer;
   if (nr < 3) return fail(h, TRX_E_ARG, "at least three layers are needed");
   if (!h->saved.empty() && (int)h->saved.size() != nr) return fail(h, TRX_E_ARG, "restored extinction has another number of layers");
   if (!h->saved.empty() && h->has_grid) return fail(h, TRX_E_UNSUPPORTED, "restored extinction together with an opacity grid");
@@ -1628,29 +1627,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (!(o->ethresh > 0)) return fail(h, TRX_E_ARG, "ethresh must be positive");
   if ((o->cloud_flag >= 2 || o->scat_flag == 2) && !a->abund && o->cloud_flag >= 2) return fail(h, TRX_E_ARG, "cloud model needs abundances");
   for (int i = 1; i < nr; i++) if (!(a->radius[i] > a->radius[i-1])) return fail(h, TRX_E_ARG, "radii must ascend");
-  HIPCHK(h, hipSetDevice(h->device));
-  hipStream_t st = h->stream;
-  const bool eager = o->eager != 0, prof = o->profile != 0, count = o->profile >= 2;
-  // A handle remembers how deep the previous spectrum went (hint_layers) and plans its steps to
-  // end exactly there; the run returns at that depth and goes on only if rays are still open.
-  const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
-  int rc;
+  return TRX_OK;
+}
 
-  // ---- layer prologue (extinction.c:364-395) --------------------------------
-  LayerHost LH;
-  if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
-  h->walk_temp_ok = true;
-  for (int r = 0; r < nr; r++) if (a->temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
-  const size_t nli = LH.nli;
+// the host's share of a run's inputs beyond prep_layers: the layer scalars of the scattering / cloud
+// models, the vertical rays' Simpson weights and per-layer chain constants, the impact parameters
+static void run_host_inputs(trx_handle *h, const trx_atm *a, LayerHost &LH, bool vertical, int gstride, size_t mw_doubles,
+                            size_t n_geom_all, std::vector<double> &geom, std::vector<double> &ipv)
+{
+  const int nr = a->nlayer, nmol = h->nmol;
   std::vector<double> &f64 = LH.f64;
-  const int32_t *psmax = LH.psmax;
-  // Layers per step.  The walk (narrow profiles) takes up to 64 layers, one per lane; its cost
-  // hardly depends on how many lanes are busy, so its steps are as large as the plan allows.
-  // The two-kernel form keeps a strength buffer per layer in flight: at most kMaxChunk, and
-  // 8 where the profiles are wide (a tile only learns between steps that its rays stopped).
-  // Optical depths are integrated in sub-steps of at most tau_cap layers.
-  const int tau_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;
-  const int user_chunk = o->layer_chunk > 0 ? std::max(3, o->layer_chunk) : 0;
   // layer-only scalars of the scattering / cloud models (tau.c:193-214, extinction.c:617-621)
   double *press = &f64[LH.extra_off], *tempk = press + nr, *mdens = tempk + nr, *nH = mdens + nr,
          *scat_pol = nH + nr, *radv = scat_pol + nr;
@@ -1670,15 +1656,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     mdens[r] = md * mm; scat_pol[r] = sp;
   }
 
-  // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
-  // (eclipse geometry uses tabulated weights for its one three-point ray only: rows of one pair,
-  // no modulation table -- 9 KB instead of 330 KB to build, copy and ship per run at 100 layers)
-  const bool vertical = o->solution == TRX_SOL_ECLIPSE;
-  const int gstride = vertical ? 4 : 4 * (nr / 2 + 1);
-  const size_t mw_doubles = vertical ? 0 : (size_t)(nr + 1) * gstride;
-  const size_t n_geom_all = (size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr +
-                            (vertical ? (size_t)kVertLay * nr : 0);       // (vertical rays: the chain's per-layer constants behind the rest)
-  std::vector<double> geom(vertical ? n_geom_all : 1, 0.0);       // (transit: device-built, see below)
+  geom.assign(vertical ? n_geom_all : 1, 0.0);                    // (transit: device-built, k_slant_geometry)
   {
     std::vector<double> sx(nr + 1);
     if (vertical) {
@@ -1709,8 +1687,133 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       // transit geometry: built on the device (k_slant_geometry), nothing to prepare or ship here
     }
   }
-  std::vector<double> ipv(nr);
+  ipv.resize((size_t)nr);
   for (int i = 0; i < nr; i++) ipv[i] = a->radius[nr - 1 - i];
+
+}
+
+// what a run hands back: the handle's statistics and depth hint, the debug copies, the status raised on the device
+struct RunOutcome {
+  int flags[8], status[4];
+  const std::vector<unsigned long long> *counters; const std::vector<uint8_t> *layer_walked;
+  Spans *spans; hipEvent_t ev_a, ev_b;                    // profiled runs (null: not profiled)
+  int nchunks; double ms_cia;
+  std::chrono::steady_clock::time_point t_host0, t_host_prep, t_host_queued; const std::string *laps;
+};
+
+static int run_finish(trx_handle *h, const trx_atm *a, const trx_opts *o, trx_debug *dbg, const RunOutcome &Q,
+                      const std::function<void(TauArgs &)> &model_args)
+{
+  const int nr = a->nlayer; const int64_t nsh = h->nsh;
+  hipStream_t st = h->stream;
+  int rc;
+  trx_stats &S = h->stats;
+  S.layers_swept = Q.flags[2];
+  h->hint_layers = Q.flags[4];
+  S.neval = S.nskip = S.sum_bins = S.sum_bins_walk = S.walk_layers = 0;
+  for (int r = 0; r < nr; r++) {
+    S.sum_bins += (int64_t)(*Q.counters)[3*r]; S.neval += (int64_t)(*Q.counters)[3*r+1]; S.nskip += (int64_t)(*Q.counters)[3*r+2];
+    if ((*Q.layer_walked)[(size_t)r]) { S.walk_layers++; S.sum_bins_walk += (int64_t)(*Q.counters)[3*r]; }
+  }
+  float ms = 0; if (Q.spans) (void)hipEventElapsedTime(&ms, Q.ev_a, Q.ev_b); S.ms_run_total = ms;
+  S.ms_cia = Q.ms_cia;
+  S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - Q.t_host0).count();
+  if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
+    char b[160];
+    std::snprintf(b, sizeof b, "run: host %.0f us preparing inputs, %.0f us queueing, %.0f us waiting for the device",
+                  1e3 * std::chrono::duration<double, std::milli>(Q.t_host_prep - Q.t_host0).count(),
+                  1e3 * std::chrono::duration<double, std::milli>(Q.t_host_queued - Q.t_host_prep).count(),
+                  1e3 * (S.ms_host_total - std::chrono::duration<double, std::milli>(Q.t_host_queued - Q.t_host0).count()));
+    log_msg(TRX_LOG_DEBUG, std::string(b) + "; queueing by phase (us):" + *Q.laps);
+  }
+  S.ms_k_sweep = S.ms_k_walk = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
+  if (Q.spans) {
+    // every launch counts (also the ~4 us gated ones after all rays stopped), so that
+    // sum / launches is the average a kernel trace reports
+    double t[4] = {0, 0, 0, 0};
+    Q.spans->sum(t);
+    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_walk = t[Spans::kWalk]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
+    S.sweep_launches = Q.nchunks;
+    S.ms_sweep = S.ms_k_sweep + S.ms_k_walk + S.ms_k_accum;
+  }
+
+  if (dbg) {
+    if (dbg->e)    HIPCHK(h, hipMemcpy(dbg->e, h->d_e.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    if (dbg->e_cs) HIPCHK(h, hipMemcpy(dbg->e_cs, h->d_ecs.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    if (dbg->tau) {
+      std::vector<double> t((size_t)nr * nsh);
+      HIPCHK(h, hipMemcpy(t.data(), h->d_tau.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+      for (int64_t w = 0; w < nsh; w++) for (int i = 0; i < nr; i++) dbg->tau[(size_t)w * nr + i] = t[(size_t)i * nsh + w];
+    }
+    if (dbg->last) {
+      std::vector<int> l(nsh);
+      HIPCHK(h, hipMemcpy(l.data(), h->d_last.p, sizeof(int) * nsh, hipMemcpyDeviceToHost));
+      for (int64_t w = 0; w < nsh; w++) dbg->last[w] = l[w];
+    }
+    if (dbg->intens && o->solution == TRX_SOL_ECLIPSE)
+      HIPCHK(h, hipMemcpy(dbg->intens, h->d_intens.p, sizeof(double) * o->nangles * nsh, hipMemcpyDeviceToHost));
+    if (dbg->computed) for (int r = 0; r < nr; r++) dbg->computed[r] = (r >= nr - S.layers_swept) ? 1 : 0;
+    if (dbg->er) HIPCHK(h, hipMemcpy(dbg->er, h->d_er.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    if (dbg->e_scat || dbg->e_cloud) {
+      DevBuf d_x;
+      if ((rc = ensure(h, d_x, sizeof(double) * 2 * (size_t)nr * nsh))) return rc;
+      TauArgs T{};
+      T.nr = nr; T.nsh = nsh; T.lo = h->lo; T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct;
+      model_args(T);
+      double *xs = d_x.as<double>(), *xc = xs + (size_t)nr * nsh;
+      hipLaunchKernelGGL(k_extras_dump, dim3((unsigned)((nsh + 255) / 256), (unsigned)nr), dim3(256), 0, st, T, xs, xc);
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (dbg->e_scat)  HIPCHK(h, hipMemcpy(dbg->e_scat, xs, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+      if (dbg->e_cloud) HIPCHK(h, hipMemcpy(dbg->e_cloud, xc, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
+    }
+  }
+  if (Q.status[0] == 1) return fail(h, TRX_E_NOTREACHED, "optical depth never reached toomuch (modlevel -1)");
+  if (Q.status[0] == 2) return fail(h, TRX_E_ARG, "fewer than three points for the radial integration");
+  if (Q.status[0] == 3) return fail(h, TRX_E_RANGE, "closest approach of a ray lies below the bottom layer (slantpath.c:39-44)");
+  return TRX_OK;
+}
+
+static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *spectrum, void *d_spectrum, trx_debug *dbg)
+{
+  if (!h || !a || !o) return TRX_E_ARG;
+  const auto t_host0 = std::chrono::steady_clock::now();
+  auto t_host_queued = t_host0;
+  const int nr = a->nlayer, nmol = h->nmol;
+  const int64_t nsh = h->nsh;
+  { const int rcc = run_check(h, a, o); if (rcc) return rcc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const bool eager = o->eager != 0, prof = o->profile != 0, count = o->profile >= 2;
+  // A handle remembers how deep the previous spectrum went (hint_layers) and plans its steps to
+  // end exactly there; the run returns at that depth and goes on only if rays are still open.
+  const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
+  int rc;
+
+  // ---- layer prologue (extinction.c:364-395) --------------------------------
+  LayerHost LH;
+  if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
+  h->walk_temp_ok = true;
+  for (int r = 0; r < nr; r++) if (a->temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
+  const size_t nli = LH.nli;
+  std::vector<double> &f64 = LH.f64;
+  const int32_t *psmax = LH.psmax;
+  // Layers per step.  The walk (narrow profiles) takes up to 64 layers, one per lane; its cost
+  // hardly depends on how many lanes are busy, so its steps are as large as the plan allows.
+  // The two-kernel form keeps a strength buffer per layer in flight: at most kMaxChunk, and
+  // 8 where the profiles are wide (a tile only learns between steps that its rays stopped).
+  // Optical depths are integrated in sub-steps of at most tau_cap layers.
+  const int tau_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;
+  const int user_chunk = o->layer_chunk > 0 ? std::max(3, o->layer_chunk) : 0;
+  // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
+  // (eclipse geometry uses tabulated weights for its one three-point ray only: rows of one pair,
+  // no modulation table -- 9 KB instead of 330 KB to build, copy and ship per run at 100 layers)
+  const bool vertical = o->solution == TRX_SOL_ECLIPSE;
+  const int gstride = vertical ? 4 : 4 * (nr / 2 + 1);
+  const size_t mw_doubles = vertical ? 0 : (size_t)(nr + 1) * gstride;
+  const size_t n_geom_all = (size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr +
+                            (vertical ? (size_t)kVertLay * nr : 0);       // (vertical rays: the chain's per-layer constants behind the rest)
+  std::vector<double> geom, ipv;
+  run_host_inputs(h, a, LH, vertical, gstride, mw_doubles, n_geom_all, geom, ipv);
 
   double ms_cia = 0;
 
@@ -2252,70 +2355,11 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
 
   drain.armed = false;                     // everything was joined into the main stream and waited for
   h->kmax_clean = true;
-  trx_stats &S = h->stats;
-  S.layers_swept = flags_host[2];
-  h->hint_layers = flags_host[4];
-  S.neval = S.nskip = S.sum_bins = S.sum_bins_walk = S.walk_layers = 0;
-  for (int r = 0; r < nr; r++) {
-    S.sum_bins += (int64_t)counters[3*r]; S.neval += (int64_t)counters[3*r+1]; S.nskip += (int64_t)counters[3*r+2];
-    if (layer_walked[(size_t)r]) { S.walk_layers++; S.sum_bins_walk += (int64_t)counters[3*r]; }
-  }
-  float ms = 0; if (prof) (void)hipEventElapsedTime(&ms, ev.a, ev.b); S.ms_run_total = ms;
-  S.ms_cia = ms_cia;
-  S.ms_host_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-  if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
-    char b[160];
-    std::snprintf(b, sizeof b, "run: host %.0f us preparing inputs, %.0f us queueing, %.0f us waiting for the device",
-                  1e3 * std::chrono::duration<double, std::milli>(t_host_prep - t_host0).count(),
-                  1e3 * std::chrono::duration<double, std::milli>(t_host_queued - t_host_prep).count(),
-                  1e3 * (S.ms_host_total - std::chrono::duration<double, std::milli>(t_host_queued - t_host0).count()));
-    log_msg(TRX_LOG_DEBUG, std::string(b) + "; queueing by phase (us):" + laps);
-  }
-  S.ms_k_sweep = S.ms_k_walk = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
-  if (prof) {
-    // every launch counts (also the ~4 us gated ones after all rays stopped), so that
-    // sum / launches is the average a kernel trace reports
-    double t[4] = {0, 0, 0, 0};
-    spans.sum(t);
-    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_walk = t[Spans::kWalk]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
-    S.sweep_launches = nchunks;
-    S.ms_sweep = S.ms_k_sweep + S.ms_k_walk + S.ms_k_accum;
-  }
-
-  if (dbg) {
-    if (dbg->e)    HIPCHK(h, hipMemcpy(dbg->e, h->d_e.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-    if (dbg->e_cs) HIPCHK(h, hipMemcpy(dbg->e_cs, h->d_ecs.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-    if (dbg->tau) {
-      std::vector<double> t((size_t)nr * nsh);
-      HIPCHK(h, hipMemcpy(t.data(), h->d_tau.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-      for (int64_t w = 0; w < nsh; w++) for (int i = 0; i < nr; i++) dbg->tau[(size_t)w * nr + i] = t[(size_t)i * nsh + w];
-    }
-    if (dbg->last) {
-      std::vector<int> l(nsh);
-      HIPCHK(h, hipMemcpy(l.data(), h->d_last.p, sizeof(int) * nsh, hipMemcpyDeviceToHost));
-      for (int64_t w = 0; w < nsh; w++) dbg->last[w] = l[w];
-    }
-    if (dbg->intens && o->solution == TRX_SOL_ECLIPSE)
-      HIPCHK(h, hipMemcpy(dbg->intens, h->d_intens.p, sizeof(double) * o->nangles * nsh, hipMemcpyDeviceToHost));
-    if (dbg->computed) for (int r = 0; r < nr; r++) dbg->computed[r] = (r >= nr - S.layers_swept) ? 1 : 0;
-    if (dbg->er) HIPCHK(h, hipMemcpy(dbg->er, h->d_er.p, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-    if (dbg->e_scat || dbg->e_cloud) {
-      DevBuf d_x;
-      if ((rc = ensure(h, d_x, sizeof(double) * 2 * (size_t)nr * nsh))) return rc;
-      TauArgs T{};
-      T.nr = nr; T.nsh = nsh; T.lo = h->lo; T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct;
-      model_args(T);
-      double *xs = d_x.as<double>(), *xc = xs + (size_t)nr * nsh;
-      hipLaunchKernelGGL(k_extras_dump, dim3((unsigned)((nsh + 255) / 256), (unsigned)nr), dim3(256), 0, st, T, xs, xc);
-      HIPCHK(h, hipStreamSynchronize(st));
-      if (dbg->e_scat)  HIPCHK(h, hipMemcpy(dbg->e_scat, xs, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-      if (dbg->e_cloud) HIPCHK(h, hipMemcpy(dbg->e_cloud, xc, sizeof(double) * nr * nsh, hipMemcpyDeviceToHost));
-    }
-  }
-  if (status_host[0] == 1) return fail(h, TRX_E_NOTREACHED, "optical depth never reached toomuch (modlevel -1)");
-  if (status_host[0] == 2) return fail(h, TRX_E_ARG, "fewer than three points for the radial integration");
-  if (status_host[0] == 3) return fail(h, TRX_E_RANGE, "closest approach of a ray lies below the bottom layer (slantpath.c:39-44)");
-  return TRX_OK;
+  RunOutcome Q{};
+  std::memcpy(Q.flags, flags_host, sizeof Q.flags); std::memcpy(Q.status, status_host, sizeof Q.status);
+  Q.counters = &counters; Q.layer_walked = &layer_walked; Q.spans = prof ? &spans : nullptr; Q.ev_a = ev.a; Q.ev_b = ev.b;
+  Q.nchunks = nchunks; Q.ms_cia = ms_cia; Q.t_host0 = t_host0; Q.t_host_prep = t_host_prep; Q.t_host_queued = t_host_queued; Q.laps = &laps;
+  return run_finish(h, a, o, dbg, Q, model_args);
 }
 
 int trx_sweep_permol(trx_handle *h, int32_t nv, const double *temp, const double *density, const double *zpart,
