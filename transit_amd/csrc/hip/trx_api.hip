@@ -91,7 +91,7 @@ struct trx_handle {
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
   // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
   // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
-  bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
+  bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase, d_rinfo;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
   bool no_row_copy = false;
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
@@ -592,6 +592,9 @@ int prepare_lines(trx_handle *h, const trx_static *s)
                        L.lgroup, L.giown, s->osamp, h->d_walk.as<WalkLine>());
     hipLaunchKernelGGL(k_walk_marks, dim3((unsigned)((h->nwaves + 63) / 64)), dim3(64), 0, h->stream, h->nwaves, h->ngw, s->niso,
                        h->d_wbase.as<int32_t>(), L.gblock, L.gfirst, L.gcount, h->d_walk.as<WalkLine>(), h->d_linebase.as<double>());
+    if ((rc = ensure(h, h->d_rinfo, sizeof(RangeInfo) * (size_t)std::max(h->nwaves, 1)))) return rc;
+    hipLaunchKernelGGL(k_range_info, dim3((unsigned)((h->nwaves + 255) / 256)), dim3(256), 0, h->stream, h->nwaves, h->ngw, s->niso,
+                       h->d_wbase.as<int32_t>(), L.gblock, L.gfirst, L.gcount, h->d_walk.as<WalkLine>(), h->d_rinfo.as<RangeInfo>());
   }
   h->stats.nlines_inrange = h->ninrange; h->stats.ngroups = h->ngroups; h->stats.nadd = h->nadd;
   // ---- candidates for the layer maximum: lines no other line of their isotope dominates
@@ -1069,7 +1072,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   if (ev_reuse) HIPCHK(h, hipStreamWaitEvent(st, ev_reuse, 0));
   if (sp && sp->begin(Spans::kWalk, st)) return fail(h, TRX_E_HIP, "event");
   WalkArgs A{};
-  A.lines = h->d_walk.as<WalkLine>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
+  A.lines = h->d_walk.as<WalkLine>(); A.rinfo = h->d_rinfo.as<RangeInfo>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
   A.gblock = h->d_gblock.as<int32_t>(); A.P = P;
   A.niso = h->niso; A.nlor = h->nlor; A.ndop = h->ndop; A.osamp = h->osamp; A.lo = h->lo; A.hi = h->hi;
   A.r_top = r_top; A.nc = nc; A.Y = Y; A.wcut = d_wcut; A.kmax = M.d_kmax; A.ethresh = M.ethresh;
@@ -1116,7 +1119,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
       log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames, " + std::to_string(S) + " ranges per wave");
     const unsigned lw = (nw + (unsigned)S - 1) / (unsigned)S;
     const dim3 grid((lw + kLanesWaves - 1) / kLanesWaves), block(64 * kLanesWaves);
-    const size_t lds = lanes_lds_bytes(nc);
+    const size_t lds = lanes_lds_bytes(nc, h->ndop);
     if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 4>), grid, block, lds, st, A, X);
     else         hipLaunchKernelGGL((k_line_walk_lanes<16, 4>), grid, block, lds, st, A, X);
   }

@@ -40,7 +40,7 @@ constexpr int kLanesMaxS = 8;          // ranges per wave at most
 constexpr int kLanesMaxGroup = 16;     // members of the longest co-added group this kernel takes
 constexpr int kLanesMaxLayers = 32;
 constexpr int kLanesLayK = 12;         // doubles per layer record
-constexpr int kLanesBases = 5;         // base points of the rebased exponential a batch's table holds (more: computed per line)
+constexpr int kLanesBases = 4;         // base points of the rebased exponential a batch's table holds (more: computed per line)
 
 struct LanesExtra {
   const double *wbase;                 // [nlines] wavenumber of the line's base point (rebased exponential)
@@ -50,7 +50,7 @@ struct LanesExtra {
 // per wave: kk [32][nc] doubles, at [32][nc] words, the layers' records (nc rounded up to even)
 __host__ __device__ inline int lanes_at_doubles(int ne) { return (((kLanesBatch + 1) * ne / 2) + 1) & ~1; }      // (the offsets' words, a whole number of 16-byte units)
 __host__ __device__ inline int lanes_wave_doubles(int nc) { const int ne = (nc + 1) & ~1; return (kLanesBatch + 1) * ne + lanes_at_doubles(ne) + kLanesLayK * ne + kLanesBases * ne; }
-__host__ __device__ inline size_t lanes_lds_bytes(int nc) { return (size_t)kLanesWaves * 8 * (size_t)lanes_wave_doubles(nc); }
+__host__ __device__ inline size_t lanes_lds_bytes(int nc, int ndop) { return (size_t)kLanesWaves * 8 * (size_t)lanes_wave_doubles(nc) + 8 * (size_t)(ndop + 1); }
 
 // lane i <- lane i + 1 of the wave (DPP wave_shl:1; lane 63 keeps `old`)
 __device__ __forceinline__ double wave_shl1(double v)
@@ -67,10 +67,11 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   constexpr int Rc = NB / 2 - 1, NS = NB / 2, LPL = 2, BL = kLanesBatch;
   static_assert(NB == 8 || NB == 16, "frames of 8 or 16 bins");
   if (!A.eager && A.flags[0] == 0) return;
-  const double *s_thr = A.dthr;                              // (the steps of the Doppler index: read where a run starts and where the index steps -- from memory)
   __shared__ double s_e2[64];
   extern __shared__ double s_dyn[];
+  double *s_thr = s_dyn + (size_t)kLanesWaves * lanes_wave_doubles(A.nc);      // [ndop + 1] steps of the nearest-Doppler-index function (the workgroup's)
   if (threadIdx.x < 64) s_e2[threadIdx.x] = A.e2tab[threadIdx.x];
+  for (int i = threadIdx.x; i <= A.ndop; i += 64 * kLanesWaves) s_thr[i] = A.dthr[i];
   __syncthreads();                                           // (the only workgroup barrier: from here the waves are on their own)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nc = A.nc, ne = (nc + 1) & ~1;                   // (ne: layers rounded up to even -- a lane pair of phase 1 takes two)
@@ -84,7 +85,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   const int L0 = (blockIdx.x * kLanesWaves + wv) * X.S;
   if (L0 >= nlaunch) return;
   const int nq = min(X.S, nlaunch - L0);
-  int r_b = 0, r_l0 = 0, r_l1 = 0, r_blo = 0, r_bhi = -1, r_open = 0, r_rlo = 0, r_rhi = 0;
+  int r_b = 0, r_l0 = 0, r_l1 = 0, r_blo = 0, r_bhi = -1, r_open = 0, r_rlo = 0, r_rhi = 0; double r_wavn0 = 0.0;
   if (lane < nq) {
     int w = L0 + lane;
     if (A.nseg > 0) {
@@ -95,9 +96,8 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       w = w0 + (w - c0);
     }
     if (w < A.P.nwaves) {
-      r_b = walk_block_of(A.P.wbase, A.niso, w);
-      const int g0 = A.gblock[r_b] + (w - A.P.wbase[r_b]) * A.P.ngw, g1 = min(g0 + A.P.ngw, A.gblock[r_b + 1]);
-      r_l0 = A.gfirst[g0]; r_l1 = A.gfirst[g1 - 1] + A.gcount[g1 - 1];
+      const RangeInfo RI = A.rinfo[w];                       // (one load: trx_create made the record)
+      r_b = RI.b; r_l0 = RI.l0; r_l1 = RI.l1; r_wavn0 = RI.wavn0;
       r_blo = A.P.blo[w]; r_bhi = A.P.bhi[w];
       const long long rec = A.P.off[w];
       r_rlo = (int)(rec & 0xffffffffLL); r_rhi = (int)(rec >> 32);
@@ -203,8 +203,8 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     // 5 alphad, 6 lower end of the current Doppler index' interval; words from double 7: index, ilor;
     // from 8: {centre + 4, row bytes, ps % osamp, -} of the current profile; from 10: of the sticky one
     const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
-    int l_first = RL(r_l0, qs);
-    { int q0 = qs; while (!((open_q >> q0) & 1ull)) q0++; l_first = RL(r_l0, q0); }
+    double wavn_first;
+    { int q0 = qs; while (!((open_q >> q0) & 1ull)) q0++; wavn_first = readlane_f64(r_wavn0, q0); }
     if (lane < ne) {
       const int cl = min(lane, nc - 1);                      // (the odd layer out: a copy of the last one, its results are never read)
       const int r = A.r_top - cl, ri = r * A.niso + b;
@@ -213,7 +213,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       const int il = A.Y.ilor[ri], idst = A.sticky_idop[ri];
       K[0] = A.Y.negc_over_t[r]; K[1] = A.Y.strength_f[ri]; K[2] = A.permol ? 1.0 : A.Y.density[ri];
       K[3] = A.ethresh * A.kmax[(long long)r * A.nmx + mx]; K[4] = A.wcut[ri]; K[5] = ad;
-      const int cur = index_from(s_thr, ad * A.lines[l_first].wavn, A.Y.idop0[ri]);
+      const int cur = index_from(s_thr, ad * wavn_first, A.Y.idop0[ri]);
       const WalkProfile wc_ = A.walkprof[cur * A.nlor + il], ws_ = A.walkprof[idst * A.nlor + il];
       K[6] = s_thr[cur];
       int *KI = (int *)(K + 7);

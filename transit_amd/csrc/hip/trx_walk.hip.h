@@ -440,8 +440,29 @@ void k_walk_marks(int nwaves, int ngw, int niso, const int32_t *__restrict__ wba
   }
 }
 
+// what a wave needs to know about its range before it can ask for anything else (k_line_walk_lanes: one load
+// instead of a chain of five through wbase, gblock, gfirst, gcount and the first line's record)
+struct alignas(32) RangeInfo { int32_t l0, l1, b, cell0; double wavn0; int32_t cell1, pad; };      // cell0 / cell1: of the first / last group
+
+__global__ __launch_bounds__(256)
+void k_range_info(int nwaves, int ngw, int niso, const int32_t *__restrict__ wbase, const int32_t *__restrict__ gblock,
+                  const int32_t *__restrict__ gfirst, const int32_t *__restrict__ gcount, const WalkLine *__restrict__ lines,
+                  RangeInfo *__restrict__ out)
+{
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwaves) return;
+  int b = 0;
+  while (b + 1 < niso && w >= wbase[b + 1]) b++;
+  const int g0 = gblock[b] + (w - wbase[b]) * ngw, g1 = min(g0 + ngw, gblock[b + 1]);
+  RangeInfo R{};
+  R.l0 = gfirst[g0]; R.l1 = gfirst[g1 - 1] + gcount[g1 - 1]; R.b = b;
+  R.cell0 = lines[R.l0].cell; R.wavn0 = lines[R.l0].wavn; R.cell1 = lines[gfirst[g1 - 1]].cell;
+  out[w] = R;
+}
+
 struct WalkArgs {
   const WalkLine *lines;
+  const RangeInfo *rinfo;           // [nwaves]
   const int32_t *gfirst, *gcount, *gblock;
   WalkPlan P;
   int niso, nlor, ndop, osamp;
@@ -517,9 +538,8 @@ void k_line_walk(WalkArgs A)
   s_e2[lane] = A.e2tab[lane];
   __builtin_amdgcn_wave_barrier();
 
-  const int b = walk_block_of(A.P.wbase, A.niso, w);
-  const int g0 = A.gblock[b] + (w - A.P.wbase[b]) * A.P.ngw, g1 = min(g0 + A.P.ngw, A.gblock[b + 1]);
-  const int l0 = A.gfirst[g0], l1 = A.gfirst[g1 - 1] + A.gcount[g1 - 1];
+  const RangeInfo RI = A.rinfo[w];                          // (one load: trx_create made the record)
+  const int b = __builtin_amdgcn_readfirstlane(RI.b), l0 = __builtin_amdgcn_readfirstlane(RI.l0), l1 = __builtin_amdgcn_readfirstlane(RI.l1);
   const long long rec0 = A.P.off[w];
 
   // ---- this lane's layer (and, with lane pairs, its part of the frame: slots part*NS ...)
@@ -541,10 +561,10 @@ void k_line_walk(WalkArgs A)
   const int psq = psm_s / A.osamp, psr = psm_s - psq * A.osamp;
   const int lo32 = (int)A.lo, hi32 = (int)A.hi;            // (the grid has < 2^31 bins: trx_create)
   // every bin this range can reach lies inside the shard: no clipping of the slot masks
-  const bool interior = A.lines[A.gfirst[g1 - 1]].cell - Rc >= lo32 && A.lines[l0].cell + Rc + 1 < hi32;
+  const bool interior = __builtin_amdgcn_readfirstlane(RI.cell1) - Rc >= lo32 && __builtin_amdgcn_readfirstlane(RI.cell0) + Rc + 1 < hi32;
 
   // Doppler index of the first anchor, then followed downwards (wavenumbers descend => it never rises)
-  int lo_i = index_from(s_thr, ad * A.lines[l0].wavn, A.Y.idop0[ri]);
+  int lo_i = index_from(s_thr, ad * RI.wavn0, A.Y.idop0[ri]);
   double thr_lo = s_thr[lo_i];
   int ps_cur = A.psize[lo_i * A.nlor + il];
   unsigned vo_cur = 4u * (unsigned)(A.poff[lo_i * A.nlor + il] + ps_cur);   // byte offset of the profile centre
@@ -555,7 +575,7 @@ void k_line_walk(WalkArgs A)
   double acc[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) acc[k] = 0.0;
-  int jc = __builtin_amdgcn_readfirstlane(A.lines[l0].cell);   // frame: acc[k] <-> bin jc - Rc + k
+  int jc = __builtin_amdgcn_readfirstlane(RI.cell0);           // frame: acc[k] <-> bin jc - Rc + k
   unsigned long long nb = 0, nev = 0, nsk = 0;
 
   auto flush = [&](int k, double v, bool mine = true) {    // bin of this lane's slot k leaves the frame
