@@ -1957,10 +1957,11 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     trx_handle *h; bool armed = true;
     ~Drain() { if (armed) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->stream); } }
   } drain{h};
-  // ---- inputs are on their way: release the other streams --------------------------------
+  // ---- inputs are on their way.  The event marks this place of the main queue (and sends the copy off); the CIA
+  // queue waits for it when its kernels are queued -- behind the first walk's launch, not on the host's way to the
+  // device's first kernel.  (The side queue needs no wait of its own: its first work waits for an event recorded
+  // behind a walk or a sweep of this run, which is behind the inputs.)
   HIPCHK(h, hipEventRecord(h->ev_inputs, st_sweep));
-  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_inputs, 0));
-  if (pipelined) HIPCHK(h, hipStreamWaitEvent(st_early, h->ev_inputs, 0));
   // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
   bool init_done = false;
   // (the start-up pass rides along with k_layer_max only where it is small next to it: a few
@@ -1996,6 +1997,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   };
   auto queue_cia = [&]() -> int {
     const auto t0 = std::chrono::steady_clock::now();
+    if (hipStreamWaitEvent(h->stream2, h->ev_inputs, 0) != hipSuccess) return fail(h, TRX_E_HIP, "event");
     if (extras_on) {        // (ahead of the first optical depth like everything on this queue)
       TauArgs X{};
       X.nr = nr; X.nsh = nsh; X.lo = h->lo; X.wn_i = h->wn_i; X.wn_d = h->wn_d; X.wn_fct = o->wn_fct;
