@@ -82,6 +82,7 @@ struct trx_handle {
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
   // the walk's copy: phase-major rows of whole cache lines (walk_row_layout), one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
+  DevBuf d_tabW32, d_wp32; const float *tabW32 = nullptr;      // compact 32-byte rows for frames of 8 bins (k_table_rows32)
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
   bool shard_frames = true;                              // frames sized for the Doppler indices the lines in reach can take (TRX_SHARD_FRAMES=0: for the isotope's whole wavenumber range)
@@ -92,7 +93,7 @@ struct trx_handle {
   // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
   // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
   bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase, d_rinfo;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
-  bool no_row_copy = false;
+  bool no_row_copy = false, no_rows32 = false;
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
   int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
@@ -284,6 +285,7 @@ int plan_table(trx_handle *h, const trx_static *s, std::vector<ProfileJob> &jobs
 void test_switches(trx_handle *h)
 {
   h->no_row_copy = std::getenv("TRX_NO_ROW_COPY") != nullptr;              // wide frames without the row copy (test_gpu_properties)
+  h->no_rows32 = std::getenv("TRX_NO_ROWS32") != nullptr;                  // k_line_walk_lanes<8> on the 64-byte rows (test_gpu_lanes)
   h->row_staging = !std::getenv("TRX_NO_ROW_STAGING");                      // k_accumulate_wide instead of k_accumulate_rows (test_gpu_rows)
   if (const char *v = std::getenv("TRX_ROWS_M8_FROM")) h->row_m8_from = std::atoll(v);      // ... and its tile size per layer (test_gpu_rows)
   h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");                      // k_line_walk_packed never / for steps of up to N layers (test_gpu_packed)
@@ -419,6 +421,32 @@ int build_table(trx_handle *h, const trx_static *s)
         const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
         hipLaunchKernelGGL(k_table_phase_major, dim3(32, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
                            d_joffW.as<long long>() + j0, h->tab, h->d_tabW.as<float>() + kTabPad, s->osamp, 1);
+      }
+      // compact rows (32 bytes) of the profiles with at most 8 entries per row: what k_line_walk_lanes<8> gathers
+      {
+        std::vector<long long> joff32(jobs.size(), -1);
+        std::vector<uint32_t> c32((size_t)s->ndop * s->nlor, 0xffffffffu);
+        long long tot32 = 0; size_t jj = 0;
+        for (int i = 0; i < s->ndop; i++)
+          for (int k = 0; k < s->nlor; k++) {
+            const size_t e = (size_t)i * s->nlor + k;
+            if (h->adop[i] * 10.0 < h->alor[k] && i != 0) { c32[e] = c32[e - s->nlor]; continue; }
+            const long long ps = h->psize[e], K = (2 * ps) / s->osamp + 1;
+            if (K <= 8 && 4 * (tot32 + (long long)s->osamp * 8) < (1LL << 32)) { joff32[jj] = tot32; c32[e] = (uint32_t)(4 * tot32); tot32 += (long long)s->osamp * 8; }
+            jj++;
+          }
+        if (tot32 > 0 && !h->no_rows32) {
+          DevBuf d_joff32;
+          if ((rc = upload(h, d_joff32, joff32)) || (rc = upload(h, h->d_wp32, c32))) return rc;
+          if ((rc = ensure(h, h->d_tabW32, sizeof(float) * (size_t)tot32))) return rc;
+          for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
+            const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
+            hipLaunchKernelGGL(k_table_rows32, dim3(16, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
+                               d_joffW.as<long long>() + j0, d_joff32.as<long long>() + j0, h->d_tabW.as<float>() + kTabPad, h->d_tabW32.as<float>(), s->osamp);
+          }
+          HIPCHK(h, hipStreamSynchronize(h->stream));
+          h->tabW32 = h->d_tabW32.as<float>();
+        }
       }
       HIPCHK(h, hipStreamSynchronize(h->stream));
       h->tabW = h->d_tabW.as<float>() + kTabPad;
@@ -919,7 +947,7 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       }
       psmax[k] = pm;
       {   // groups of the block that refresh the Doppler index: wavn >= wcut (descending order)
-        const double *gb = h->h_gwavn.data() + h->h_gblock[i], *ge = h->h_gwavn.data() + h->h_gblock[i + 1];
+        const double *gb = h->h_gwavn.data() + h->h_gblock[i];
         const double wc = wcut[k];
         // (the block's groups descend in wavenumber: bracketed by the per-cell counts first -- groups two cells above
         // wcut's are all >= it, groups two cells below all < it -- so that the bisection stays inside ~3 cells of groups
@@ -1091,6 +1119,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
   A.table = h->tab; A.zero_index = h->tab_n;
   A.tabw = h->tabW; A.walkprof = h->d_walkprof.as<WalkProfile>();
+  A.tabw32 = h->tabW32; A.wp32 = h->tabW32 ? h->d_wp32.as<uint32_t>() : nullptr;
   A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
   // a shard launches only the ranges that can reach it: per isotope block the groups whose cells

@@ -117,7 +117,8 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   const int li = lane >> 1, part = lane & 1;
   const bool valid = li < nc;
   const int lic = valid ? li : 0;
-  const char *tabw_base = (const char *)A.tabw - 4 * (Rc + 1);     // (wave-uniform; a lane adds its part's 4 * NS * part)
+  const bool r32 = NB == 8 && A.tabw32 != nullptr;           // compact 32-byte rows (frames of 8 bins): offset = row * 32, no borrow term
+  const char *tabw_base = r32 ? (const char *)A.tabw32 : (const char *)A.tabw - 4 * (Rc + 1);     // (wave-uniform; a lane adds its part's 4 * NS * part)
   const unsigned part_off = 4u * NS * (unsigned)part;
   const double *s_kk_lane = s_kk + lic; const uint32_t *s_at_lane = s_at + lic;
   double acc[NS];
@@ -218,8 +219,8 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       K[6] = s_thr[cur];
       int *KI = (int *)(K + 7);
       KI[0] = cur; KI[1] = il;
-      KI[2] = (int)wc_.centre4 + 4; KI[3] = wc_.rowb; KI[4] = wc_.psr; KI[5] = 0;
-      KI[6] = (int)ws_.centre4 + 4; KI[7] = ws_.rowb; KI[8] = ws_.psr; KI[9] = idst;
+      KI[2] = r32 ? (int)A.wp32[cur * A.nlor + il] : (int)wc_.centre4 + 4; KI[3] = wc_.rowb; KI[4] = wc_.psr; KI[5] = 0;
+      KI[6] = r32 ? (int)A.wp32[idst * A.nlor + il] : (int)ws_.centre4 + 4; KI[7] = ws_.rowb; KI[8] = ws_.psr; KI[9] = idst;
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -315,18 +316,20 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
           const int cur = KI[0];
           int idx = cur; double th = K[6];
           while (__any(in && v < th)) { if (in && v < th) { idx--; th = s_thr[idx]; } }
-          if (idx != cur) { const WalkProfile wp = A.walkprof[idx * A.nlor + KI[1]]; pc.x = (int)wp.centre4 + 4; pc.y = wp.rowb; pc.z = wp.psr; }
+          if (idx != cur) { const WalkProfile wp = A.walkprof[idx * A.nlor + KI[1]]; pc.x = r32 ? (int)A.wp32[idx * A.nlor + KI[1]] : (int)wp.centre4 + 4; pc.y = wp.rowb; pc.z = wp.psr; }
           const int ncur = __shfl(idx, (n - 1) + (h1 << lg), 64);
           __builtin_amdgcn_wave_barrier();
           if (t1 == 0 && c2 + h1 < ne && ncur != cur) {        // the next batch starts from the last line's index
             const WalkProfile wp = A.walkprof[ncur * A.nlor + KI[1]];
-            K[6] = s_thr[ncur]; KI[0] = ncur; KI[2] = (int)wp.centre4 + 4; KI[3] = wp.rowb; KI[4] = wp.psr;
+            K[6] = s_thr[ncur]; KI[0] = ncur; KI[2] = r32 ? (int)A.wp32[ncur * A.nlor + KI[1]] : (int)wp.centre4 + 4; KI[3] = wp.rowb; KI[4] = wp.psr;
           }
         }
         const bool own = wavn >= wc;                           // own index while alphad*wn/alphal >= 0.1, else the sticky one
         const int c4p = own ? pc.x : ps.x, rb = own ? pc.y : ps.y, psr = own ? pc.z : ps.z;
         const int d = psr - imod, sgn = d >> 31;              // sgn = -1: borrowed a cell
-        const unsigned at = __umul24((unsigned)(d + (sgn & A.osamp)), (unsigned)rb) + (unsigned)(c4p + (sgn << 2));     // (osamp < 2^21, a row < 2^24 bytes)
+        const unsigned rowsel = (unsigned)(d + (sgn & A.osamp));
+        const unsigned at = r32 ? (unsigned)c4p + (rowsel << 5)
+                                : __umul24(rowsel, (unsigned)rb) + (unsigned)(c4p + (sgn << 2));     // (osamp < 2^21, a row < 2^24 bytes)
         s_kk[row8 + c] = kk; s_at[row8 + c] = at;
       };
       using T = std::true_type; using F = std::false_type;

@@ -479,6 +479,7 @@ struct WalkArgs {
   long long zero_index;             // index (in `table`) where kWalkMaxFrame*osamp zeros begin
   const float *table;               // the Voigt table, followed by kWalkMaxFrame cells of zeros (k_table_padded)
   const float *tabw; const WalkProfile *walkprof;   // the walk's row copy and its descriptors [ndop][nlor]
+  const float *tabw32; const uint32_t *wp32;        // its compact 32-byte rows (frames of 8 bins) and their byte offsets [ndop][nlor] (null: none)
   double *part;                     // [records][64]
   unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
   const int *flags; const int *last; int eager;
