@@ -92,6 +92,7 @@ struct trx_handle {
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
   // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
   // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
+  int xcd_map = 1;                                   // blocks -> ranges by XCD (xcd_block): bit 0 k_line_walk_lanes, bit 1 k_line_walk (measured: slower there).  TRX_XCD_MAP, A/B
   bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase, d_rinfo;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
   bool no_row_copy = false, no_rows32 = false;
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
@@ -290,6 +291,7 @@ void test_switches(trx_handle *h)
   if (const char *v = std::getenv("TRX_ROWS_M8_FROM")) h->row_m8_from = std::atoll(v);      // ... and its tile size per layer (test_gpu_rows)
   h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");                      // k_line_walk_packed never / for steps of up to N layers (test_gpu_packed)
   if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
+  if (const char *e = std::getenv("TRX_XCD_MAP")) h->xcd_map = std::atoi(e);
   if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }      // k_line_walk_lanes never / also on sparse lists (test_gpu_lanes)
   if (const char *e = std::getenv("TRX_LANES_S")) h->lanes_s = std::max(0, std::min(kLanesMaxS, std::atoi(e)));                       // ... ranges per wave
   if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;            // the step kernels instead of k_ray_tail (test_gpu_tail)
@@ -1120,6 +1122,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.table = h->tab; A.zero_index = h->tab_n;
   A.tabw = h->tabW; A.walkprof = h->d_walkprof.as<WalkProfile>();
   A.tabw32 = h->tabW32; A.wp32 = h->tabW32 ? h->d_wp32.as<uint32_t>() : nullptr;
+  A.xcd_map = h->xcd_map & 2;                        // (bit 1: k_line_walk, bit 0: k_line_walk_lanes)
   A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;
   // a shard launches only the ranges that can reach it: per isotope block the groups whose cells
@@ -1154,6 +1157,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     int S = h->lanes_s;
     if (S <= 0) S = 1;
     LanesExtra X{h->d_linebase.as<double>(), S};
+    A.xcd_map = h->xcd_map & 1;
     if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG)
       log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames, " + std::to_string(S) + " ranges per wave");
     const unsigned lw = (nw + (unsigned)S - 1) / (unsigned)S;

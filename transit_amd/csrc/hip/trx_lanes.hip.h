@@ -82,7 +82,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
 
   // ---- the wave's ranges: launched indices L0 .. L0 + nq - 1, lane q holds range q's numbers
   const int nlaunch = A.nseg > 0 ? A.seg_cum[A.nseg] : A.P.nwaves;
-  const int L0 = (blockIdx.x * kLanesWaves + wv) * X.S;
+  const int L0 = ((A.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kLanesWaves + wv) * X.S;
   if (L0 >= nlaunch) return;
   const int nq = min(X.S, nlaunch - L0);
   int r_b = 0, r_l0 = 0, r_l1 = 0, r_blo = 0, r_bhi = -1, r_open = 0, r_rlo = 0, r_rhi = 0; double r_wavn0 = 0.0;

@@ -460,6 +460,17 @@ void k_range_info(int nwaves, int ngw, int niso, const int32_t *__restrict__ wba
   out[w] = R;
 }
 
+// Workgroups go to the 8 XCDs in turn (block i runs on XCD i % 8), each XCD with an L2 of its own.  The
+// ranges are in wavenumber order and the table rows a range gathers depend on its wavenumber (Doppler index)
+// and its layers: with block i working on ranges xcd_block(i), an XCD takes ONE contiguous eighth of the
+// launch in order, so the rows its L2 holds at any time are those of a narrow band -- an eighth of what the
+// launch order asks every L2 to hold.
+__device__ __forceinline__ int xcd_block(int i, int n)
+{
+  const int x = i & 7, k = i >> 3, q = n >> 3, r = n & 7;     // XCD x has q + (x < r) blocks
+  return x * q + min(x, r) + k;
+}
+
 struct WalkArgs {
   const WalkLine *lines;
   const RangeInfo *rinfo;           // [nwaves]
@@ -479,6 +490,7 @@ struct WalkArgs {
   long long zero_index;             // index (in `table`) where kWalkMaxFrame*osamp zeros begin
   const float *table;               // the Voigt table, followed by kWalkMaxFrame cells of zeros (k_table_padded)
   const float *tabw; const WalkProfile *walkprof;   // the walk's row copy and its descriptors [ndop][nlor]
+  int xcd_map;                                      // blocks -> ranges by xcd_block (0: in launch order)
   const float *tabw32; const uint32_t *wp32;        // its compact 32-byte rows (frames of 8 bins) and their byte offsets [ndop][nlor] (null: none)
   double *part;                     // [records][64]
   unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
@@ -516,7 +528,7 @@ void k_line_walk(WalkArgs A)
   static_assert(LPL == 1 || (LPL == 2 && ROWS && NS >= 4), "lane pairs: row form, frames of 8+ bins");
   if (!A.eager && A.flags[0] == 0) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int w = blockIdx.x * kWalkWaves + wv;                  // wave-uniform
+  int w = (A.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kWalkWaves + wv;      // wave-uniform
   if (A.nseg > 0) {                                       // only the ranges that can reach the shard were launched
     if (w >= A.seg_cum[A.nseg]) return;
     int sgm = 0;
@@ -767,7 +779,7 @@ void k_line_walk_packed(WalkArgs A, int S)
   constexpr int Rc = NB / 2 - 1;
   if (!A.eager && A.flags[0] == 0) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int W = blockIdx.x * kWalkWaves + wv;             // wave-uniform: ranges W*S .. W*S + S - 1 of the launch
+  const int W = (A.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kWalkWaves + wv;     // wave-uniform: ranges W*S .. W*S + S - 1 of the launch
   const int lane = threadIdx.x & 63;
   const int slot = lane / A.nc, li = lane - slot * A.nc;
   int widx = W * S + slot;                                // index into the launched ranges
