@@ -61,6 +61,14 @@ int main(int argc, char **argv)
     args.push_back(argv[i]);
   }
   if (ngpus < 1) { std::fprintf(stderr, "transit_hip: --gpus needs a positive number\n"); return EXIT_FAILURE; }
+  // a one-shot run uses the first N devices: keep the runtime from opening the node's other GPUs (agents,
+  // memory pools and queues of all 8 are set up otherwise, whichever one the run uses).  The user's own
+  // choice of visible devices stands.
+  if (!std::getenv("ROCR_VISIBLE_DEVICES") && !std::getenv("HIP_VISIBLE_DEVICES") && !std::getenv("CUDA_VISIBLE_DEVICES")) {
+    std::string vis;
+    for (int k = 0; k < ngpus; k++) vis += (k ? "," : "") + std::to_string(k);
+    setenv("ROCR_VISIBLE_DEVICES", vis.c_str(), 0);        // (entries past the node's last device are ignored)
+  }
   int rc = trh_load((int)args.size(), args.data(), &P, err, sizeof(err));
   if (rc == 1) return EXIT_SUCCESS;                       // --help / --version (argum.c:582-607)
   if (rc != TRX_OK) { std::fprintf(stderr, "transit_hip: %s (%s)\n", err, trx_strerror(rc)); return EXIT_FAILURE; }
@@ -122,7 +130,9 @@ int main(int argc, char **argv)
   // ---- shards, devices, communicator
   std::vector<int64_t> bounds((size_t)ngpus + 1);
   if (trh_shard_bounds(P, ngpus, bounds.data()) != TRX_OK) { std::fprintf(stderr, "transit_hip: cannot cut %d shards\n", ngpus); trh_free(P); return EXIT_FAILURE; }
-  const int ndev = trx_device_count();
+  t0 = now_s();
+  const int ndev = trx_device_count();                     // (the process's first HIP call: the runtime comes up here)
+  if (verblevel > 3) std::printf("Check point: 00 - 06 GPU runtime up, %d device(s) visible:  dt = %.4f sec.\n\n", ndev, now_s() - t0);
   const bool rccl = ngpus > 1 && ndev >= ngpus;
   unsigned char comm_id[TRX_COMM_ID_BYTES];
   if (rccl && (rc = trx_comm_unique_id(comm_id)) != TRX_OK) {
