@@ -434,6 +434,20 @@ def main():
             extras["ms_per_spectrum_3_handles_at_once"] = 1e3 * (time.time() - t0) / (3 * n3)
             for e in engs:
                 e.close()
+            # the same through the C ABI's own batch call: 8 atmospheres per trx_run_batch, dealt to 3 handles
+            # by the library's host threads (no Python between the spectra)
+            from transit_amd.engine import Batch
+            bt = Batch(st, ways=3)
+            atms8 = [P.atm] * 8
+            for _ in range(3):
+                bt.run(atms8, opts)
+            nb8 = max(8, args.steps // 4)
+            t0 = time.time()
+            for _ in range(nb8):
+                bt.run(atms8, opts)
+            extras["ms_per_spectrum_batch8"] = 1e3 * (time.time() - t0) / (8 * nb8)
+            extras["batch_ways"] = 3
+            bt.close()
         exe = os.path.join(ROOT, "transit_amd", "lib", "transit_hip")
         if os.path.exists(exe):          # the one-shot command, fresh process, same input files
             t0 = time.time()

@@ -252,6 +252,20 @@ int  trx_run_device(trx_handle *h, const trx_atm *atm, const trx_opts *opts,
                     void *d_spectrum, trx_debug *dbg);
 void trx_destroy(trx_handle *h);
 
+/* Several atmospheres per call -- what a retrieval driver does with the reference by calling run_transit
+ * (transit.c:118-122) once per atmosphere.  A batch keeps `ways` handles made from one description (line list
+ * and tables `ways` times in device memory) and a host thread for each; trx_run_batch deals the k
+ * atmospheres to them and returns when all are done.  spectra[j] ([wn_hi-wn_lo], host) is what
+ * trx_run(h, &atm[j], opts, spectra[j], NULL) gives, bit for bit.  On failure: the first error's code, its
+ * text through trx_last_error(NULL); spectra of other atmospheres may or may not have been written. */
+#define TRX_BATCH_MAX_WAYS 8
+typedef struct trx_batch trx_batch;
+int  trx_batch_create(const trx_static *st, int32_t ways, trx_batch **out);
+int  trx_run_batch(trx_batch *b, int32_t k, const trx_atm *atm /* [k] */, const trx_opts *opts,
+                   double *const *spectra /* [k] */);
+int  trx_batch_ways(const trx_batch *b);
+void trx_batch_destroy(trx_batch *b);
+
 /* The per-layer operator of the reference in its per-molecule form,
  *   computemolext(tr, kiso, temp, density, Z, permol = 1)   (extinction.c:282)
  * batched over nv independent thermodynamic states -- what calcopacity()

@@ -22,7 +22,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -2475,6 +2478,94 @@ int trx_run_device(trx_handle *h, const trx_atm *a, const trx_opts *o, void *d_s
 {
   if (!d_spectrum) return TRX_E_ARG;
   return run_once(h, a, o, nullptr, d_spectrum, dbg);
+}
+
+// ---- several atmospheres per call -----------------------------------------------------------------
+// A retrieval driver runs many chains over one line list (the reference: one run_transit per atmosphere,
+// transit.c:118-122, one process each).  One spectrum leaves the device idle between its kernels and while
+// the host prepares and queues (about a fifth of a CH4-demo spectrum), and another
+// spectrum's kernels fit there: a batch keeps `ways` handles made from ONE description, each with a host
+// thread of its own, and deals the K atmospheres of a call to them.  Every spectrum is what trx_run gives
+// for its atmosphere, bit for bit -- it IS a trx_run, on whichever handle was free (a run's sums do not
+// depend on the handle's history: the depth hint only changes the step plan).
+struct trx_batch {
+  std::vector<trx_handle *> hs;
+  std::vector<std::thread> workers;
+  std::mutex mu; std::condition_variable cv_work, cv_done;
+  // the call being served (under mu)
+  uint64_t epoch = 0; bool quit = false;
+  int32_t k = 0; const trx_atm *atm = nullptr; const trx_opts *opts = nullptr; double *const *spectra = nullptr;
+  std::atomic<int32_t> next{0};
+  int32_t busy = 0; int rc = TRX_OK; std::string err;
+};
+
+int trx_batch_create(const trx_static *st, int32_t ways, trx_batch **out)
+{
+  if (!st || !out || ways < 1 || ways > TRX_BATCH_MAX_WAYS) return TRX_E_ARG;
+  *out = nullptr;
+  std::unique_ptr<trx_batch> B(new trx_batch);
+  for (int i = 0; i < ways; i++) {
+    trx_handle *h = nullptr;
+    const int rc = trx_create(st, &h);
+    if (rc != TRX_OK) { for (trx_handle *x : B->hs) trx_destroy(x); return rc; }
+    B->hs.push_back(h);
+  }
+  trx_batch *b = B.get();
+  for (int i = 0; i < ways; i++)
+    b->workers.emplace_back([b, i]() {
+      uint64_t seen = 0;
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> lk(b->mu);
+          b->cv_work.wait(lk, [&] { return b->quit || b->epoch != seen; });
+          if (b->quit) return;
+          seen = b->epoch;
+        }
+        for (;;) {
+          const int32_t j = b->next.fetch_add(1);
+          if (j >= b->k) break;
+          const int rc = trx_run(b->hs[(size_t)i], b->atm + j, b->opts, b->spectra[j], nullptr);
+          if (rc != TRX_OK) {
+            std::lock_guard<std::mutex> lk(b->mu);
+            if (b->rc == TRX_OK) { b->rc = rc; b->err = "atmosphere " + std::to_string(j) + ": " + b->hs[(size_t)i]->err; }
+            b->next.store(b->k);                           // (the others finish the spectrum they are on and stop)
+          }
+        }
+        std::lock_guard<std::mutex> lk(b->mu);
+        if (--b->busy == 0) b->cv_done.notify_all();
+      }
+    });
+  *out = B.release();
+  return TRX_OK;
+}
+
+int trx_run_batch(trx_batch *b, int32_t k, const trx_atm *atm, const trx_opts *opts, double *const *spectra)
+{
+  g_comm_err.clear();
+  if (!b || k < 0 || (k > 0 && (!atm || !opts || !spectra))) return TRX_E_ARG;
+  for (int32_t j = 0; j < k; j++) if (!spectra[j]) return TRX_E_ARG;
+  if (k == 0) return TRX_OK;
+  std::unique_lock<std::mutex> lk(b->mu);
+  b->k = k; b->atm = atm; b->opts = opts; b->spectra = spectra;
+  b->next.store(0); b->rc = TRX_OK; b->err.clear();
+  b->busy = (int32_t)b->workers.size();
+  b->epoch++;
+  b->cv_work.notify_all();
+  b->cv_done.wait(lk, [&] { return b->busy == 0; });
+  if (b->rc != TRX_OK) g_comm_err = b->err;                // trx_last_error(NULL)
+  return b->rc;
+}
+
+int trx_batch_ways(const trx_batch *b) { return b ? (int)b->hs.size() : 0; }
+
+void trx_batch_destroy(trx_batch *b)
+{
+  if (!b) return;
+  { std::lock_guard<std::mutex> lk(b->mu); b->quit = true; }
+  b->cv_work.notify_all();
+  for (std::thread &t : b->workers) t.join();
+  for (trx_handle *h : b->hs) trx_destroy(h);
+  delete b;
 }
 
 }  // extern "C"

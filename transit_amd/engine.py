@@ -229,6 +229,50 @@ class Engine(CEngine):
             raise EngineError(rc, "trx_gather", self._last_error())
 
 
+class Batch:
+    """trx_batch: `ways` handles made from one description, each with a host thread of its own inside
+    the library; run(atms, opts) deals the atmospheres to them (trx_run_batch) and returns their
+    spectra -- each one what Engine.run gives for its atmosphere, bit for bit."""
+
+    def __init__(self, static: _abi.TrxStatic, ways: int = 3):
+        lib = hip_library()
+        lib.trx_batch_create.argtypes = [C.POINTER(_abi.TrxStatic), C.c_int32, C.POINTER(C.c_void_p)]
+        lib.trx_batch_create.restype = C.c_int
+        lib.trx_run_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_abi.TrxAtm), C.POINTER(_abi.TrxOpts),
+                                      C.POINTER(_abi.c_double_p)]
+        lib.trx_run_batch.restype = C.c_int
+        lib.trx_batch_destroy.argtypes = [C.c_void_p]
+        lib.trx_batch_destroy.restype = None
+        lib.trx_last_error.argtypes = [C.c_void_p]
+        lib.trx_last_error.restype = C.c_char_p
+        self._lib, self._b = lib, C.c_void_p()
+        self.nwn = int(static.wn_hi - static.wn_lo)
+        rc = lib.trx_batch_create(C.byref(static), int(ways), C.byref(self._b))
+        if rc != 0:
+            raise EngineError(rc, "trx_batch_create", (lib.trx_last_error(None) or b"").decode(errors="replace"))
+
+    def run(self, atms, opts: _abi.TrxOpts) -> np.ndarray:
+        k = len(atms)
+        out = np.zeros((k, self.nwn))
+        arr = (_abi.TrxAtm * k)(*atms)
+        ptrs = (_abi.c_double_p * k)(*[out[j].ctypes.data_as(_abi.c_double_p) for j in range(k)])
+        rc = self._lib.trx_run_batch(self._b, k, arr, C.byref(opts), ptrs)
+        if rc != 0:
+            raise EngineError(rc, "trx_run_batch", (self._lib.trx_last_error(None) or b"").decode(errors="replace"))
+        return out
+
+    def close(self):
+        if self._b:
+            self._lib.trx_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 LOG_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 _log_keep = None
 
