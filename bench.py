@@ -592,9 +592,9 @@ def main():
                                  "stream).  bmin_frac / balg_frac = the whole spectrum against SURVEY 8(d)'s layer-fused "
                                  "minimum / reference-flow byte counts (null where the count exceeds what HBM could "
                                  "deliver in the measured time: the fused layers read the line list once, not once "
-                                 "per layer).  The walk is not HBM-bandwidth bound: it issues ~38 (two-bin frame) and "
-                                 "~58 (eight-bin frame) vector instructions per line and step, nearly all at the fp64 "
-                                 "rate of one per 4 clocks and SIMD -- valu_issue_frac = SQ_INSTS_VALU x 4 clocks / "
+                                 "per layer).  The walk is not HBM-bandwidth bound: it issues ~38 (two-bin frames, lanes = "
+                                 "layers) and ~42 (eight-bin frames, k_line_walk_lanes) vector instructions per line and step, most at the fp64 "
+                                 "rate of one per 4 clocks and SIMD, and the deep step's row gathers are one L2 request per (group, layer) -- valu_issue_frac = SQ_INSTS_VALU x 4 clocks / "
                                  "(launch time x 1024 SIMDs x 2.4 GHz); counters and probes in profiles/, DESIGN.md section 4"},
         }
         out["config"].update(extras)
@@ -615,7 +615,7 @@ def main():
                                         "quoted for this kernel.  achieved = 2 flop per accumulated bin / launch time; "
                                         "lds_frac = 8 B per accumulated bin (the staged doubles) / launch time against "
                                         "the LDS read peak -- both count the bins a profile reaches, not the tile bins "
-                                        "beyond its ends that are computed as zeros (profiles/r03_c5_*: counters)")
+                                        "beyond its ends that are computed as zeros (profiles/r04_c5_*: counters)")
             out["roofline"]["bmin_frac"] = out["roofline"]["balg_frac"] = None
             for k in ("alg_bytes_per_launch",):
                 out["roofline"].pop(k, None)
