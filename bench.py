@@ -107,7 +107,7 @@ def production_launches(kernels, kernel, launch_key):
     return {n: v for n, v in prod.items() if v >= 0.5 * top}
 
 
-DEMO_KEY = "2501 x 100 x 1000000"        # summaries without a workload_key (round 2) were taken on the default workload
+DEMO_KEY = "2501 x 100 x 1000000 / 81"        # summaries without a workload_key (round 2) were taken on the default workload
 
 
 def measured_traffic(kernel, key=DEMO_KEY):
@@ -531,7 +531,7 @@ def main():
         b_min_run = world * (52.0 * L + 4.0 * stats["sum_bins"] + 24.0 * R * nbins + 8.0 * nbins * (1 + nang))
         # the roof this kernel is actually near: vector-instruction issue.  A wave64 instruction holds
         # its SIMD's 16 lanes for 4 clocks; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock.
-        wkey = "%d x %d x %d" % (nwn, nlayer, int(st.nlines))
+        wkey = "%d x %d x %d / %d" % (nwn, nlayer, int(st.nlines), layers_needed)
         prof_k = "k_accumulate_rows" if ("k_accumulate" in dom and args.wnosamp == 1) else dom.split(" ")[0]     # (the kernel's name in a trace)
         valu = measured_valu(prof_k, wkey) if world == 1 else None
         valu_frac = (valu * 4.0 / (kern[dom] / dlaunch * 1e-3 * 1024 * 2.4e9)) if (valu and kern[dom] > 0) else None

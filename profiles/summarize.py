@@ -65,12 +65,12 @@ def kernel_source_hash():
 
 
 def workload_key(src):
-    """What bench.py calls this workload (its own n_wn x n_layers x n_lines), from the bench line of the
+    """What bench.py calls this workload (its own n_wn x n_layers x n_lines / layers needed: the geometry and the CIA tables change the last), from the bench line of the
     traced run: bench.py quotes counters only from a summary of the workload it is running."""
     line = os.path.join(src, "bench_line_under_trace.json")
     try:
         c = json.loads(open(line).read().strip().splitlines()[-1])["config"]
-        return "%d x %d x %d" % (c["n_wn"], c["n_layers"], c["n_lines"])
+        return "%d x %d x %d / %d" % (c["n_wn"], c["n_layers"], c["n_lines"], c["layers_needed"])
     except Exception:
         return None
 
