@@ -85,7 +85,7 @@ struct trx_handle {
   float *tab = nullptr; const float *tabT = nullptr; const long long *poffT = nullptr;
   // the walk's copy: phase-major rows of whole cache lines (walk_row_layout), one WalkProfile per table entry
   DevBuf d_tabW, d_walkprof; const float *tabW = nullptr; bool tabw_ok = false;
-  DevBuf d_tabW32, d_wp32; const float *tabW32 = nullptr;      // compact 32-byte rows for frames of 8 bins (k_table_rows32)
+  DevBuf d_tabW32, d_wp32; const float *tabW32 = nullptr; unsigned slab32 = 0;      // compact 32-byte rows for frames of 8 bins (k_table_rows32)
   long long row_m8_from = 768;      // profile width (bins) from which a layer's tiles are 512 bins (TRX_ROWS_M8_FROM: measurements)
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
   bool shard_frames = true;                              // frames sized for the Doppler indices the lines in reach can take (TRX_SHARD_FRAMES=0: for the isotope's whole wavenumber range)
@@ -431,24 +431,27 @@ int build_table(trx_handle *h, const trx_static *s)
       {
         std::vector<long long> joff32(jobs.size(), -1);
         std::vector<uint32_t> c32((size_t)s->ndop * s->nlor, 0xffffffffu);
-        long long tot32 = 0; size_t jj = 0;
+        long long nq = 0; size_t jj = 0;                 // profiles with compact rows: [phase][profile][8 floats]
         for (int i = 0; i < s->ndop; i++)
           for (int k = 0; k < s->nlor; k++) {
             const size_t e = (size_t)i * s->nlor + k;
             if (h->adop[i] * 10.0 < h->alor[k] && i != 0) { c32[e] = c32[e - s->nlor]; continue; }
             const long long ps = h->psize[e], K = (2 * ps) / s->osamp + 1;
-            if (K <= 8 && 4 * (tot32 + (long long)s->osamp * 8) < (1LL << 32)) { joff32[jj] = tot32; c32[e] = (uint32_t)(4 * tot32); tot32 += (long long)s->osamp * 8; }
+            if (K <= 8) { joff32[jj] = 8 * nq; c32[e] = (uint32_t)(32 * nq); nq++; }
             jj++;
           }
-        if (tot32 > 0 && !h->no_rows32) {
+        const long long tot32 = nq * 8 * (long long)s->osamp;
+        // (a slab below 2^24 bytes and the phase below 2^24: the kernel's 24-bit multiply; the whole below 4 GB)
+        if (nq > 0 && 32 * nq < (1LL << 24) && s->osamp < (1 << 24) && 4 * tot32 < (1LL << 32) && !h->no_rows32) {
           DevBuf d_joff32;
           if ((rc = upload(h, d_joff32, joff32)) || (rc = upload(h, h->d_wp32, c32))) return rc;
           if ((rc = ensure(h, h->d_tabW32, sizeof(float) * (size_t)tot32))) return rc;
           for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
             const int nj = (int)std::min<size_t>(32768, jobs.size() - j0);
             hipLaunchKernelGGL(k_table_rows32, dim3(16, nj), dim3(256), 0, h->stream, d_jobs.as<ProfileJob>() + j0,
-                               d_joffW.as<long long>() + j0, d_joff32.as<long long>() + j0, h->d_tabW.as<float>() + kTabPad, h->d_tabW32.as<float>(), s->osamp);
+                               d_joffW.as<long long>() + j0, d_joff32.as<long long>() + j0, h->d_tabW.as<float>() + kTabPad, h->d_tabW32.as<float>(), s->osamp, 8 * nq);
           }
+          h->slab32 = (unsigned)(32 * nq);
           HIPCHK(h, hipStreamSynchronize(h->stream));
           h->tabW32 = h->d_tabW32.as<float>();
         }
@@ -1124,7 +1127,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   A.psize = h->d_psize.as<int32_t>(); A.poff = h->d_poff.as<long long>();
   A.table = h->tab; A.zero_index = h->tab_n;
   A.tabw = h->tabW; A.walkprof = h->d_walkprof.as<WalkProfile>();
-  A.tabw32 = h->tabW32; A.wp32 = h->tabW32 ? h->d_wp32.as<uint32_t>() : nullptr;
+  A.tabw32 = h->tabW32; A.wp32 = h->tabW32 ? h->d_wp32.as<uint32_t>() : nullptr; A.slab32 = h->slab32;
   A.xcd_map = h->xcd_map & 2;                        // (bit 1: k_line_walk, bit 0: k_line_walk_lanes)
   A.part = part.as<double>(); A.counters = M.prof ? h->d_counters.as<unsigned long long>() : nullptr;
   A.flags = h->d_flags.as<int>(); A.last = M.skip_done ? h->d_last.as<int>() : nullptr; A.eager = M.eager;

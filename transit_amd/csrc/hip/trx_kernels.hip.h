@@ -864,16 +864,19 @@ void k_table_phase_major(const ProfileJob *jobs, const long long *joffT, const f
 }
 
 // The compact rows of the walk's copy for frames of 8 bins (k_line_walk_lanes): of a profile with at most
-// 8 entries per row, row r keeps exactly the 8 floats a group of that row reads -- its window starts one
-// float earlier when the row index borrowed a cell (r > ps % osamp) -- so a row is 32 bytes, two to a cache
-// line, and the rows of the ~34 profiles a deep step uses (2 isotopes x 17 layers: 2.4 MB) stay in an
-// XCD's L2 where the 64-byte rows (4.7 MB) did not.
+// 8 entries per row, a row keeps exactly the 8 floats a group of that row reads -- its window starts one
+// float earlier when the row index borrowed a cell (r > ps % osamp) -- so a row is 32 bytes.  Laid out
+// [phase][profile][8]: the row a group of phase ph reads (row (ps % osamp - ph) mod osamp of the 64-byte
+// copy) of EVERY profile in one slab, profiles in table order (Lorentz index fastest).  The layers of a
+// step differ by a step or none of the Lorentz index and share or nearly share the Doppler index: a group's
+// rows of its 17 layers are then a few cache lines, not 17 (L1 -> L2 requests of the deep step 1.13e7 ->
+// 5.9e6 per launch).
 __global__ __launch_bounds__(256)
 void k_table_rows32(const ProfileJob *jobs, const long long *joffW, const long long *joff32, const float *__restrict__ tabW,
-                    float *__restrict__ tab32, int of)
+                    float *__restrict__ tab32, int of, long long slab_floats)
 {
   const ProfileJob J = jobs[blockIdx.y];
-  const long long o32 = joff32[blockIdx.y];
+  const long long o32 = joff32[blockIdx.y];                // the profile's place inside a slab (floats)
   if (o32 < 0) return;                                   // (more than 8 entries per row: no frame of 8 bins reads it)
   const long long offW = joffW[blockIdx.y];
   const int ps = (J.nv - 1) / 2, psq = ps / of, psr = ps - psq * of;
@@ -881,7 +884,9 @@ void k_table_rows32(const ProfileJob *jobs, const long long *joffW, const long l
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int r = (int)(t >> 3), k = (int)(t & 7);
     const int start = 1 + psq - (r > psr ? 1 : 0);
-    tab32[o32 + t] = tabW[offW + (long long)r * 16 + start + k];
+    int ph = psr - r;                                      // the phase whose groups read row r
+    if (ph < 0) ph += of;
+    tab32[(long long)ph * slab_floats + o32 + k] = tabW[offW + (long long)r * 16 + start + k];
   }
 }
 

@@ -117,7 +117,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   const int li = lane >> 1, part = lane & 1;
   const bool valid = li < nc;
   const int lic = valid ? li : 0;
-  const bool r32 = NB == 8 && A.tabw32 != nullptr;           // compact 32-byte rows (frames of 8 bins): offset = row * 32, no borrow term
+  const bool r32 = NB == 8 && A.tabw32 != nullptr;           // compact 32-byte rows (frames of 8 bins): offset = profile's + phase * slab, no borrow term
   const char *tabw_base = r32 ? (const char *)A.tabw32 : (const char *)A.tabw - 4 * (Rc + 1);     // (wave-uniform; a lane adds its part's 4 * NS * part)
   const unsigned part_off = 4u * NS * (unsigned)part;
   const double *s_kk_lane = s_kk + lic; const uint32_t *s_at_lane = s_at + lic;
@@ -328,7 +328,9 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
         const int c4p = own ? pc.x : ps.x, rb = own ? pc.y : ps.y, psr = own ? pc.z : ps.z;
         const int d = psr - imod, sgn = d >> 31;              // sgn = -1: borrowed a cell
         const unsigned rowsel = (unsigned)(d + (sgn & A.osamp));
-        const unsigned at = r32 ? (unsigned)c4p + (rowsel << 5)
+        // (compact rows: [phase][profile][8 floats] -- the row of phase imod of every profile in one slab, so the
+        // rows of one group's layers, whose profiles are neighbours in the table, share cache lines)
+        const unsigned at = r32 ? (unsigned)c4p + __umul24((unsigned)imod, A.slab32)
                                 : __umul24(rowsel, (unsigned)rb) + (unsigned)(c4p + (sgn << 2));     // (osamp < 2^21, a row < 2^24 bytes)
         s_kk[row8 + c] = kk; s_at[row8 + c] = at;
       };

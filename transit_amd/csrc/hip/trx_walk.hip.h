@@ -491,7 +491,8 @@ struct WalkArgs {
   const float *table;               // the Voigt table, followed by kWalkMaxFrame cells of zeros (k_table_padded)
   const float *tabw; const WalkProfile *walkprof;   // the walk's row copy and its descriptors [ndop][nlor]
   int xcd_map;                                      // blocks -> ranges by xcd_block (0: in launch order)
-  const float *tabw32; const uint32_t *wp32;        // its compact 32-byte rows (frames of 8 bins) and their byte offsets [ndop][nlor] (null: none)
+  const float *tabw32; const uint32_t *wp32;        // its compact 32-byte rows (frames of 8 bins), [phase][profile][8], and the profiles' byte offsets inside a phase's slab [ndop][nlor] (null: none)
+  unsigned slab32;                                  // bytes of a slab (profiles with such rows x 32)
   double *part;                     // [records][64]
   unsigned long long *counters;     // [layer][3] {bins, evaluated, skipped} or null
   const int *flags; const int *last; int eager;
