@@ -70,9 +70,10 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   __shared__ double s_e2[64];
   extern __shared__ double s_dyn[];
   double *s_thr = s_dyn + (size_t)kLanesWaves * lanes_wave_doubles(A.nc);      // [ndop + 1] steps of the nearest-Doppler-index function (the workgroup's)
-  if (threadIdx.x < 64) s_e2[threadIdx.x] = A.e2tab[threadIdx.x];
-  for (int i = threadIdx.x; i <= A.ndop; i += 64 * kLanesWaves) s_thr[i] = A.dthr[i];
-  __syncthreads();                                           // (the only workgroup barrier: from here the waves are on their own)
+  // (a wave's start is a chain of dependent round trips -- 18 % of its life when each waited for the one before: the two
+  // tables for LDS, the range's records and, as soon as the range's isotope block is known, the layers' scalars are asked
+  // for together; the closed-ray test runs under them)
+  const double e2_mine = threadIdx.x < 64 ? A.e2tab[threadIdx.x] : 0.0;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nc = A.nc, ne = (nc + 1) & ~1;                   // (ne: layers rounded up to even -- a lane pair of phase 1 takes two)
   double *s_kk = s_dyn + (size_t)wv * lanes_wave_doubles(nc);                // [BL lines + 1][ne]
@@ -83,8 +84,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   // ---- the wave's ranges: launched indices L0 .. L0 + nq - 1, lane q holds range q's numbers
   const int nlaunch = A.nseg > 0 ? A.seg_cum[A.nseg] : A.P.nwaves;
   const int L0 = ((A.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kLanesWaves + wv) * X.S;
-  if (L0 >= nlaunch) return;
-  const int nq = min(X.S, nlaunch - L0);
+  const int nq = max(0, min(X.S, nlaunch - L0));             // (0: a wave past the launch's last range; it still fills the tables and meets the barrier)
   int r_b = 0, r_l0 = 0, r_l1 = 0, r_blo = 0, r_bhi = -1, r_open = 0, r_rlo = 0, r_rhi = 0; double r_wavn0 = 0.0;
   if (lane < nq) {
     int w = L0 + lane;
@@ -101,17 +101,35 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       r_blo = A.P.blo[w]; r_bhi = A.P.bhi[w];
       const long long rec = A.P.off[w];
       r_rlo = (int)(rec & 0xffffffffLL); r_rhi = (int)(rec >> 32);
-      bool open = r_bhi >= r_blo;                            // (else: nothing of this range reaches the shard)
-      if (open && A.last) {   // every ray of the range's bins has stopped (tau.c:277-287): nobody reads them
-        open = false;
-        for (int j = r_blo; j <= r_bhi && !open; j++) open = A.last[j - A.lo] < 0;
-      }
-      r_open = open;
+      r_open = r_bhi >= r_blo;                               // (else: nothing of this range reaches the shard)
     }
   }
+  for (int i = threadIdx.x; i <= A.ndop; i += 64 * kLanesWaves) s_thr[i] = A.dthr[i];
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = e2_mine;
+  auto RL = [&](int v, int q) { return __builtin_amdgcn_readlane(v, q); };
+  // the layers' scalars of the first range's isotope block (lane c = layer c): in flight under the closed-ray test
+  const int b0 = RL(r_b, 0);
+  struct LayerScalars { double ad, ct, f, dens, kmax, wcut; int il, idst, idop0; } pre{};
+  auto layer_scalars = [&](int b) {
+    LayerScalars v{};
+    if (lane < ne) {
+      const int cl = min(lane, nc - 1);                      // (the odd layer out: a copy of the last one, its results are never read)
+      const int r = A.r_top - cl, ri = r * A.niso + b;
+      v.ad = A.Y.alphad[ri]; v.il = A.Y.ilor[ri]; v.idst = A.sticky_idop[ri];
+      v.ct = A.Y.negc_over_t[r]; v.f = A.Y.strength_f[ri]; v.dens = A.permol ? 1.0 : A.Y.density[ri];
+      v.kmax = A.kmax[(long long)r * A.nmx + (A.nmx == 1 ? 0 : A.iso_mx[b])]; v.wcut = A.wcut[ri]; v.idop0 = A.Y.idop0[ri];
+    }
+    return v;
+  };
+  if (nq > 0) pre = layer_scalars(b0);
+  if (A.last && lane < nq && r_open) {   // every ray of the range's bins has stopped (tau.c:277-287): nobody reads them
+    bool open = false;
+    for (int j = r_blo; j <= r_bhi && !open; j++) open = A.last[j - A.lo] < 0;
+    r_open = open;
+  }
+  __syncthreads();                                           // (the only workgroup barrier: from here the waves are on their own)
   const unsigned long long open_q = __ballot(r_open != 0);
   if (open_q == 0ull) return;
-  auto RL = [&](int v, int q) { return __builtin_amdgcn_readlane(v, q); };
 
   // ---- phase 2's lane: layer li, part of the frame (slots part*NS ...)
   const int li = lane >> 1, part = lane & 1;
@@ -194,33 +212,38 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   if (lane < ne) { s_kk[BL * ne + lane] = 0.0; s_at[BL * ne + lane] = 0u; }
 
   // ---- runs of ranges that share an isotope block and follow each other in the list
-  for (int qs = 0; qs < nq; ) {
-    const int b = RL(r_b, qs);
-    int qe = qs + 1;
-    while (qe < nq && RL(r_b, qe) == b && RL(r_l0, qe) == RL(r_l1, qe - 1)) qe++;
-    if (((open_q >> qs) & ((1ull << (qe - qs)) - 1ull)) == 0ull) { qs = qe; continue; }      // the whole run is closed
-    // the layers' records (lane c = layer c of the step): constants of (layer, isotope), the Doppler
-    // index at the run's first line and its profile.  Doubles 0 ct, 1 f, 2 density, 3 threshold, 4 wcut,
-    // 5 alphad, 6 lower end of the current Doppler index' interval; words from double 7: index, ilor;
-    // from 8: {centre + 4, row bytes, ps % osamp, -} of the current profile; from 10: of the sticky one
-    const int mx = A.nmx == 1 ? 0 : A.iso_mx[b];
-    double wavn_first;
-    { int q0 = qs; while (!((open_q >> q0) & 1ull)) q0++; wavn_first = readlane_f64(r_wavn0, q0); }
+  // the layers' records (lane c = layer c of the step): constants of (layer, isotope), the Doppler
+  // index at the run's first line and its profile.  Doubles 0 ct, 1 f, 2 density, 3 threshold, 4 wcut,
+  // 5 alphad, 6 lower end of the current Doppler index' interval; words from double 7: index, ilor;
+  // from 8: {centre + 4, row bytes, ps % osamp, -} of the current profile; from 10: of the sticky one
+  auto write_records = [&](const LayerScalars &ls, double wavn_first) {
     if (lane < ne) {
-      const int cl = min(lane, nc - 1);                      // (the odd layer out: a copy of the last one, its results are never read)
-      const int r = A.r_top - cl, ri = r * A.niso + b;
       double *K = LK[lane];
-      const double ad = A.Y.alphad[ri];
-      const int il = A.Y.ilor[ri], idst = A.sticky_idop[ri];
-      K[0] = A.Y.negc_over_t[r]; K[1] = A.Y.strength_f[ri]; K[2] = A.permol ? 1.0 : A.Y.density[ri];
-      K[3] = A.ethresh * A.kmax[(long long)r * A.nmx + mx]; K[4] = A.wcut[ri]; K[5] = ad;
-      const int cur = index_from(s_thr, ad * wavn_first, A.Y.idop0[ri]);
+      const double ad = ls.ad;
+      const int il = ls.il, idst = ls.idst;
+      K[0] = ls.ct; K[1] = ls.f; K[2] = ls.dens;
+      K[3] = A.ethresh * ls.kmax; K[4] = ls.wcut; K[5] = ad;
+      const int cur = index_from(s_thr, ad * wavn_first, ls.idop0);
       const WalkProfile wc_ = A.walkprof[cur * A.nlor + il], ws_ = A.walkprof[idst * A.nlor + il];
       K[6] = s_thr[cur];
       int *KI = (int *)(K + 7);
       KI[0] = cur; KI[1] = il;
       KI[2] = r32 ? (int)A.wp32[cur * A.nlor + il] : (int)wc_.centre4 + 4; KI[3] = wc_.rowb; KI[4] = wc_.psr; KI[5] = 0;
       KI[6] = r32 ? (int)A.wp32[idst * A.nlor + il] : (int)ws_.centre4 + 4; KI[7] = ws_.rowb; KI[8] = ws_.psr; KI[9] = idst;
+    }
+  };
+  // (the first run's, from the scalars asked for at the start: they are not kept beyond this point)
+  write_records(pre, readlane_f64(r_wavn0, __builtin_ctzll(open_q)));
+  const int q_first = __builtin_ctzll(open_q);               // the first run is the one that holds this range
+  for (int qs = 0; qs < nq; ) {
+    const int b = RL(r_b, qs);
+    int qe = qs + 1;
+    while (qe < nq && RL(r_b, qe) == b && RL(r_l0, qe) == RL(r_l1, qe - 1)) qe++;
+    if (((open_q >> qs) & ((1ull << (qe - qs)) - 1ull)) == 0ull) { qs = qe; continue; }      // the whole run is closed
+    if (!(b == b0 && q_first >= qs && q_first < qe)) {
+      int q0 = qs; while (!((open_q >> q0) & 1ull)) q0++;
+      __builtin_amdgcn_wave_barrier();                       // (the run before may still read its records)
+      write_records(layer_scalars(b), readlane_f64(r_wavn0, q0));
     }
     __builtin_amdgcn_wave_barrier();
 
