@@ -1322,9 +1322,10 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
     RunInit R{}; R.nsh = -1;
     if (with_init) { R = *init; *init_done = true; }
     // (at most kLayerMaxWaves waves per group of layers: beyond that a wave takes several chunks of candidates)
-    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)std::min<long long>((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines), kLayerMaxWaves), ny + (with_init ? 1u : 0u)), dim3(64), sizeof(double) * (size_t)kLayerMaxGroup * (size_t)std::max(h->niso, 1), st,
+    const int xwaves = (int)std::min<long long>((n + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines), kLayerMaxWaves);
+    hipLaunchKernelGGL(k_layer_max, dim3((unsigned)((xwaves + kLayerMaxBlock - 1) / kLayerMaxBlock), ny + (with_init ? 1u : 0u)), dim3(64 * kLayerMaxBlock), sizeof(double) * (size_t)kLayerMaxGroup * (size_t)std::max(h->niso, 1), st,
                        h->L, Yr, h->niso, nr, pruned ? h->d_candrec.as<CandLine>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
-                       (unsigned long long *)(kmax + (size_t)r0 * nmx), R, with_init ? (int)ny : -1);
+                       (unsigned long long *)(kmax + (size_t)r0 * nmx), R, with_init ? (int)ny : -1, xwaves);
   }
   for (int r0 = 0; r0 < nv; r0 += 4096) {               // one wave per (layer, isotope)
     const int nr = std::min(4096, nv - r0);

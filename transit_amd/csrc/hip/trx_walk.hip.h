@@ -165,79 +165,43 @@ constexpr int kLayerMaxGroup = 8;
 constexpr int kLayerMaxLines = 4;
 constexpr int kLayerMaxWaves = 128;   // waves per group of layers at most (each takes every gridDim.x-th chunk of 256 candidates)
 
-__global__ __launch_bounds__(64)
+constexpr int kLayerMaxBlock = 4;     // waves per block: their maxima meet in LDS, ONE atomic per block and layer (the atomics of
+                                      // all waves of a layer go to one word, ~0.17 us each one after the other: 62 of them were
+                                      // most of this kernel's 13 us at the demo size)
+
+__global__ __launch_bounds__(64 * kLayerMaxBlock)
 void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__restrict__ cand, long long ncand,
                  const double *__restrict__ e2tab, int nmx, const int32_t *__restrict__ iso_mx,
-                 unsigned long long *__restrict__ kmax_bits, RunInit R, int init_row)
+                 unsigned long long *__restrict__ kmax_bits, RunInit R, int init_row, int xwaves)
 {
   if ((int)blockIdx.y == init_row) {     // the extra row of blocks: the run's small buffers
-    run_init_elements(R, (long long)blockIdx.x * 64 + threadIdx.x, (long long)gridDim.x * 64);
+    run_init_elements(R, (long long)blockIdx.x * (64 * kLayerMaxBlock) + threadIdx.x, (long long)gridDim.x * (64 * kLayerMaxBlock));
     return;
   }
   __shared__ double s_e2[64];
-  s_e2[threadIdx.x] = e2tab[threadIdx.x];
-  __builtin_amdgcn_wave_barrier();
-  if ((long long)gridDim.x * 64 * kLayerMaxLines >= ncand) {      // one chunk per wave (lists of up to 128 chunks of candidates): the straight form
-    double gf[kLayerMaxLines], elow[kLayerMaxLines], wavn[kLayerMaxLines]; int iso[kLayerMaxLines];
-#pragma unroll
-    for (int u = 0; u < kLayerMaxLines; u++) {
-      const long long t = ((long long)blockIdx.x * kLayerMaxLines + u) * 64 + threadIdx.x;
-      gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
-      if (t < ncand) {
-        if (cand) { const CandLine c = cand[t]; gf[u] = c.gf; elow[u] = c.elow; wavn[u] = c.wavn; iso[u] = c.iso; }
-        else if (L.inrange[t]) { gf[u] = L.gf[t]; elow[u] = L.elow[t]; wavn[u] = L.wavn[t]; iso[u] = L.iso[t]; }
-      }
-    }
-    const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
-    // the wave's layer scalars in LDS, one round trip for all of them (read per layer from global
-    // memory they were a dependent round trip per layer of this one-wave chain)
-    __shared__ double s_ct[kLayerMaxGroup];
-    extern __shared__ double s_f[];                      // [kLayerMaxGroup][niso] (dynamic: the launch sizes it)
-    for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64) s_f[t] = Y.strength_f[r0 * niso + t];
-    if ((int)threadIdx.x < r1 - r0) s_ct[threadIdx.x] = Y.negc_over_t[r0 + threadIdx.x];
-    __builtin_amdgcn_wave_barrier();
-    for (int r = r0; r < r1; r++) {
-      const double ct = s_ct[r - r0];
-      double best = 0.0;
-#pragma unroll
-      for (int u = 0; u < kLayerMaxLines; u++) {
-        const double s = gf[u] * exp_neg(ct * elow[u], s_e2) * (1 - exp_neg(ct * wavn[u], s_e2));
-        const double k = s * s_f[(r - r0) * niso + iso[u]];
-        if (nmx == 1) best = fmax(best, k);
-        else if (k > 0) {       // per-molecule maxima (extinction.c:406-407, permol)
-          unsigned long long *slot = &kmax_bits[(long long)r * nmx + iso_mx[iso[u]]];
-          const unsigned long long kb = (unsigned long long)__double_as_longlong(k);
-          if (kb > *slot) atomicMax(slot, kb);
-        }
-      }
-      if (nmx == 1) {
-        const double m = wave_max(best);
-        if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r], (unsigned long long)__double_as_longlong(m));
-      }
-    }
-
-    return;
-  }
-  const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
-  // the wave's layer scalars in LDS, one round trip for all of them (read per layer from global
-  // memory they were a dependent round trip per layer of this one-wave chain)
   __shared__ double s_ct[kLayerMaxGroup];
+  __shared__ double s_best[kLayerMaxBlock][kLayerMaxGroup];
   extern __shared__ double s_f[];                      // [kLayerMaxGroup][niso] (dynamic: the launch sizes it)
-  for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64) s_f[t] = Y.strength_f[r0 * niso + t];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int xw = blockIdx.x * kLayerMaxBlock + wv;     // this wave's place among the xwaves waves of its group of layers
+  const int r0 = blockIdx.y * kLayerMaxGroup, r1 = min(r0 + kLayerMaxGroup, nr);
+  // the block's layer scalars in LDS, one round trip for all of them (read per layer from global
+  // memory they were a dependent round trip per layer of this one-wave chain)
+  if (threadIdx.x < 64) s_e2[threadIdx.x] = e2tab[threadIdx.x];
+  for (int t = threadIdx.x; t < (r1 - r0) * niso; t += 64 * kLayerMaxBlock) s_f[t] = Y.strength_f[r0 * niso + t];
   if ((int)threadIdx.x < r1 - r0) s_ct[threadIdx.x] = Y.negc_over_t[r0 + threadIdx.x];
-  __builtin_amdgcn_wave_barrier();
-  // A wave takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ... of 256 candidates and keeps its
-  // layers' running maxima over all of them: one atomic per layer and WAVE, not per chunk (a list of
-  // 8*10^6 lines has 1.2*10^5 candidates: 488 chunks' atomics on the same hundred words took 100 us).
+  __syncthreads();
+  // A wave takes the chunks xw, xw + xwaves, ... of 256 candidates and keeps its layers' running maxima over
+  // all of them (a list of 8*10^6 lines has 1.2*10^5 candidates: one chunk per wave would be 488 waves)
   double best[kLayerMaxGroup];
 #pragma unroll
   for (int q = 0; q < kLayerMaxGroup; q++) best[q] = 0.0;
   const long long nchunk = (ncand + 64 * kLayerMaxLines - 1) / (64 * kLayerMaxLines);
-  for (long long chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+  for (long long chunk = xw; chunk < nchunk && xw < xwaves; chunk += xwaves) {
     double gf[kLayerMaxLines], elow[kLayerMaxLines], wavn[kLayerMaxLines]; int iso[kLayerMaxLines];
 #pragma unroll
     for (int u = 0; u < kLayerMaxLines; u++) {
-      const long long t = (chunk * kLayerMaxLines + u) * 64 + threadIdx.x;
+      const long long t = (chunk * kLayerMaxLines + u) * 64 + lane;
       gf[u] = 0.0; elow[u] = 0.0; wavn[u] = 0.0; iso[u] = 0;
       if (t < ncand) {
         if (cand) { const CandLine c = cand[t]; gf[u] = c.gf; elow[u] = c.elow; wavn[u] = c.wavn; iso[u] = c.iso; }
@@ -266,10 +230,15 @@ void k_layer_max(LinesDev L, LayerDev Y, int niso, int nr, const CandLine *__res
   if (nmx == 1) {
 #pragma unroll
     for (int q = 0; q < kLayerMaxGroup; q++) {
-      if (r0 + q < r1) {
-        const double m = wave_max(best[q]);
-        if (threadIdx.x == 0 && m > 0) atomicMax(&kmax_bits[r0 + q], (unsigned long long)__double_as_longlong(m));
-      }
+      const double m = wave_max(best[q]);
+      if (lane == 0) s_best[wv][q] = m;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < r1 - r0) {
+      double m = s_best[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < kLayerMaxBlock; w++) m = fmax(m, s_best[w][threadIdx.x]);
+      if (m > 0) atomicMax(&kmax_bits[r0 + threadIdx.x], (unsigned long long)__double_as_longlong(m));
     }
   }
 }
