@@ -1330,7 +1330,7 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
   for (int r0 = 0; r0 < nv; r0 += 4096) {               // one wave per (layer, isotope)
     const int nr = std::min(4096, nv - r0);
     hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nr * h->niso)), dim3(64), 0, st,
-                       h->L, Y, h->niso, r0 + nr - 1, nr, kmax, nmx, d_iso_mx, ethresh, h->d_adop.as<double>(), h->ndop,
+                       h->L, Y, h->niso, r0 + nr - 1, nr, kmax, nmx, d_iso_mx, ethresh, h->d_dopthr.as<double>(), h->ndop,
                        h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), 1);
   }
   HIPCHK(h, hipGetLastError());

@@ -411,7 +411,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
 __global__ __launch_bounds__(64)
 void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
                     const double *__restrict__ kmax /* [layer][nmx] */, int nmx, const int32_t *__restrict__ iso_mx, double ethresh,
-                    const double *__restrict__ adop, int ndop,
+                    const double *__restrict__ dthr, int ndop,   // the steps of the nearest-Doppler-index function (index_from), [ndop + 1]
                     const double *__restrict__ e2tab,    // 2^(j/64): the same exp as the sweep => the same decisions
                     const int *__restrict__ npre,        // [layer][iso] refreshing groups
                     int *__restrict__ sticky_idop,       // [layer][iso]
@@ -426,6 +426,10 @@ void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
   const int r = r_top - c, ri = r * niso + b, lane = threadIdx.x;
   const int gb0 = L.gblock[b];
   const double ct = Y.negc_over_t[r], lim = ethresh * kmax[(long long)r * nmx + (nmx == 1 ? 0 : iso_mx[b])], f = Y.strength_f[ri];
+  // (what the end of this one-wave chain needs, asked for at its start: the layer's own index and width, and the index
+  // function's steps 1 .. 64, one per lane -- the bisection of nearest_index was six dependent round trips of one lane)
+  const int id0 = Y.idop0[ri]; const double ad = Y.alphad[ri];
+  const double thr_mine = 1 + lane < ndop ? dthr[1 + lane] : 0.0;
   int found = -1;
   for (int base = npre[ri] - 1; base >= 0 && found < 0; base -= 64) {
     const int k = base - lane;
@@ -444,11 +448,14 @@ void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
     const unsigned long long mask = __ballot(ev);
     if (mask) found = base - (__ffsll((long long)mask) - 1);
   }
-  if (lane == 0) {
-    int id = Y.idop0[ri];
-    if (found >= 0) id = nearest_index(adop, Y.alphad[ri] * L.gwavn[gb0 + found], 0, ndop);
-    sticky_idop[ri] = id;
+  int id = id0;
+  if (found >= 0) {                                          // (wave-uniform)
+    // the index of the width: the number of steps 1 .. ndop - 1 at or below it (index_from's definition)
+    const double v = ad * L.gwavn[gb0 + found];
+    id = __builtin_popcountll(__ballot(1 + lane < ndop && v >= thr_mine));
+    for (int k0 = 65; k0 < ndop; k0 += 64) id += __builtin_popcountll(__ballot(k0 + lane < ndop && v >= dthr[min(k0 + lane, ndop)]));
   }
+  if (lane == 0) sticky_idop[ri] = id;
 }
 
 // sum per-block partial counters: out[slot] += sum_k parts[slot*nparts + k]
