@@ -5,23 +5,28 @@
 // the other: whatever the number of layers, a line costs the wave its ~58 vector and ~36 scalar
 // instructions -- the demo's deep step (17 layers, two lanes each: 34 of 64 lanes busy, the two lanes of
 // a pair computing the SAME strength) paid 136 us for 17 layers where the 64-layer step pays 104.
-// Here a wavefront takes S consecutive ranges and goes through their lines 32 at a time:
+// Here a wavefront takes S consecutive ranges (production: one) and goes through their lines 32 at a time:
 //
-//   phase 1   lanes = (line, parity of the layer), the step's layers two at a time.  Everything per layer
-//             comes from one 96-byte record per layer in LDS (two addresses per read), per line: the two
-//             exponentials, the co-added group's sum (in line order: the anchor's lane adds its members'
-//             strengths one after the other, 87 % of the groups are single lines), the threshold
+//   phase 1   lanes = (line, set of layers): 32 lines x 2 sets, the last lines of a run 16 x 4 or 8 x 8, the
+//             step's layers in a loop.  Everything per layer comes from one 96-byte record per layer in LDS,
+//             per line: the two exponentials (exp(ct * base point) once per (base point, layer) of the
+//             batch), the co-added group's sum (in line order: the anchor's lane adds its members'
+//             strengths one after the other by DPP, 87 % of the groups are single lines), the threshold
 //             (extinction.c:467), the nearest Doppler index (:480-483, followed downwards from the
-//             batch before: lines descend in wavenumber), the profile and the byte offset of the row
-//             segment the group's bins read.  Per (anchor line, layer): the weight kk (0 below the
-//             threshold) and that offset go to LDS -- 12 bytes.
+//             batch before: lines descend in wavenumber; searched per line only in a batch in which it
+//             steps), the profile and the byte offset of the row the group's bins read (compact rows
+//             [phase][profile][8 floats] for frames of 8 bins: the profile's offset + phase x slab).  Per
+//             (line, layer): the weight kk (0 below the threshold) and that offset go to LDS -- 12 bytes.
 //   phase 2   lanes = (layer, half of the frame) exactly as k_line_walk<NB, false, 2>: the frame of NB
 //             accumulators slides down with the groups' cells, a bin that leaves it becomes one entry of
 //             the range's partial record -- but a group now costs a lane two LDS reads, one 16- or
 //             32-byte load and NB/2 multiply-adds.  Groups that share a cell (a dense list has hundreds
 //             per cell) are taken D at a time: their row segments are requested together, one block
-//             ahead of the block being added, so a wave keeps up to 2 D gathers in flight (the one-range
-//             kernel: one, and seven waves per SIMD to cover it).
+//             ahead of the block being added (two register sets in turn; the block in flight at a batch's
+//             end stays in flight under the next batch's lines and strengths).
+// Workgroups take their ranges by XCD (xcd_block): an L2 then holds the rows of one contiguous eighth of
+// the list.  What a wave's time goes to, what bounds the kernel and the forms that were measured and not
+// kept: DESIGN.md section 4.
 //
 // Same lines in the same order, same base points of the rebased exponential (their wavenumbers per line:
 // WalkArgs-side array `wbase`, made by k_walk_marks), same frame, same records: the SAME BITS as
@@ -35,7 +40,7 @@
 namespace trx {
 
 constexpr int kLanesWaves = 2;         // waves per workgroup (each with 12 bytes x 32 lines x layers of LDS)
-constexpr int kLanesBatch = 32;        // lines per batch: a lane of phase 1 is (line, parity of the layer)
+constexpr int kLanesBatch = 32;        // lines per batch: a lane of phase 1 is (line, set of layers)
 constexpr int kLanesMaxS = 8;          // ranges per wave at most
 constexpr int kLanesMaxGroup = 16;     // members of the longest co-added group this kernel takes
 constexpr int kLanesMaxLayers = 32;
