@@ -163,7 +163,7 @@ void k_cand_pack(int n, const int32_t *__restrict__ cand, const double *__restri
 // patterns, zeroed beforehand.
 constexpr int kLayerMaxGroup = 8;
 constexpr int kLayerMaxLines = 4;
-constexpr int kLayerMaxWaves = 128;   // waves per group of layers at most (each takes every gridDim.x-th chunk of 256 candidates)
+constexpr int kLayerMaxWaves = 128;   // waves per group of layers at most (each takes every xwaves-th chunk of 256 candidates)
 
 constexpr int kLayerMaxBlock = 4;     // waves per block: their maxima meet in LDS, ONE atomic per block and layer (the atomics of
                                       // all waves of a layer go to one word, ~0.17 us each one after the other: 62 of them were
