@@ -92,3 +92,25 @@ def test_lanes_walk_threshold_and_coadding(tmp_path):
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
     a, b, used = both(P)
     assert_same(a, b)
+
+
+@pytest.mark.parametrize("xcd_map", ["0", "3"])
+def test_ranges_by_xcd_or_in_launch_order(tmp_path, xcd_map):
+    """Which workgroup takes which range (xcd_block: one contiguous eighth of the list per XCD, the production
+    mapping of k_line_walk_lanes; TRX_XCD_MAP=0: launch order everywhere, 3: by XCD in both walks) is no
+    part of a result: every range writes its own partial records."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=150_000, wnlow=2500, wnhigh=2900, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=77)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    ref_e = Engine(P.static)
+    ref = [ref_e.run(P.atm, P.opts, debug=("e", "tau", "last", "computed")) for _ in range(2)] + [ref_e.run(P.atm, P.opts)]
+    ref_e.close()
+    os.environ["TRX_XCD_MAP"] = xcd_map
+    try:
+        e = Engine(P.static)
+    finally:
+        os.environ.pop("TRX_XCD_MAP", None)
+    got = [e.run(P.atm, P.opts, debug=("e", "tau", "last", "computed")) for _ in range(2)] + [e.run(P.atm, P.opts)]
+    e.close()
+    assert_same(got, ref)
