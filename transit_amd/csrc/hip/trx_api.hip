@@ -95,6 +95,7 @@ struct trx_handle {
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
   // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
   // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
+  bool no_binrec = false;                            // TRX_NO_BINREC: k_ray_tail finds a bin's records through the ranges' numbers (A/B, tests)
   int xcd_map = 1;                                   // blocks -> ranges by XCD (xcd_block): bit 0 k_line_walk_lanes, bit 1 k_line_walk (measured: slower there).  TRX_XCD_MAP, A/B
   bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase, d_rinfo;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
   bool no_row_copy = false, no_rows32 = false;
@@ -115,7 +116,7 @@ struct trx_handle {
   DevBuf d_walk, d_wbase, d_part[2];   // partial records: consecutive steps alternate
   std::vector<int32_t> h_wbase; int nwaves = 0, ngw = 0; bool walk_ok = false;
   bool walk_temp_ok = true;         // this run's layers are all warmer than kWalkMinTemp
-  struct Plan { bool built = false; DevBuf blo, bhi, off, binw; int64_t records = 0; };
+  struct Plan { bool built = false; DevBuf blo, bhi, off, binw, binrec; int64_t records = 0; };
   Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
   // CIA (host copies)
   struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw, ruw, rh; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw, d_ruw, d_rh; };
@@ -295,6 +296,7 @@ void test_switches(trx_handle *h)
   h->packed_walk = !std::getenv("TRX_NO_PACKED_WALK");                      // k_line_walk_packed never / for steps of up to N layers (test_gpu_packed)
   if (const char *v = std::getenv("TRX_PACKED_MAX_LAYERS")) h->packed_max_layers = std::max(1, std::min(32, std::atoi(v)));
   if (const char *e = std::getenv("TRX_XCD_MAP")) h->xcd_map = std::atoi(e);
+  h->no_binrec = std::getenv("TRX_NO_BINREC") != nullptr;
   if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }      // k_line_walk_lanes never / also on sparse lists (test_gpu_lanes)
   if (const char *e = std::getenv("TRX_LANES_S")) h->lanes_s = std::max(0, std::min(kLanesMaxS, std::atoi(e)));                       // ... ranges per wave
   if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;            // the step kernels instead of k_ray_tail (test_gpu_tail)
@@ -1050,6 +1052,10 @@ int walk_plan(trx_handle *h, int nb, hipStream_t st, WalkPlan &P, trx_handle::Pl
   const bool with_binw = nbinw > 0 && nbinw <= (1LL << 24);
   if (!pl->built && with_binw && (rc = ensure(h, pl->binw, 8 * (size_t)nbinw))) return rc;
   P.binw = with_binw ? pl->binw.as<int32_t>() : nullptr;
+  // (and the bin's record in each of its first 64 ranges, for k_ray_tail: 256 bytes per bin and isotope, small shards only)
+  const bool with_binrec = with_binw && nbinw <= (1LL << 17) && !h->no_binrec;
+  if (!pl->built && with_binrec && (rc = ensure(h, pl->binrec, 256 * (size_t)nbinw))) return rc;
+  P.binrec = with_binrec ? pl->binrec.as<int32_t>() : nullptr;
   if (!pl->built) {
     hipLaunchKernelGGL(k_wave_plan, dim3(1), dim3(256), 0, st, P, h->niso, h->d_gblock.as<int32_t>(), h->d_gidiv.as<int32_t>(),
                        nb / 2 - 1, (long long)h->lo, (long long)h->hi);
@@ -1060,6 +1066,7 @@ int walk_plan(trx_handle *h, int nb, hipStream_t st, WalkPlan &P, trx_handle::Pl
     HIPCHK(h, hipStreamSynchronize(st));                 // once per handle and frame size
     pl->records = total; pl->built = true;
   }
+  if (pl->records >= (1LL << 31)) P.binrec = nullptr;      // (32-bit record numbers)
   return TRX_OK;
 }
 

@@ -66,12 +66,17 @@ struct TailBin { int wa[kTailSteps], wz[kTailSteps]; long long myrec[kTailSteps]
 __device__ __forceinline__ void tail_bin_plan(const TailArgs &A, int b, long long j, int lane, TailBin &B)
 {
   const TauArgs &T = A.T;
+  int32_t rec32[kTailSteps] = {};                            // (the plan's per-bin record table: asked for next to the range numbers, one round trip for both)
 #pragma unroll
   for (int s = 0; s < kTailSteps; s++) {
     B.wa[s] = B.wz[s] = 0;
     if (s < A.nsteps) {
       const WalkPlan &P = A.S[s].P;
-      if (P.binw) { const long long t = (long long)b * T.nsh + (j - T.lo); B.wa[s] = P.binw[2 * t]; B.wz[s] = P.binw[2 * t + 1]; }
+      if (P.binw) {
+        const long long t = (long long)b * T.nsh + (j - T.lo);
+        B.wa[s] = P.binw[2 * t]; B.wz[s] = P.binw[2 * t + 1];
+        if (P.binrec) rec32[s] = P.binrec[t * 64 + lane];
+      }
       else ranges_of_bin(P, b, j, B.wa[s], B.wz[s]);
     }
   }
@@ -79,7 +84,10 @@ __device__ __forceinline__ void tail_bin_plan(const TailArgs &A, int b, long lon
   for (int s = 0; s < kTailSteps; s++) {
     B.wa[s] = __builtin_amdgcn_readfirstlane(B.wa[s]); B.wz[s] = __builtin_amdgcn_readfirstlane(B.wz[s]);
     B.myrec[s] = 0;
-    if (lane < B.wz[s] - B.wa[s]) B.myrec[s] = A.S[s].P.off[B.wa[s] + lane] + (j - A.S[s].P.blo[B.wa[s] + lane]);     // (the first 64 ranges)
+    if (lane < B.wz[s] - B.wa[s]) {                          // (the first 64 ranges)
+      if (s < A.nsteps && A.S[s].P.binrec) B.myrec[s] = rec32[s];
+      else B.myrec[s] = A.S[s].P.off[B.wa[s] + lane] + (j - A.S[s].P.blo[B.wa[s] + lane]);
+    }
   }
 }
 

@@ -260,6 +260,8 @@ struct WalkPlan {
   int64_t *off;                     // [nwaves + 1]
   int32_t *binw;                    // [niso][bins of the shard][2]: first and one-past-last range of the
                                     // block that touches the bin (null: the combine searches blo/bhi itself)
+  int32_t *binrec;                  // [niso][bins of the shard][64]: the bin's record in each of its first 64 ranges
+                                    // (off[w] + j - blo[w]); null: none.  One look-up instead of two dependent ones in k_ray_tail
 };
 
 __device__ __forceinline__ int walk_block_of(const int32_t *wbase, int niso, int w)
@@ -327,6 +329,8 @@ void k_bin_ranges(WalkPlan P, int niso, long long lo, long long nsh)
   int wa = 0, wz = 0;
   if (P.wbase[b] != P.wbase[b + 1]) ranges_of_bin(P, b, j, wa, wz);
   P.binw[2 * t] = wa; P.binw[2 * t + 1] = wz;
+  if (P.binrec)
+    for (int u = 0; u < min(wz - wa, 64); u++) P.binrec[t * 64 + u] = (int32_t)(P.off[wa + u] + (j - P.blo[wa + u]));
 }
 
 // ---------------------------------------------------------------------------
