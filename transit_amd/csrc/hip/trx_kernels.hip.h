@@ -55,12 +55,6 @@ __global__ void k_probe_set(volatile int *flag) { *flag = 1; }
 // ---------------------------------------------------------------------------
 // wavefront helpers (64 lanes, fixed butterfly order => deterministic sums)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 // Wave maximum of non-negative doubles without LDS traffic: rotate-and-max inside
 // the four rows of 16 lanes (DPP row_ror 1,2,4,8 leaves every lane with its row's
 // maximum), then the four row results through SGPRs.  Result is wave-uniform.
@@ -70,6 +64,29 @@ __device__ __forceinline__ double dpp_f64(double v)
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+// The butterfly sum of a wave: every lane gets the total, partner lane ^ 32, 16, 8, 4, 2, 1 in that order.  The
+// four steps inside a row of 16 lanes are DPP moves on the vector pipe instead of lane permutes through the LDS
+// pipe (which a block of k_ray_tail's seven emission waves keeps busy): lane ^ 8 is row_ror:8, lane ^ 4 is
+// row_shl:4 for the lanes of banks 0 and 2 and row_shr:4 for banks 1 and 3, lane ^ 2 and lane ^ 1 are
+// quad_perm -- the same partner in every step, so the same bits as six __shfl_xor.
+__device__ __forceinline__ double lane_xor4(double v)
+{
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x104, 0xF, 0x5, false);       // row_shl:4 -> lanes of banks 0, 2 read lane + 4
+  lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x114, 0xF, 0xA, false);           // row_shr:4 -> lanes of banks 1, 3 read lane - 4
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x104, 0xF, 0x5, false);
+  hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xF, 0xA, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += dpp_f64<0x128>(v);      // row_ror:8 = lane ^ 8
+  v += lane_xor4(v);
+  v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]: lane ^ 1
+  return v;
 }
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
