@@ -1732,14 +1732,14 @@ __device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int
       tv = tau_at(i);
       B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
     }
-    double Bp = __shfl_up(B, 1, 64);
+    double Bp = dpp_f64<0x138>(B);              // wave_shr:1 -- the lane before (lane 0: set below)
     if (lane == 0) Bp = B_c;
     const int top = min(63, last - i0);        // lane of the pass's last height
 #pragma unroll
     for (int a = 0; a < NANG; a++) {
       if (a < E.nang) {
         const double dt = have ? exp_neg(slant_depth(E, a, tv), s_e2) : 0.0;
-        double dtp = __shfl_up(dt, 1, 64);
+        double dtp = dpp_f64<0x138>(dt);
         if (lane == 0) dtp = dt_c[a];
         const double term = (have && i > 0) ? (dt - dtp) * (B + Bp) : 0.0;
         sum[a] += wave_sum(term);

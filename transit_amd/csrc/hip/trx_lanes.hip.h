@@ -172,7 +172,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     } else {
       for (; sh > 0; sh--) {
         flush(NS - 1, acc[NS - 1], part == LPL - 1);
-        const double carry = __shfl_xor(acc[NS - 1], 1, 64);
+        const double carry = dpp_f64<0xB1>(acc[NS - 1]);          // quad_perm [1,0,3,2]: the pair's other lane
 #pragma unroll
         for (int k = NS - 1; k > 0; k--) acc[k] = acc[k - 1];
         acc[0] = part == 1 ? carry : 0.0;

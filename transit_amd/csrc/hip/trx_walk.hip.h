@@ -679,7 +679,7 @@ void k_line_walk(WalkArgs A)
             for (; sh > 0; sh--) {
               flush(NS - 1, acc[NS - 1], part == LPL - 1);            // the frame's last bin
               double carry = 0.0;                                      // the lower part's last bin moves up a lane
-              if (LPL == 2) carry = __shfl_xor(acc[NS - 1], 1, 64);
+              if (LPL == 2) carry = dpp_f64<0xB1>(acc[NS - 1]);       // quad_perm [1,0,3,2]: the pair's other lane
 #pragma unroll
               for (int k = NS - 1; k > 0; k--) acc[k] = acc[k - 1];
               acc[0] = (LPL == 2 && part == 1) ? carry : 0.0;
