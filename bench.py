@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--layer-chunk", type=int, default=0)
     ap.add_argument("--solution", choices=("eclipse", "transit"), default="eclipse")
     ap.add_argument("--ncia", type=int, default=1)
+    ap.add_argument("--species", type=int, choices=(1, 3), default=1,
+                    help="line databases: 1 = CH4 (two isotopes), 3 = H2O + CH4 + CO (six isotopes, --lines in total: BASELINE configs[2])")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N>1 headline: strong = the ONE CH4 2-4 um demo run split N ways -- BASELINE.json's metric "
                          "(wall-clock of that run at 1/2/4/8 GPUs; 2501 rays are too few to fill 8 GPUs: DESIGN.md "
@@ -81,7 +83,7 @@ def kernel_source_hash():
     return h.hexdigest()[:12]
 
 
-def production_launches(kernels, kernel, launch_key):
+def production_launches(kernels, kernel, launch_key, family=True):
     """{name: launches} of the PRODUCTION instantiations of `kernel` in a profile summary that belong to
     the bench's step plan.  Names carry their template arguments -- trx::k_line_walk<NB, PROF, LPL>,
     trx::k_line_walk_lanes<NB, D>, trx::k_accumulate_rows<COUNT, M> -- and a boolean is the counting switch: those
@@ -92,7 +94,7 @@ def production_launches(kernels, kernel, launch_key):
     prod = {}
     for name, k in kernels.items():
         m = re.match(r"(?:void )?trx::(\w+)(?:<([^>]*)>)?", name)
-        if not m or (m.group(1) != kernel and not (kernel == "k_line_walk" and m.group(1) in ("k_line_walk_packed", "k_line_walk_lanes"))):
+        if not m or (m.group(1) != kernel and not (family and kernel == "k_line_walk" and m.group(1) in ("k_line_walk_packed", "k_line_walk_lanes"))):
             continue
         targs = [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
         if "true" in targs:            # PROF / COUNT
@@ -136,7 +138,7 @@ def measured_traffic(kernel, key=DEMO_KEY):
     return None, None
 
 
-def measured_valu(kernel, key=DEMO_KEY):
+def measured_valu(kernel, key=DEMO_KEY, family=True):
     """SQ_INSTS_VALU per launch of `kernel` (weighted over the production instantiations of the step
     plan) from the committed SQ pass that matches this tree's kernel sources, or None."""
     import glob
@@ -146,7 +148,7 @@ def measured_valu(kernel, key=DEMO_KEY):
             if t.get("kernel_sources") != kernel_source_hash() or (t.get("workload_key") or DEMO_KEY) != key:
                 continue
             d = json.load(open(f.replace("pmc_traffic", "sq_mix")))
-            w = production_launches(d["kernels"], kernel, "launches")
+            w = production_launches(d["kernels"], kernel, "launches", family)
             tot = n = 0.0
             for name, nl in w.items():
                 tot += float(d["kernels"][name]["SQ_INSTS_VALU_avg_launch"]) * nl
@@ -162,9 +164,12 @@ def make_workload(args, tag, nlines, verb=2, wnhigh=None, unique=True):
     from transit_amd import synth
     d = os.path.join(tempfile.gettempdir(), "transit_bench_%s_%d_%d_%s" % (
         tag, nlines, args.layers, os.getpid() if unique else os.environ.get("MASTER_PORT", "0")))
+    if getattr(args, "species", 1) == 3:
+        d += "_3sp"
     if not unique and os.path.exists(os.path.join(d, "case.cfg")):
         return d
-    synth.make_case(d, nlines=nlines, wnlow=args.wnlow, wnhigh=wnhigh or args.wnhigh, wndelt=args.wndelt,
+    dbs = synth.three_species_dbs(nlines // 3, args.wnlow, wnhigh or args.wnhigh) if getattr(args, "species", 1) == 3 else None
+    synth.make_case(d, nlines=nlines, dbs=dbs, wnlow=args.wnlow, wnhigh=wnhigh or args.wnhigh, wndelt=args.wndelt,
                     wnosamp=args.wnosamp,
                     nlayers=args.layers, solution=args.solution, toomuch=10.0, ethresh=1e-50, nwidth=20.0,
                     raygrid="0 20 40 60 80", ncia=args.ncia, seed=1234, extra={"verb": verb})
@@ -254,6 +259,25 @@ def cpu_all_cores(args, workdir, layers_needed, ref_spectrum):
                 "vs_reference_max_rel": ok}
     except Exception as e:                                   # a baseline, never a reason to lose the bench line
         return {"kind": "port", "error": "%s: %s" % (type(e).__name__, e)}
+
+
+def baseline_config(args, grow=1):
+    """Which of BASELINE.json's configs the flags describe ("custom" when none): the label of config.workload."""
+    near = lambda a, b: abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1.0)
+    demo_grid = near(args.wnlow, 2500.0) and near(args.wnhigh, 5000.0) and near(args.wndelt, 1.0) and args.wnosamp == 2160
+    if grow == 1 and demo_grid and args.layers == 100 and args.lines == 1_000_000 and args.species == 1:
+        if args.solution == "eclipse" and args.ncia == 1:
+            return "BASELINE configs[1]: CH4-demo-shaped emission"
+        if args.solution == "transit" and args.ncia == 2:
+            return "BASELINE configs[3]: transmission (slant paths), H2-H2 + H2-He CIA"
+    wide = near(args.wnlow, 333.33) and near(args.wnhigh, 10000.0)
+    if grow == 1 and wide and near(args.wndelt, 1.0) and args.wnosamp == 2160 and args.layers == 200 and args.lines == 3_000_000 \
+            and args.species == 3 and args.solution == "eclipse":
+        return "BASELINE configs[2]: H2O + CH4 + CO, 1-30 um at 1 cm-1, 200 layers"
+    if grow == 1 and wide and near(args.wndelt, 0.0009667) and args.wnosamp == 1 and args.layers == 150 and args.lines == 10_000_000 \
+            and args.solution == "eclipse":
+        return "BASELINE configs[4]: retrieval scale, 1e7 wavenumbers x 150 layers x 1e7 lines"
+    return "custom (no BASELINE config has these flags)"
 
 
 def frac_or_none(x):
@@ -348,6 +372,11 @@ def main():
         spec_local = torch.zeros(mpad, dtype=torch.float64, device=dev)      # slice + padding to equal counts
         gathered = torch.zeros(mpad * world, dtype=torch.float64, device=dev if comm is not None else cdev) if world > 1 else None
 
+        host_spec = np.zeros(hi - lo)
+
+        def step_host():          # SURVEY 8(d)'s t_run: trx_run, H2D of the atmosphere and D2H of the spectrum included
+            eng.run_into(P.atm, opts, host_spec)
+
         def step():
             eng.run_device(P.atm, opts, spec_local.data_ptr())
             if world > 1:       # the single exchange of the path
@@ -356,24 +385,31 @@ def main():
                 else:                     # rehearsal on a shared GPU: gloo through host memory
                     dist.all_gather_into_tensor(gathered, spec_local.cpu())
 
-        ms_step = time_steps(step, fence, warmup, steps, reduce_max if world > 1 else None)
+        # N = 1: the headline is trx_run with the spectrum handed back to the HOST (8(d)); N > 1: the spectrum stays in
+        # device memory for the gather (trx_run_device + trx_gather).  The other form rides along (ms_device_spectrum).
+        timed = step_host if world == 1 else step
+        ms_step = time_steps(timed, fence, warmup, steps, reduce_max if world > 1 else None)
         # rider: the same step timed over at least 200 more steps right behind the timed region (no further
         # warm-up).  The headline keeps the driver's K and W; with K = 20 its 7 ms sit on a device whose
         # clocks are still on their way up (5 warm-up steps are 2 ms of GPU work): 0.362 ms per step
         # against 0.345 over 200 and 0.341 over 2000 steps, same box, same build (round 4, gpurun_out/r4_base_*).
         steady_steps = max(200, steps) if steps < 2000 else 0
-        ms_steady = time_steps(step, fence, 0, steady_steps, reduce_max if world > 1 else None) if steady_steps else ms_step
+        ms_steady = time_steps(timed, fence, 0, steady_steps, reduce_max if world > 1 else None) if steady_steps else ms_step
+        ms_device_spectrum = time_steps(step, fence, 0, steady_steps or steps) if world == 1 else None
         # the same steps once more with the production kernels bracketed by HIP events on the
         # streams they are launched on (profile 1): every launch counts, sum / launches is what
         # a kernel trace reports as the average
         opts.profile = 1
-        ev = {"ms_k_sweep": 0.0, "ms_k_walk": 0.0, "ms_k_accum": 0.0, "ms_tau": 0.0, "ms_run_total": 0.0, "sweep_launches": 0, "runs": 0}
+        ev = {"ms_k_sweep": 0.0, "ms_k_walk": 0.0, "ms_k_accum": 0.0, "ms_tau": 0.0, "ms_run_total": 0.0, "sweep_launches": 0, "runs": 0,
+              "ms_k_walk_form": [0.0, 0.0, 0.0]}
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.run_device(P.atm, opts, spec_local.data_ptr())
             s1 = eng.stats()
             for k in ("ms_k_sweep", "ms_k_walk", "ms_k_accum", "ms_tau", "ms_run_total", "sweep_launches"):
                 ev[k] += s1[k]
+            for fi in range(3):
+                ev["ms_k_walk_form"][fi] += s1["ms_k_walk_form"][fi]
             ev["runs"] += 1
         ev["ms_per_step_with_events"] = 1e3 * (time.perf_counter() - t0) / max(steps, 1)
         opts.profile = 2                 # one counted run (instrumented kernel variants): bins, evaluated / skipped groups
@@ -388,7 +424,10 @@ def main():
             full = np.concatenate([g[k * mpad: k * mpad + (h - l)] for k, (l, h) in enumerate(bounds)])
         else:
             full = spec_local[: hi - lo].cpu().numpy()
+            if not np.array_equal(full, host_spec):
+                raise SystemExit("bench: trx_run and trx_run_device returned different spectra")
         out = dict(P=P, eng=eng, stats=stats, ms_step=ms_step, ms_steady=ms_steady, steady_steps=steady_steps or steps,
+                   ms_device_spectrum=ms_device_spectrum,
                    layers_needed=layers_needed, full=full, nwn=nwn,
                    bounds=bounds, t_first_create=t_first_create, opts=opts, dir=d, static=st)
         if not keep:
@@ -512,9 +551,23 @@ def main():
         # index), then 13 B per group and layer read back + 4 B per accumulated bin + e.
         acc_name = "k_walk_combine" if walked else ("k_accumulate" if wsteps == 0 else "k_walk_combine + k_accumulate")
         kern, alg, nlaunch = {}, {}, {}
+        # the walk family, form by form (trx_stats.walk_form_*): k_line_walk reads a 32-byte record per line and step,
+        # k_line_walk_lanes also the line's 8-byte base point (40 B); both 4 B per accumulated bin and their partial records
+        FORMS = ("k_line_walk", "k_line_walk_lanes", "k_line_walk_packed")
+        walk_forms = {}
+        for fi, fname in enumerate(FORMS):
+            fsteps = int(stats["walk_form_steps"][fi])
+            if not fsteps:
+                continue
+            fms = ev["ms_k_walk_form"][fi] / runs
+            fbytes = (40.0 if fi == 1 else 32.0) * L * fsteps + 4.0 * stats["walk_form_bins"][fi] + 8.0 * stats["walk_form_record_lanes"][fi]
+            walk_forms[fname] = {"steps_per_run": fsteps, "layers": int(stats["walk_form_layers"][fi]), "ms_per_run": fms,
+                                 "avg_launch_ms": fms / fsteps, "alg_bytes_per_launch": fbytes / fsteps,
+                                 "achieved_GBs": fbytes / (fms * 1e-3) / 1e9 if fms > 0 else None,
+                                 "frac": fbytes / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS if fms > 0 else None}
         if wsteps:
             kern["k_line_walk"] = ev["ms_k_walk"] / runs; nlaunch["k_line_walk"] = wsteps
-            alg["k_line_walk"] = 32.0 * L * wsteps + 4.0 * bins_w + 8.0 * stats["walk_record_lanes"]
+            alg["k_line_walk"] = sum(v["alg_bytes_per_launch"] * v["steps_per_run"] for v in walk_forms.values())
         if ssteps:
             kern["k_group_sweep"] = ev["ms_k_sweep"] / runs; nlaunch["k_group_sweep"] = ssteps
             alg["k_group_sweep"] = 27.0 * L * ssteps + 9.0 * G * Rs
@@ -523,6 +576,8 @@ def main():
         dom = max(kern, key=kern.get)
         line_k = "k_line_walk" if wsteps else "k_group_sweep"
         dlaunch = max(nlaunch[dom], 1)
+        # (the walk family under its members' names: achieved / avg_launch_ms are over all its launches, `kernels` has each form)
+        dom_label = " + ".join(walk_forms) if (dom == "k_line_walk" and walk_forms) else dom
         ach = alg[dom] / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
         # whole run against SURVEY 8(d): B_alg follows the reference's flow (two scans of the 26-byte
         # line record per layer), B_min is the layer-fused minimum (lines once, 4 B per bin, the
@@ -534,6 +589,10 @@ def main():
         wkey = "%d x %d x %d / %d" % (nwn, nlayer, int(st.nlines), layers_needed)
         prof_k = "k_accumulate_rows" if ("k_accumulate" in dom and args.wnosamp == 1) else dom.split(" ")[0]     # (the kernel's name in a trace)
         valu = measured_valu(prof_k, wkey) if world == 1 else None
+        if world == 1:
+            for fname, v in walk_forms.items():      # each form's own instruction count, where a profile of this tree holds it
+                fv = measured_valu(fname, wkey, family=False)
+                v["valu_issue_frac"] = (fv * 4.0 / (v["avg_launch_ms"] * 1e-3 * 1024 * 2.4e9)) if (fv and v["avg_launch_ms"] > 0) else None
         valu_frac = (valu * 4.0 / (kern[dom] / dlaunch * 1e-3 * 1024 * 2.4e9)) if (valu and kern[dom] > 0) else None
         tr_pair, traffic_file = measured_traffic(prof_k, wkey) if world == 1 else (None, None)
         traffic, traffic_raw = tr_pair if tr_pair else (None, None)
@@ -543,12 +602,17 @@ def main():
             "unit": "wavenumber-points*layers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "ms_per_step_steady": M["ms_steady"], "steady_steps": M["steady_steps"],
+            "timed_call": "trx_run: atmosphere from host memory, spectrum back to host memory (SURVEY 8(d) t_run)" if world == 1
+                          else "trx_run_device + trx_gather: the slices stay in device memory for the one ncclAllGather",
+            "ms_per_step_device_spectrum": M["ms_device_spectrum"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "CH4-demo-shaped emission (BASELINE configs[1]%s): %g-%g cm-1 @%g cm-1, wnosamp %d, "
+            "config": {"workload": "%s%s: %g-%g cm-1 @%g cm-1, wnosamp %d, %s, "
                                    "%s, H2-H2%s CIA" % (
-                                       ", band and line list x%d: one demo-sized slice per GPU" % grow if grow > 1 else "",
+                                       baseline_config(args, grow),
+                                       " -- BASELINE configs[1] with band and line list x%d: one demo-sized slice per GPU" % grow if grow > 1 else "",
                                        args.wnlow, wnhigh, args.wndelt, args.wnosamp,
+                                       "H2O + CH4 + CO lines" if args.species == 3 else "CH4 lines",
                                        "eclipse, 5 angles" if args.solution == "eclipse" else "transit (slant paths)",
                                        " + H2-He" if args.ncia > 1 else ""),
                        "n_wn": nwn, "n_layers": nlayer, "layers_needed": layers_needed, "layers_swept": R,
@@ -560,8 +624,8 @@ def main():
                        "layer_chunk": args.layer_chunk or "auto: the previous run's depth in equal steps (<= 64 layers where "
                                                           "the line walk applies, one lane per layer)",
                        "steps_per_run": launches, "walk_steps_per_run": wsteps,
-                       "line_kernel": "k_line_walk (%d steps, %d layers) + k_group_sweep (%d steps, %d layers): each with its own "
-                                      "time and bytes in ms_kernels / roofline" % (wsteps, Rw, ssteps, Rs) if mixed else line_k,
+                       "line_kernel": " + ".join(["%s (%d steps, %d layers)" % (n, v["steps_per_run"], v["layers"]) for n, v in walk_forms.items()] +
+                                                 (["k_group_sweep (%d steps, %d layers)" % (ssteps, Rs)] if ssteps else [])),
                        "depth_hint": "step plan ends at the previous run's deepest layer (retrieval-loop reuse; "
                                      "warm-up runs provide it); a run that needs more goes on from there",
                        "ms_create_voigt_table_kernels": stats["ms_create_table"],
@@ -579,17 +643,19 @@ def main():
                        "b_alg_run_bytes": b_alg_run, "b_min_run_bytes": b_min_run,
                        "whole_run_alg_GBs": b_alg_run / (ms_step * 1e-3) / 1e9,
                        "line_layer_bins_per_s": world * stats["sum_bins"] / (ms_step * 1e-3)},
-            "roofline": {"bound": "hbm (distance, not the binding roof)", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm (distance, not the binding roof)", "kernel": dom_label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
+                         "kernels": walk_forms if dom == "k_line_walk" else None,
                          "traffic": traffic, "traffic_uncorrected": traffic_raw, "traffic_source": traffic_file,
                          "bmin_frac": frac_or_none(b_min_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS),
                          "balg_frac": frac_or_none(b_alg_run / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS),
                          "alg_bytes_per_launch": alg[dom] / dlaunch, "avg_launch_ms": kern[dom] / dlaunch,
                          "binding_roof": "fp64-rate vector-instruction issue", "valu_issue_frac": valu_frac,
                          "launches": dlaunch,
-                         "note": "achieved = bytes the dominant kernel's data flow must move (32 B per line record, 4 B "
-                                 "per accumulated bin, its partial records) / its measured time (HIP events on its own "
-                                 "stream).  bmin_frac / balg_frac = the whole spectrum against SURVEY 8(d)'s layer-fused "
+                         "note": "achieved = bytes the dominant kernel family's data flow must move (32 B per line record -- 40 B in "
+                                 "k_line_walk_lanes, which also reads the line's base point --, 4 B per accumulated bin, its "
+                                 "partial records) / its measured time (HIP events on its own stream); `kernels` prices each "
+                                 "member of the family with its own launches and bytes.  bmin_frac / balg_frac = the whole spectrum against SURVEY 8(d)'s layer-fused "
                                  "minimum / reference-flow byte counts (null where the count exceeds what HBM could "
                                  "deliver in the measured time: the fused layers read the line list once, not once "
                                  "per layer).  The walk is not HBM-bandwidth bound: it issues ~38 (two-bin frames, lanes = "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRX_ABI_VERSION 3
+#define TRX_ABI_VERSION 4
 
 typedef enum {
   TRX_OK            =  0,
@@ -226,6 +226,13 @@ typedef struct {
                              records x layers of the step (8 bytes each)                 */
   int64_t walk_layers;    /* layers of the last run swept by walk steps (the rest of layers_swept: two-kernel steps) */
   int64_t sum_bins_walk;  /* the part of sum_bins accumulated by walk steps (counting runs)                          */
+  /* the walk steps by kernel form (ABI 4): [0] k_line_walk (lanes = layers, one range per wave),
+     [1] k_line_walk_lanes (lanes = lines for the strengths), [2] k_line_walk_packed (several ranges per wave) */
+  int64_t walk_form_steps[3];        /* steps of the last run                                                   */
+  int64_t walk_form_layers[3];       /* layers they swept                                                       */
+  int64_t walk_form_record_lanes[3]; /* their share of walk_record_lanes                                        */
+  int64_t walk_form_bins[3];         /* their share of sum_bins_walk (counting runs)                            */
+  double  ms_k_walk_form[3];         /* their share of ms_k_walk (profile >= 1)                                 */
 } trx_stats;
 
 typedef struct trx_handle trx_handle;

@@ -22,15 +22,7 @@ from tolerances import DEBUG_KEYS, assert_tau_close
 pytestmark = pytest.mark.gpu
 
 
-def three_species(n_each, lo, hi):
-    h2o = synth.synth_linedb(n_each, lo, hi, seed=21, name="HITEMP H2O (synthetic)", molname="H2O",
-                             iso_names=("161", "181", "171"), iso_masses=(18.010565, 20.014811, 19.01478),
-                             iso_ratios=(0.997317, 0.002, 0.000372), iso_split=(0.8, 0.15, 0.05), z_scale=170.0)
-    ch4 = synth.synth_linedb(n_each, lo, hi, seed=22)
-    co = synth.synth_linedb(n_each, lo, hi, seed=23, name="HITEMP CO (synthetic)", molname="CO",
-                            iso_names=("26",), iso_masses=(27.994915,), iso_ratios=(0.98654,), iso_split=(1.0,),
-                            z_scale=107.0, log_gf=(-10.0, -4.0))
-    return [h2o, ch4, co]
+three_species = synth.three_species_dbs
 
 
 # Optical depths: the arithmetic's 1e-9 plus the rounding steps of the reference's parabola in

@@ -83,6 +83,22 @@ def test_lanes_walk_demo_shape(tmp_path, nlayers, solution, S):
     assert np.array_equal(sa[-1]["spectrum"], a[-1]["spectrum"][37:211])
 
 
+def test_lanes_walk_without_the_compact_rows(tmp_path):
+    """TRX_NO_ROWS32: k_line_walk_lanes<8> gathers from the 64-byte rows of the walk's table copy (what a handle
+    does whose compact copy would pass 4 GB or whose slab would pass 2^24 bytes) -- the same bits as with the
+    32-byte rows and as k_line_walk."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=120_000, wnlow=2500, wnhigh=2800, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=11)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    a, b, used = both(P, env={"TRX_NO_ROWS32": "1"})
+    assert used > 0, "the lanes form was never taken: the test compares nothing"
+    assert_same(a, b)
+    c, _, used = both(P)                       # (the default form: compact rows)
+    assert used > 0
+    assert_same(a, c)
+
+
 def test_lanes_walk_threshold_and_coadding(tmp_path):
     """A coarse fine grid (wnosamp 400: 2.5 lines per fine-grid point, co-added groups of up to ~10 lines)
     and a threshold that drops groups."""

@@ -395,7 +395,7 @@ def test_every_walk_frame_and_lane_form_against_oracle(tmp_path):
     engine.set_log(lambda lvl, msg: seen.append(msg), 5)
     try:
         eng = Engine(P.static)
-        for chunk in (0, 16):
+        for chunk in (0, 16, 5):                 # (steps of 5 layers: some hold 8-bin frames only)
             P.opts.layer_chunk = chunk
             runs.append(eng.run(P.atm, P.opts, debug=("e",)))
         eng.close()
@@ -407,10 +407,14 @@ def test_every_walk_frame_and_lane_form_against_oracle(tmp_path):
     assert frames, "no frame report in the debug log"
     kinds = set(int(t) for t in frames[0].split(":")[-1].split())
     assert kinds == {0, 2, 4, 8, 16}, kinds
+    # the 16- and 5-layer steps of the later runs put the wide frames through k_line_walk_lanes (a dense list): both of
+    # its instantiations are what is compared with the oracle below
+    assert any("walk: lanes = lines" in m and "8-bin frames" in m for m in seen), "k_line_walk_lanes<8> did not run"
+    assert any("walk: lanes = lines" in m and "16-bin frames" in m for m in seen), "k_line_walk_lanes<16> did not run"
     for r in runs:
         assert rel_err(r["e"], ref["e"]) < 1e-9
         assert rel_err(r["spectrum"], ref["spectrum"]) < 1e-9
-    assert np.array_equal(runs[0]["e"], runs[1]["e"])
+    assert np.array_equal(runs[0]["e"], runs[1]["e"]) and np.array_equal(runs[0]["e"], runs[2]["e"])
 
 
 def test_wide_frames_without_the_row_copy_give_the_same_bits(tmp_path, monkeypatch):

@@ -43,6 +43,8 @@ def test_hinted_production_run_against_the_reference_binary(tmp_path, nlines, so
     engine.set_log(None)
     eng.close()
     assert any("ray tail over" in m for m in msgs), "the hinted run did not take the production path (k_ray_tail)"
+    if solution == "eclipse":       # the deep step (17 layers, 8-bin frames on a dense list) is k_line_walk_lanes: checked HERE against the reference
+        assert any("walk: lanes = lines" in m for m in msgs), "the deep step did not run k_line_walk_lanes"
     assert np.array_equal(prod["spectrum"], got["spectrum"])
     assert len(ref_spec) == P.nwn
     assert np.array_equal(got["last"], ref_last), "rays stop at other layers than the reference's"

@@ -146,6 +146,33 @@ def test_tail_with_copy_commands_instead_of_pinned_outputs(tmp_path):
 
 
 @pytest.mark.parametrize("solution", ["eclipse", "transit"])
+def test_tail_without_the_per_bin_record_table(tmp_path, solution):
+    """TRX_NO_BINREC: the tail finds a bin's records through the ranges' numbers (blo, off) instead of the plan's
+    per-bin record table -- what a handle does whose shard is too large for that table (niso x bins > 2^17) or
+    whose records pass 2^31.  The same bits as the default form and as the step kernels."""
+    d = str(tmp_path / "c")
+    synth.make_case(d, nlines=60_000, wnlow=2500, wnhigh=2700, wndelt=1.0, wnosamp=2160, nlayers=90,
+                    solution=solution, toomuch=10.0, ethresh=1e-50, seed=3, ncia=2 if solution == "transit" else 1)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    os.environ["TRX_NO_BINREC"] = "1"
+    try:
+        c = Engine(P.static)
+    finally:
+        os.environ.pop("TRX_NO_BINREC", None)
+    t, r = engines(P)
+    try:
+        for k in range(3):
+            a, b, x = t.run(P.atm, P.opts, debug=KEYS), c.run(P.atm, P.opts, debug=KEYS), r.run(P.atm, P.opts, debug=KEYS)
+            assert_same(a, x, k); assert_same(b, x, k)
+    finally:
+        t.close(); r.close(); c.close()
+        engine.set_log(None)
+    assert tail_runs(msgs) >= 4          # (hinted runs of both tail handles)
+
+
+@pytest.mark.parametrize("solution", ["eclipse", "transit"])
 @pytest.mark.parametrize("extra", [{"cloudtop": "-2.0", "scattering": "1.5"}, {"scattering": "polar"}])
 def test_tail_with_cloud_and_scattering_models(tmp_path, extra, solution):
     """extinction.c:587-693 switched on: the tail adds the layer parts of both models to the line and

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int16_p = C.POINTER(C.c_int16)
@@ -86,10 +86,13 @@ class TrxStats(C.Structure):
         ("ms_tau", C.c_double), ("ms_cia", C.c_double), ("ms_host_total", C.c_double),
         ("ms_spectrum", C.c_double), ("ncandidates", C.c_int64), ("walk_steps", C.c_int64), ("walk_records", C.c_int64), ("walk_record_lanes", C.c_int64),
         ("walk_layers", C.c_int64), ("sum_bins_walk", C.c_int64),
+        ("walk_form_steps", C.c_int64 * 3), ("walk_form_layers", C.c_int64 * 3), ("walk_form_record_lanes", C.c_int64 * 3),
+        ("walk_form_bins", C.c_int64 * 3), ("ms_k_walk_form", C.c_double * 3),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: (list(getattr(self, name)) if hasattr(getattr(self, name), "__len__") else getattr(self, name))
+                for name, _ in self._fields_}
 
 
 def bind_engine_api(lib, prefix: str = "trx_"):

@@ -984,7 +984,7 @@ void layer_dev(const double *df, const int32_t *di, const LayerHost &LH, int nr,
 
 // ---- per-kernel timing of a profiled run: (start, end) event pairs on the stream of the kernel ----
 struct Spans {
-  enum Kind { kSweep = 0, kWalk = 1, kAccum = 2, kTau = 3 };
+  enum Kind { kSweep = 0, kWalk = 1, kAccum = 2, kTau = 3, kWalkLanes = 4, kWalkPacked = 5, kKinds = 6 };      // (kWalk: k_line_walk itself; the three walk forms add up to trx_stats.ms_k_walk)
   struct Span { hipEvent_t a, b; int kind; };
   std::vector<Span> v;
   int begin(int kind, hipStream_t st) {
@@ -994,7 +994,7 @@ struct Spans {
     return hipEventRecord(sp.a, st) == hipSuccess ? 0 : -1;
   }
   int end(hipStream_t st) { return hipEventRecord(v.back().b, st) == hipSuccess ? 0 : -1; }
-  void sum(double out[4]) const {
+  void sum(double out[kKinds]) const {
     for (const Span &sp : v) { float t = 0; if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) out[sp.kind] += t; }
   }
   ~Spans() { for (Span &sp : v) { if (sp.a) (void)hipEventDestroy(sp.a); if (sp.b) (void)hipEventDestroy(sp.b); } }
@@ -1107,7 +1107,8 @@ int launch_combine(trx_handle *h, PendingCombine &pc, Spans *sp)
 // step's combine.
 int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, int r_top, int nc, const SweepMode &M, Spans *sp,
                int parity, hipStream_t st_comb, hipEvent_t ev_walk, hipEvent_t ev_reuse = nullptr, hipEvent_t ev_done = nullptr,
-               PendingCombine *defer = nullptr /* non-null: the combine is handed back instead of launched */)
+               PendingCombine *defer = nullptr /* non-null: the combine is handed back instead of launched */,
+               int *form_out = nullptr /* which kernel took the step: 0 k_line_walk, 1 k_line_walk_lanes, 2 k_line_walk_packed */)
 {
   hipStream_t st = M.st ? M.st : h->stream;
   WalkPlan P{}; trx_handle::Plan *pl = nullptr;
@@ -1123,7 +1124,6 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   }
   // this buffer's previous records (two steps ago) must have been combined
   if (ev_reuse) HIPCHK(h, hipStreamWaitEvent(st, ev_reuse, 0));
-  if (sp && sp->begin(Spans::kWalk, st)) return fail(h, TRX_E_HIP, "event");
   WalkArgs A{};
   A.lines = h->d_walk.as<WalkLine>(); A.rinfo = h->d_rinfo.as<RangeInfo>(); A.gfirst = h->d_gfirst.as<int32_t>(); A.gcount = h->d_gcount.as<int32_t>();
   A.gblock = h->d_gblock.as<int32_t>(); A.P = P;
@@ -1164,6 +1164,10 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
                      h->max_gcount <= kLanesMaxGroup && (h->ngroups >= 8 * h->nwn || h->lanes_force);
   // steps of few layers: several ranges per wave (k_line_walk_packed: an instruction serves S lines)
   const bool packed = !lanes && nw > 0 && !M.prof && A.tabw != nullptr && nc <= h->packed_max_layers && h->packed_walk;
+  const int form = lanes ? 1 : packed ? 2 : 0;
+  if (form_out) *form_out = form;
+  h->stats.walk_form_steps[form]++; h->stats.walk_form_layers[form] += nc; h->stats.walk_form_record_lanes[form] += pl->records * nc;
+  if (sp && sp->begin(form == 1 ? Spans::kWalkLanes : form == 2 ? Spans::kWalkPacked : Spans::kWalk, st)) return fail(h, TRX_E_HIP, "event");
   if (lanes) {
     // ranges per wave: one (measured at the demo size: 1, 2, 3, 4 ranges per wave 0.239 / 0.257 / 0.283 / 0.276 ms for
     // the spectrum's two walks -- the last lines of a run already get lanes = (line, 4 or 8 layer sets))
@@ -1771,9 +1775,10 @@ static int run_finish(trx_handle *h, const trx_atm *a, const trx_opts *o, trx_de
   S.layers_swept = Q.flags[2];
   h->hint_layers = Q.flags[4];
   S.neval = S.nskip = S.sum_bins = S.sum_bins_walk = S.walk_layers = 0;
+  S.walk_form_bins[0] = S.walk_form_bins[1] = S.walk_form_bins[2] = 0;
   for (int r = 0; r < nr; r++) {
     S.sum_bins += (int64_t)(*Q.counters)[3*r]; S.neval += (int64_t)(*Q.counters)[3*r+1]; S.nskip += (int64_t)(*Q.counters)[3*r+2];
-    if ((*Q.layer_walked)[(size_t)r]) { S.walk_layers++; S.sum_bins_walk += (int64_t)(*Q.counters)[3*r]; }
+    if (const int fw = (*Q.layer_walked)[(size_t)r]) { S.walk_layers++; S.sum_bins_walk += (int64_t)(*Q.counters)[3*r]; S.walk_form_bins[fw - 1] += (int64_t)(*Q.counters)[3*r]; }
   }
   float ms = 0; if (Q.spans) (void)hipEventElapsedTime(&ms, Q.ev_a, Q.ev_b); S.ms_run_total = ms;
   S.ms_cia = Q.ms_cia;
@@ -1787,12 +1792,14 @@ static int run_finish(trx_handle *h, const trx_atm *a, const trx_opts *o, trx_de
     log_msg(TRX_LOG_DEBUG, std::string(b) + "; queueing by phase (us):" + *Q.laps);
   }
   S.ms_k_sweep = S.ms_k_walk = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
+  S.ms_k_walk_form[0] = S.ms_k_walk_form[1] = S.ms_k_walk_form[2] = 0;
   if (Q.spans) {
     // every launch counts (also the ~4 us gated ones after all rays stopped), so that
     // sum / launches is the average a kernel trace reports
-    double t[4] = {0, 0, 0, 0};
+    double t[Spans::kKinds] = {0, 0, 0, 0, 0, 0};
     Q.spans->sum(t);
-    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_walk = t[Spans::kWalk]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
+    S.ms_k_walk_form[0] = t[Spans::kWalk]; S.ms_k_walk_form[1] = t[Spans::kWalkLanes]; S.ms_k_walk_form[2] = t[Spans::kWalkPacked];
+    S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_walk = t[Spans::kWalk] + t[Spans::kWalkLanes] + t[Spans::kWalkPacked]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
     S.sweep_launches = Q.nchunks;
     S.ms_sweep = S.ms_k_sweep + S.ms_k_walk + S.ms_k_accum;
   }
@@ -2090,7 +2097,8 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   if (prof) HIPCHK(h, hipEventRecord(ev.a, st));
 
   h->stats.walk_steps = 0; h->stats.walk_records = 0; h->stats.walk_record_lanes = 0;
-  std::vector<uint8_t> layer_walked((size_t)nr, 0);         // layers swept by walk steps (stats)
+  for (int k = 0; k < 3; k++) h->stats.walk_form_steps[k] = h->stats.walk_form_layers[k] = h->stats.walk_form_record_lanes[k] = 0;
+  std::vector<uint8_t> layer_walked((size_t)nr, 0);         // layers swept by walk steps: 1 + the form that took them (stats)
   if (!h->has_grid && log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
     std::string ln = "run: walk frame (bins) per layer, top first; 0 = two-kernel form:";
     for (int r = nr - 1; r >= 0; r--) ln += " " + std::to_string(walk_frame_bins(h, psmax, r));
@@ -2133,7 +2141,11 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   };
   struct SideWork { bool active = false, first = false; int r_top = 0, nc = 0, swept = 0; hipStream_t st_tau = nullptr; PendingCombine pc; };
   SideWork pending;
+  bool early_behind_inputs = false;            // the side queue has waited for this run's input copy
   auto run_side = [&](SideWork &S) -> int {
+    // The side queue's first work of a run waits for the inputs explicitly.  (Every step kind of today queues it behind
+    // an event recorded on the main queue after the copy -- a walk's, a sweep's -- but that is a rule nothing states.)
+    if (S.st_tau != st && !early_behind_inputs) { HIPCHK(h, hipStreamWaitEvent(S.st_tau, h->ev_inputs, 0)); early_behind_inputs = true; }
     int rc = launch_combine(h, S.pc, prof ? &spans : nullptr);
     if (rc) return rc;
     if (S.first) {
@@ -2267,7 +2279,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (prof && spans.end(st)) return fail(h, TRX_E_HIP, "event");
     } else {
       SweepMode M{};
-      bool walked = false;
+      bool walked = false; int form = 0;
       M.eager = eager; M.prof = count; M.ethresh = o->ethresh;
       M.skip_done = (!eager && !(dbg && dbg->e)); M.nmx = 1; M.d_iso_mx = nullptr; M.permol = false;
       M.d_e = h->d_e.as<double>(); M.d_kmax = kmax_run; M.d_sticky = h->d_sticky.as<int>();
@@ -2277,7 +2289,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (h->ngroups > 0 && !all_saved) {
         if (nb && tail_mode && !resumed) {
           // (no combine of its own: its records wait for the tail, each step in its own buffer)
-          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr, nwalks, nullptr, nullptr, nullptr, nullptr, &S.pc);
+          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr, nwalks, nullptr, nullptr, nullptr, nullptr, &S.pc, &form);
           if (!rc) {
             TailStep &TS = TA.S[TA.nsteps++];
             TS.P = S.pc.C.P; TS.part = S.pc.C.part; TS.nc = nc;
@@ -2288,14 +2300,14 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
         }
         else if (nb) {
           rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, st_tau != st ? st_tau : nullptr, h->ev_ac[nchunks],
-                          nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()], &S.pc);
+                          nwalks >= 2 ? h->ev_cb[(nwalks - 2) % h->ev_cb.size()] : nullptr, h->ev_cb[nwalks % h->ev_cb.size()], &S.pc, &form);
           nwalks++;
         }
         else    rc = sweep_chunk(h, Y, d_wcut, psmax, r_top, nc, sg_layers, M, prof ? &spans : nullptr);
         if (rc) return rc;
         walked = nb != 0;
         step_walked = walked;
-        if (walked) for (int c = 0; c < nc; c++) layer_walked[(size_t)(r_top - c)] = 1;
+        if (walked) for (int c = 0; c < nc; c++) layer_walked[(size_t)(r_top - c)] = (uint8_t)(1 + form);
       }
       if (st_tau != st && !walked) {     // the optical depth of this step follows its extinction
         HIPCHK(h, hipEventRecord(h->ev_ac[nchunks], st));
@@ -2512,16 +2524,30 @@ struct trx_batch {
 
 int trx_batch_create(const trx_static *st, int32_t ways, trx_batch **out)
 {
-  if (!st || !out || ways < 1 || ways > TRX_BATCH_MAX_WAYS) return TRX_E_ARG;
+  g_comm_err.clear();
+  if (!st || !out || ways < 1 || ways > TRX_BATCH_MAX_WAYS) { g_comm_err = "batch: bad argument (ways 1.." + std::to_string(TRX_BATCH_MAX_WAYS) + ")"; return TRX_E_ARG; }
   *out = nullptr;
-  std::unique_ptr<trx_batch> B(new trx_batch);
+  std::unique_ptr<trx_batch> B(new (std::nothrow) trx_batch);
+  if (!B) { g_comm_err = "batch: out of host memory"; return TRX_E_NOMEM; }
+  // (no C++ exception crosses the C boundary: a failed handle, allocation or thread start gives the handles back,
+  // joins the workers that did start and returns a code, its text through trx_last_error(NULL))
+  auto give_up = [&](int rc, const std::string &why) {
+    { std::lock_guard<std::mutex> lk(B->mu); B->quit = true; }
+    B->cv_work.notify_all();
+    for (std::thread &t : B->workers) if (t.joinable()) t.join();
+    for (trx_handle *x : B->hs) trx_destroy(x);
+    B->hs.clear(); B->workers.clear();
+    g_comm_err = why;
+    return rc;
+  };
   for (int i = 0; i < ways; i++) {
     trx_handle *h = nullptr;
     const int rc = trx_create(st, &h);
-    if (rc != TRX_OK) { for (trx_handle *x : B->hs) trx_destroy(x); return rc; }
-    B->hs.push_back(h);
+    if (rc != TRX_OK) return give_up(rc, "batch: handle " + std::to_string(i) + ": " + trx_strerror(rc));
+    try { B->hs.push_back(h); } catch (...) { trx_destroy(h); return give_up(TRX_E_NOMEM, "batch: out of host memory"); }
   }
   trx_batch *b = B.get();
+  try {
   for (int i = 0; i < ways; i++)
     b->workers.emplace_back([b, i]() {
       uint64_t seen = 0;
@@ -2546,6 +2572,8 @@ int trx_batch_create(const trx_static *st, int32_t ways, trx_batch **out)
         if (--b->busy == 0) b->cv_done.notify_all();
       }
     });
+  } catch (const std::bad_alloc &) { return give_up(TRX_E_NOMEM, "batch: out of host memory");
+  } catch (const std::exception &e) { return give_up(TRX_E_HIP, std::string("batch: worker thread: ") + e.what()); }
   *out = B.release();
   return TRX_OK;
 }

@@ -86,6 +86,15 @@ class CEngine:
             raise EngineError(rc, self._p + "run", self._last_error())
         return out
 
+    def run_into(self, atm: _abi.TrxAtm, opts: _abi.TrxOpts, spectrum: np.ndarray) -> None:
+        """trx_run into a caller's float64 array of this handle's shard size: no allocation per call
+        (retrieval loops, bench.py's timed step)."""
+        if spectrum.dtype != np.float64 or not spectrum.flags.c_contiguous or spectrum.size < self.nwn:
+            raise ValueError("spectrum: a C-contiguous float64 array of at least %d elements" % self.nwn)
+        rc = self._f("run")(self._h, C.byref(atm), C.byref(opts), spectrum.ctypes.data_as(_abi.c_double_p), None)
+        if rc != 0:
+            raise EngineError(rc, self._p + "run", self._last_error())
+
     def sweep_permol(self, nv, temp, density, zpart, ethresh, nslot, iso_slot) -> np.ndarray:
         """computemolext(permol=1) for nv states: returns o[nv][nslot][nwn]."""
         out = np.zeros((nv, nslot, self.nwn))

@@ -275,6 +275,19 @@ def write_cfg(path: str, options: Dict[str, object]) -> str:
 # --------------------------------------------------------------------------
 # one-call case builder
 # --------------------------------------------------------------------------
+def three_species_dbs(n_each: int, lo: float, hi: float) -> List[LineDB]:
+    """H2O + CH4 + CO line databases of n_each lines (six isotopes): BASELINE configs[2]'s multi-species TLI
+    (three databases over 333.33-10000 cm-1)."""
+    h2o = synth_linedb(n_each, lo, hi, seed=21, name="HITEMP H2O (synthetic)", molname="H2O",
+                       iso_names=("161", "181", "171"), iso_masses=(18.010565, 20.014811, 19.01478),
+                       iso_ratios=(0.997317, 0.002, 0.000372), iso_split=(0.8, 0.15, 0.05), z_scale=170.0)
+    ch4 = synth_linedb(n_each, lo, hi, seed=22)
+    co = synth_linedb(n_each, lo, hi, seed=23, name="HITEMP CO (synthetic)", molname="CO",
+                      iso_names=("26",), iso_masses=(27.994915,), iso_ratios=(0.98654,), iso_split=(1.0,),
+                      z_scale=107.0, log_gf=(-10.0, -4.0))
+    return [h2o, ch4, co]
+
+
 def make_case(outdir: str, *, nlines: int = 3000, wnlow: float = 2500.0, wnhigh: float = 2560.0,
               wndelt: float = 1.0, wnosamp: int = 2160, nlayers: int = 30,
               solution: str = "eclipse", toomuch: float = 10.0, ethresh: float = 1e-50,
