@@ -4,7 +4,7 @@ k_line_walk_packed: the same lines in the same order, the same base points of th
 the same frame and the same partial records -- so the same BITS in extinction, optical depth and
 spectrum.  Goldens (forced on their sparse lists: single-group blocks, frames that jump), demo-shaped
 atmospheres whose deep step has 17 layers, a shard, lists with long co-added groups and several
-isotopes, and every S (ranges per wave)."""
+isotopes."""
 import os
 
 import numpy as np
@@ -63,19 +63,18 @@ def test_lanes_walk_on_goldens(case):
     assert_same(a, b)
 
 
-@pytest.mark.parametrize("nlayers,solution,S", [(100, "eclipse", "0"), (100, "transit", "3"), (100, "eclipse", "1"), (100, "eclipse", "8"),
-                                                (24, "transit", "5"), (31, "eclipse", "2")])
-def test_lanes_walk_demo_shape(tmp_path, nlayers, solution, S):
+@pytest.mark.parametrize("nlayers,solution", [(100, "eclipse"), (100, "transit"), (24, "transit"), (31, "eclipse")])
+def test_lanes_walk_demo_shape(tmp_path, nlayers, solution):
     d = str(tmp_path / "c")
     synth.make_case(d, nlines=120_000, wnlow=2500, wnhigh=2800, wndelt=1.0, wnosamp=2160, nlayers=nlayers,
                     solution=solution, toomuch=10.0, ethresh=1e-50, seed=11, ncia=2 if solution == "transit" else 1)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
-    a, b, used = both(P, env={"TRX_LANES_S": S})
+    a, b, used = both(P)
     assert used > 0, "the lanes form was never taken: the test compares nothing"
     assert_same(a, b)
     P.set_shard(37, 211)                       # a shard: only the ranges that reach it are launched
     try:
-        sa, sb, used = both(P, runs=1, env={"TRX_LANES_S": S})
+        sa, sb, used = both(P, runs=1)
     finally:
         P.set_shard(0, P.nwn)
     assert used > 0

@@ -393,9 +393,33 @@ def test_every_walk_frame_and_lane_form_against_oracle(tmp_path):
     ora.close()
     seen, runs = [], []
     engine.set_log(lambda lvl, msg: seen.append(msg), 5)
+
+    def frames_of():
+        fr = [m for m in seen if "walk frame (bins) per layer" in m]
+        assert fr, "no frame report in the debug log"
+        return [int(t) for t in fr[0].split(":")[-1].split()]          # top layer first
+
     try:
         eng = Engine(P.static)
-        for chunk in (0, 16, 5):                 # (steps of 5 layers: some hold 8-bin frames only)
+        P.opts.layer_chunk = 0
+        runs.append(eng.run(P.atm, P.opts, debug=("e",)))
+        frames = frames_of()
+        # a step size whose steps (equal parts from the top) include one that holds 8-bin frames and nothing wider:
+        # that step is k_line_walk_lanes<8>'s (a dense list); the 16-bin frames get theirs in any step of <= 32 layers
+        def step_frames(c):                        # the step plan of trx_run for layer_chunk = c (plan_step: equal parts of what is left)
+            nwalk = frames.index(0) if 0 in frames else len(frames)
+            pos, out = 0, []
+            while pos < nwalk:
+                left = nwalk - pos
+                nc = -(-left // -(-left // c))
+                if pos == 0:
+                    nc = max(nc, 3)
+                out.append(max(frames[pos:pos + nc]))
+                pos += nc
+            return out
+        chunk8 = next((c for c in range(3, 17) if 8 in step_frames(c)), None)
+        assert chunk8 is not None, frames
+        for chunk in (16, chunk8):
             P.opts.layer_chunk = chunk
             runs.append(eng.run(P.atm, P.opts, debug=("e",)))
         eng.close()
@@ -403,11 +427,9 @@ def test_every_walk_frame_and_lane_form_against_oracle(tmp_path):
         engine.set_log(None)
         P.opts.layer_chunk = 0
         P.opts.eager = 0
-    frames = [m for m in seen if "walk frame (bins) per layer" in m]
-    assert frames, "no frame report in the debug log"
-    kinds = set(int(t) for t in frames[0].split(":")[-1].split())
+    kinds = set(frames)
     assert kinds == {0, 2, 4, 8, 16}, kinds
-    # the 16- and 5-layer steps of the later runs put the wide frames through k_line_walk_lanes (a dense list): both of
+    # the 16-layer steps and the steps of the chosen size put the wide frames through k_line_walk_lanes: both of
     # its instantiations are what is compared with the oracle below
     assert any("walk: lanes = lines" in m and "8-bin frames" in m for m in seen), "k_line_walk_lanes<8> did not run"
     assert any("walk: lanes = lines" in m and "16-bin frames" in m for m in seen), "k_line_walk_lanes<16> did not run"

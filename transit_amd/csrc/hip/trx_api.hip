@@ -94,10 +94,10 @@ struct trx_handle {
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
   // steps of at most 32 layers with frames of 8+ bins: lanes = lines for the strengths (trx_lanes.hip.h; TRX_LANES_WALK=0:
-  // the one-range / packed forms; TRX_LANES_S: ranges per wave, 0 = by the launch's size)
+  // the one-range / packed forms)
   bool no_binrec = false;                            // TRX_NO_BINREC: k_ray_tail finds a bin's records through the ranges' numbers (A/B, tests)
   int xcd_map = 1;                                   // blocks -> ranges by XCD (xcd_block): bit 0 k_line_walk_lanes, bit 1 k_line_walk (measured: slower there).  TRX_XCD_MAP, A/B
-  bool lanes_walk = true, lanes_force = false; int lanes_s = 0; int max_gcount = 0; DevBuf d_linebase, d_rinfo;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
+  bool lanes_walk = true, lanes_force = false; int max_gcount = 0; DevBuf d_linebase, d_rinfo;   // (TRX_LANES_WALK=2: also on sparse lists, tests)
   bool no_row_copy = false, no_rows32 = false;
   bool row_staging = true;          // osamp == 1: wide profiles through k_accumulate_rows (TRX_NO_ROW_STAGING at create: tests compare the two forms)
   // lines
@@ -298,7 +298,6 @@ void test_switches(trx_handle *h)
   if (const char *e = std::getenv("TRX_XCD_MAP")) h->xcd_map = std::atoi(e);
   h->no_binrec = std::getenv("TRX_NO_BINREC") != nullptr;
   if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }      // k_line_walk_lanes never / also on sparse lists (test_gpu_lanes)
-  if (const char *e = std::getenv("TRX_LANES_S")) h->lanes_s = std::max(0, std::min(kLanesMaxS, std::atoi(e)));                       // ... ranges per wave
   if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;            // the step kernels instead of k_ray_tail (test_gpu_tail)
   if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;      // ... copy commands instead of stores into pinned memory
   if (const char *e = std::getenv("TRX_CIA_WINDOW")) h->cia_window = std::atoi(e) != 0;        // the CIA spline over the whole table (test_gpu_cia_window)
@@ -1169,19 +1168,35 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
   h->stats.walk_form_steps[form]++; h->stats.walk_form_layers[form] += nc; h->stats.walk_form_record_lanes[form] += pl->records * nc;
   if (sp && sp->begin(form == 1 ? Spans::kWalkLanes : form == 2 ? Spans::kWalkPacked : Spans::kWalk, st)) return fail(h, TRX_E_HIP, "event");
   if (lanes) {
-    // ranges per wave: one (measured at the demo size: 1, 2, 3, 4 ranges per wave 0.239 / 0.257 / 0.283 / 0.276 ms for
-    // the spectrum's two walks -- the last lines of a run already get lanes = (line, 4 or 8 layer sets))
-    int S = h->lanes_s;
-    if (S <= 0) S = 1;
-    LanesExtra X{h->d_linebase.as<double>(), S};
+    // one range per wave (round 4 measured 2, 3, 4 ranges per wave at the demo size: 0.257 / 0.283 / 0.276 ms for the
+    // spectrum's two walks against 0.239 -- the last lines of a range already get lanes = (line, 4 or 8 layer sets);
+    // the kernel no longer has that form)
+    LanesExtra X{h->d_linebase.as<double>()};
+#ifdef TRX_CLK
+    static DevBuf clkbuf; static std::vector<long long> clkhost; static double clktot[8]; static long long clkn = 0, clkw = 0;
+    if (ensure(h, clkbuf, 64 * (size_t)h->nwaves)) return TRX_E_NOMEM;
+    (void)hipMemsetAsync(clkbuf.p, 0, 64 * (size_t)h->nwaves, st);
+    X.clk = clkbuf.as<long long>();
+#endif
     A.xcd_map = h->xcd_map & 1;
     if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG)
-      log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames, " + std::to_string(S) + " ranges per wave");
-    const unsigned lw = (nw + (unsigned)S - 1) / (unsigned)S;
-    const dim3 grid((lw + kLanesWaves - 1) / kLanesWaves), block(64 * kLanesWaves);
+      log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames");
+    const dim3 grid((nw + kLanesWaves - 1) / kLanesWaves), block(64 * kLanesWaves);
     const size_t lds = lanes_lds_bytes(nc, h->ndop);
-    if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 4>), grid, block, lds, st, A, X);
+    if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 4>), grid, block, lds, st, A, X);       // (blocks of 4 groups; 5: 101.2 us, 6: 103.6 against 102.2, round 5)
     else         hipLaunchKernelGGL((k_line_walk_lanes<16, 4>), grid, block, lds, st, A, X);
+#ifdef TRX_CLK
+    (void)hipStreamSynchronize(st);
+    clkhost.resize(8 * (size_t)h->nwaves);
+    (void)hipMemcpy(clkhost.data(), clkbuf.p, 64 * (size_t)h->nwaves, hipMemcpyDeviceToHost);
+    for (int wv_ = 0; wv_ < h->nwaves; wv_++) { bool any = false; for (int k = 0; k < 8; k++) { clktot[k] += (double)clkhost[8 * (size_t)wv_ + k]; any |= clkhost[8 * (size_t)wv_ + k] != 0; } clkw += any; }
+    if (++clkn % 100 == 0) {
+      double tot = 0; for (int k = 0; k < 8; k++) tot += clktot[k];
+      std::fprintf(stderr, "CLK launches %lld waves/launch %.0f clocks/wave %.0f :", clkn, (double)clkw / clkn, tot / clkw);
+      for (int k = 0; k < 6; k++) std::fprintf(stderr, " [%d] %.1f%%", k, 100.0 * clktot[k] / tot);
+      std::fprintf(stderr, "\n");
+    }
+#endif
   }
   else if (packed) {
     const int S = 64 / nc;
