@@ -1172,12 +1172,6 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     // spectrum's two walks against 0.239 -- the last lines of a range already get lanes = (line, 4 or 8 layer sets);
     // the kernel no longer has that form)
     LanesExtra X{h->d_linebase.as<double>()};
-#ifdef TRX_CLK
-    static DevBuf clkbuf; static std::vector<long long> clkhost; static double clktot[8]; static long long clkn = 0, clkw = 0;
-    if (ensure(h, clkbuf, 64 * (size_t)h->nwaves)) return TRX_E_NOMEM;
-    (void)hipMemsetAsync(clkbuf.p, 0, 64 * (size_t)h->nwaves, st);
-    X.clk = clkbuf.as<long long>();
-#endif
     A.xcd_map = h->xcd_map & 1;
     if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG)
       log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames");
@@ -1185,18 +1179,6 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     const size_t lds = lanes_lds_bytes(nc, h->ndop);
     if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 4>), grid, block, lds, st, A, X);       // (blocks of 4 groups; 5: 101.2 us, 6: 103.6 against 102.2, round 5)
     else         hipLaunchKernelGGL((k_line_walk_lanes<16, 4>), grid, block, lds, st, A, X);
-#ifdef TRX_CLK
-    (void)hipStreamSynchronize(st);
-    clkhost.resize(8 * (size_t)h->nwaves);
-    (void)hipMemcpy(clkhost.data(), clkbuf.p, 64 * (size_t)h->nwaves, hipMemcpyDeviceToHost);
-    for (int wv_ = 0; wv_ < h->nwaves; wv_++) { bool any = false; for (int k = 0; k < 8; k++) { clktot[k] += (double)clkhost[8 * (size_t)wv_ + k]; any |= clkhost[8 * (size_t)wv_ + k] != 0; } clkw += any; }
-    if (++clkn % 100 == 0) {
-      double tot = 0; for (int k = 0; k < 8; k++) tot += clktot[k];
-      std::fprintf(stderr, "CLK launches %lld waves/launch %.0f clocks/wave %.0f :", clkn, (double)clkw / clkn, tot / clkw);
-      for (int k = 0; k < 6; k++) std::fprintf(stderr, " [%d] %.1f%%", k, 100.0 * clktot[k] / tot);
-      std::fprintf(stderr, "\n");
-    }
-#endif
   }
   else if (packed) {
     const int S = 64 / nc;

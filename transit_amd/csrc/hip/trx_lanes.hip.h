@@ -54,9 +54,6 @@ constexpr int kLanesRows = kLanesBatch + 2;      // rows of the two per-(group, 
 
 struct LanesExtra {
   const double *wbase;                 // [nlines] wavenumber of the line's base point (rebased exponential)
-#ifdef TRX_CLK
-  long long *clk;                      // [waves][8] shader clocks per phase (a measurement build)
-#endif
 };
 
 // per wave: kk [rows][ne] doubles, at [rows][ne] words, the layers' records (ne: layers rounded up to even), exp(ct * base point) [bases][ne], the groups' cells [batch] words
@@ -127,15 +124,8 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     for (int j = blo + lane; j <= bhi; j += 64) o |= A.last[j - A.lo] < 0;
     open = __ballot(o) != 0ull;
   }
-#ifdef TRX_CLK
-  long long clk_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clk_prev = (long long)__builtin_amdgcn_s_memtime();
-  auto stamp = [&](int k) { const long long t = (long long)__builtin_amdgcn_s_memtime(); clk_sum[k] += t - clk_prev; clk_prev = t; };
-#else
-  auto stamp = [](int) {};
-#endif
   __syncthreads();                                           // (the only workgroup barrier: from here the waves are on their own)
   if (!open) return;
-  stamp(0);
 
   // ---- phase 2's lane: layer li, part of the frame (slots part*NS ...)
   const int li = lane >> 1, part = lane & 1;
@@ -233,7 +223,6 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
   };
   Lines cur = fetch(l0);
   __builtin_amdgcn_wave_barrier();
-  stamp(1);
   // set 1 starts as an empty block IN FLIGHT (weights 0): the state every later batch begins in -- the first batch's wait
   // for its line records then leaves these loads outstanding like any other's (one wait count for the loop, not "all")
   bn[1] = 0; bcell[1] = cell0;
@@ -295,7 +284,6 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     { const double wl = readlane_f64(wavn, n - 1); if (lane < ne) step = LK[lane][5] * wl < LK[lane][6]; }
     const bool slow = __any(step);
     __builtin_amdgcn_wave_barrier();
-    stamp(2);
     auto layer = [&](int c2, auto E0TAB, auto SLOW) {
       const int c = min(c2 + h1, ne - 1);                   // (sets past the last layer repeat it: the same values to the same places)
       double *K = LK[c];
@@ -353,7 +341,6 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     else if (e0_tab) for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, T{}, F{});
     else             for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, F{}, F{});
     __builtin_amdgcn_wave_barrier();
-    stamp(3);
 
     // ---- the next batch's lines: requested here, they arrive under phase 2
     const int l_next = l + n;
@@ -392,7 +379,6 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       consume(std::integral_constant<int, 0>{});
     } while (--it > 0);
     __builtin_amdgcn_wave_barrier();                         // (the next batch overwrites the LDS entries)
-    stamp(4);
     l = l_next;
   }
   // the block still in flight, then the range's last bins
@@ -400,10 +386,6 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
 #pragma unroll
   for (int k = 0; k < NS; k++) flush(k, acc[k], true);
   fill_zero(blo, jc - Rc - 1);
-#ifdef TRX_CLK
-  stamp(5);
-  if (lane == 0) for (int k = 0; k < 8; k++) X.clk[(long long)w * 8 + k] = clk_sum[k];
-#endif
 }
 
 }  // namespace trx
