@@ -127,7 +127,7 @@ struct trx_handle {
   DevBuf d_SG, d_idop8, d_sticky, d_part3;
   // per-run inputs: packed into ONE pinned host block and copied with ONE transfer
   // (layer scalars, ray geometry, impact parameters, CIA density products)
-  DevBuf d_in; void *h_in = nullptr; size_t h_in_bytes = 0;
+  DevBuf d_in; void *h_in = nullptr; size_t h_in_bytes = 0; const double *h_in_dev = nullptr;      // (h_in_dev: the pinned block as the device sees it)
   DevBuf d_pm_f64, d_pm_i32;         // the same scalars of a per-molecule sweep (trx_sweep_permol)
   // what the host reads back after a run, in ONE device block and one pinned host block:
   // flags (8 ints, byte 0), status (4 ints, byte 64), counters (3 per layer, byte 128)
@@ -881,6 +881,12 @@ struct LayerHost {
   LayerHost(std::vector<double> &f, std::vector<int32_t> &i) : f64(f), i32(i) {}
 };
 
+// -c/T per layer and the strength factor SIGCTE*ratio/(m*Z) per (layer, isotope): all k_layer_max needs of a run's
+// inputs.  trx_run writes them first, straight into the pinned block, and launches the layer maxima before the rest of
+// the prologue (prep_layers, which computes the same values again for the block's device copy).
+inline double layer_negct(double temp) { return -kExpCte * kTliEfct / temp; }
+inline double layer_strength(const trx_handle *h, int i, double z) { return kSigCte * h->iso_ratio[i] / (h->iso_mass[i] * z); }
+
 int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *density /* [nmol][nr] */,
                 const double *zpart /* [niso][nr] */, size_t extra_doubles, LayerHost &LH)
 {
@@ -896,7 +902,7 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
   for (int r = 0; r < nr; r++) {
     const double temp = temp_k[r];
     if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
-    negct[r] = -kExpCte * kTliEfct / temp;
+    negct[r] = layer_negct(temp);
     const double fdoppler = std::sqrt(2 * kKb * temp / kAmu) * kSqrtLn2 / kLs;
     const double florentz = std::sqrt(2 * kKb * temp / kPi / kAmu) / (kAmu * kLs);
     for (int i = 0; i < niso; i++) {
@@ -910,7 +916,7 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       alphal[k] = al; alphad[k] = ad;
       idop0[k] = nearest_index(h->adop.data(), ad * h->wn_i, 0, h->ndop);
       ilor[k]  = nearest_index(h->alor.data(), al, 0, h->nlor);
-      strength[k] = kSigCte * h->iso_ratio[i] / (h->iso_mass[i] * zpart[(size_t)i * nr + r]);
+      strength[k] = layer_strength(h, i, zpart[(size_t)i * nr + r]);
       dens[k] = density[(size_t)h->iso_imol[i] * nr + r];
       wcut[k] = doppler_refresh_cut(ad, al);
       int dlo = idop0[k], dhi = idop0[k];
@@ -1310,13 +1316,12 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
 // on the inputs only, not on how far the rays get, so they leave the per-step chain.
 // kmax: [nv][nmx], zero on entry.  init: the run's small buffers, initialised by an extra row of
 // blocks of the first launch (null: none); *init_done tells whether that happened.
-int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_npre, int nv, const double *temp_k,
-                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st, double *kmax,
-                            const RunInit *init = nullptr, bool *init_done = nullptr)
+// Two launches, each usable on its own: trx_run queues the maxima BEFORE the rest of its host prologue
+// (they need -c/T and the strength factors only, which it hands over in pinned host memory).
+int launch_layer_max(trx_handle *h, const LayerDev &Y, int nv, const double *temp_k, int nmx, const int32_t *d_iso_mx,
+                     hipStream_t st, double *kmax, const RunInit *init = nullptr, bool *init_done = nullptr)
 {
-  int rc;
   if (init_done) *init_done = false;
-  if ((rc = ensure(h, h->d_sticky, sizeof(int) * (size_t)nv * std::max(h->niso, 1)))) return rc;
   if (h->ngroups == 0) return TRX_OK;
   // the pruning argument needs c*nu/T well above the rounding of 1 - exp(-c*nu/T) (trx_walk.hip.h)
   bool pruned = h->ncand > 0;
@@ -1335,14 +1340,41 @@ int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_n
                        h->L, Yr, h->niso, nr, pruned ? h->d_candrec.as<CandLine>() : nullptr, n, h->d_e2tab.as<double>(), nmx, d_iso_mx,
                        (unsigned long long *)(kmax + (size_t)r0 * nmx), R, with_init ? (int)ny : -1, xwaves);
   }
-  for (int r0 = 0; r0 < nv; r0 += 4096) {               // one wave per (layer, isotope)
-    const int nr = std::min(4096, nv - r0);
-    hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nr * h->niso)), dim3(64), 0, st,
+  return TRX_OK;
+}
+
+// (copy_*: the run's input block from pinned host memory into device memory, by extra blocks of the first launch)
+int launch_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_npre, int nv, int nmx, const int32_t *d_iso_mx, double ethresh,
+                  hipStream_t st, const double *kmax, const void *copy_src = nullptr, void *copy_dst = nullptr, size_t copy_bytes = 0)
+{
+  const long long n16 = (long long)(copy_bytes / 16);
+  if (h->ngroups == 0 && n16 == 0) return TRX_OK;
+  bool copied = n16 == 0;
+  for (int r0 = 0; r0 < nv || !copied; r0 += 4096) {               // one wave per (layer, isotope)
+    const int nr = h->ngroups == 0 ? 0 : std::max(0, std::min(4096, nv - r0));
+    const int nst = nr * h->niso;
+    const int ncp = copied ? 0 : (int)std::min<long long>((n16 + 63) / 64, 64);
+    if (nst + ncp == 0) break;
+    hipLaunchKernelGGL(k_sticky_index, dim3((unsigned)(nst + ncp)), dim3(64), 0, st,
                        h->L, Y, h->niso, r0 + nr - 1, nr, kmax, nmx, d_iso_mx, ethresh, h->d_dopthr.as<double>(), h->ndop,
-                       h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), 1);
+                       h->d_e2tab.as<double>(), d_npre, h->d_sticky.as<int>(), h->d_flags.as<int>(), 1,
+                       copied ? nullptr : (const uint4 *)copy_src, copied ? nullptr : (uint4 *)copy_dst, copied ? 0LL : n16, nst);
+    copied = true;
   }
   HIPCHK(h, hipGetLastError());
   return TRX_OK;
+}
+
+int layer_maxima_and_sticky(trx_handle *h, const LayerDev &Y, const int32_t *d_npre, int nv, const double *temp_k,
+                            int nmx, const int32_t *d_iso_mx, double ethresh, hipStream_t st, double *kmax,
+                            const RunInit *init = nullptr, bool *init_done = nullptr)
+{
+  int rc;
+  if (init_done) *init_done = false;
+  if ((rc = ensure(h, h->d_sticky, sizeof(int) * (size_t)nv * std::max(h->niso, 1)))) return rc;
+  if (h->ngroups == 0) return TRX_OK;
+  if ((rc = launch_layer_max(h, Y, nv, temp_k, nmx, d_iso_mx, st, kmax, init, init_done))) return rc;
+  return launch_sticky(h, Y, d_npre, nv, nmx, d_iso_mx, ethresh, st, kmax);
 }
 
 }  // namespace
@@ -1853,21 +1885,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const bool stop_at_hint_ok = !h->has_grid && !eager && h->hint_layers > 0 && h->hint_layers <= nr;
   int rc;
 
-  // ---- layer prologue (extinction.c:364-395) --------------------------------
-  LayerHost LH(h->run_f64, h->run_i32);
-  if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
-  h->walk_temp_ok = true;
-  for (int r = 0; r < nr; r++) if (a->temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
-  const size_t nli = LH.nli;
-  std::vector<double> &f64 = LH.f64;
-  const int32_t *psmax = LH.psmax;
-  // Layers per step.  The walk (narrow profiles) takes up to 64 layers, one per lane; its cost
-  // hardly depends on how many lanes are busy, so its steps are as large as the plan allows.
-  // The two-kernel form keeps a strength buffer per layer in flight: at most kMaxChunk, and
-  // 8 where the profiles are wide (a tile only learns between steps that its rays stopped).
-  // Optical depths are integrated in sub-steps of at most tau_cap layers.
-  const int tau_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;
-  const int user_chunk = o->layer_chunk > 0 ? std::max(3, o->layer_chunk) : 0;
+  hipStream_t st_sweep = st;
+  const auto t_host_first = std::chrono::steady_clock::now();
+  const bool lap_on = log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG;
+  std::string laps; auto t_lap = t_host_first;
+  auto lap = [&](const char *what) {
+    if (!lap_on) return;
+    const auto n = std::chrono::steady_clock::now();
+    char b[64]; std::snprintf(b, sizeof b, " %s %.0f", what, 1e3 * std::chrono::duration<double, std::milli>(n - t_lap).count());
+    laps += b; t_lap = n;
+  };
   // ---- ray geometry: Simpson weights per start layer (eclipse.c:82-96, slantpath.c:76-95)
   // (eclipse geometry uses tabulated weights for its one three-point ray only: rows of one pair,
   // no modulation table -- 9 KB instead of 330 KB to build, copy and ship per run at 100 layers)
@@ -1876,91 +1903,25 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const size_t mw_doubles = vertical ? 0 : (size_t)(nr + 1) * gstride;
   const size_t n_geom_all = (size_t)(nr + 1) * gstride + mw_doubles + 2 * (size_t)(nr + 1) + 4 * (size_t)nr + 2 * (size_t)nr +
                             (vertical ? (size_t)kVertLay * nr : 0);       // (vertical rays: the chain's per-layer constants behind the rest)
-  std::vector<double> &geom = h->run_geom, &ipv = h->run_ipv;
-  run_host_inputs(h, a, LH, vertical, gstride, mw_doubles, n_geom_all, geom, ipv);
-
-  double ms_cia = 0;
-
-  // ---- workspaces -------------------------------------------------------------
-  // Two streams: the line sweep of step c+1 (saturates the machine) runs on stream4 while the
-  // optical depth of step c (a latency chain on a few waves) is integrated on the main stream.
-  const bool pipelined = !h->has_grid;
-  bool any_wide = false;                      // some layer needs the two-kernel form
-  for (int r = 0; r < nr && !any_wide; r++) any_wide = walk_frame_bins(h, psmax, r) == 0;
-  const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
-  const int sg_layers = any_wide ? (user_chunk ? std::min(user_chunk, kMaxChunk) : kMaxChunk) : 1;
-  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * sg_layers)) || (rc = ensure(h, h->d_idop8, gr_b * sg_layers)) ||
-      (rc = ensure_small(h, nr)) ||
-      (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
-      (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_last, sizeof(int) * nsh)) ||
-      (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)) ||
-      (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)))
-    return rc;
-  if (pipelined)
-    while ((int)h->ev_ac.size() < nr + 1) {
-      hipEvent_t e1, e2;
-      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
-      h->ev_ac.push_back(e1); h->ev_cb.push_back(e2);
-    }
-  if (count && any_wide && (rc = ensure(h, h->d_part3, 24 * (size_t)kMaxChunk * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
-    return rc;
-  if ((rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh))) return rc;
-  // ---- per-run inputs: one pinned block, one transfer ------------------------------------
+  // ---- per-run inputs: one pinned block (its layout is the run's shape alone)
   // [layer scalars f64 | ray geometry | impact parameters | CIA density products | layer scalars i32]
-  const size_t n_f64 = f64.size(), n_geom = geom.size(), n_ip = ipv.size(), n_cd = (size_t)nr * h->cia.size(), n_i32 = LH.i32.size();
+  const size_t nli = (size_t)nr * std::max(h->niso, 1);
+  const size_t n_f64 = 7 * nli + 8 * (size_t)nr, n_geom = vertical ? n_geom_all : 1, n_ip = (size_t)nr, n_cd = (size_t)nr * h->cia.size(), n_i32 = 4 * nli;
   const size_t off_geom = n_f64, off_ip = off_geom + n_geom, off_cd = off_ip + n_ip, off_i32 = off_cd + n_cd;    // in doubles
-  const size_t in_bytes = 8 * off_i32 + 4 * n_i32 + 8;
+  const size_t in_bytes = (8 * off_i32 + 4 * n_i32 + 8 + 15) & ~(size_t)15;
   if (h->h_in_bytes < in_bytes) {
     if (h->h_in) (void)hipHostFree(h->h_in);
-    h->h_in = nullptr; h->h_in_bytes = 0;
+    h->h_in = nullptr; h->h_in_bytes = 0; h->h_in_dev = nullptr;
     HIPCHK(h, hipHostMalloc(&h->h_in, in_bytes, hipHostMallocDefault));
     h->h_in_bytes = in_bytes;
+    void *dp = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_in, 0));
+    h->h_in_dev = (const double *)dp;
   }
-  if ((rc = ensure(h, h->d_in, in_bytes))) return rc;
-  {
-    double *hin = (double *)h->h_in;
-    std::memcpy(hin, f64.data(), 8 * n_f64);
-    std::memcpy(hin + off_geom, geom.data(), 8 * n_geom);
-    std::memcpy(hin + off_ip, ipv.data(), 8 * n_ip);
-    cia_densities(h, a, hin + off_cd);
-    std::memcpy(hin + off_i32, LH.i32.data(), 4 * n_i32);
-  }
-  // the whole front end of a run goes to the stream the line sweep runs on (the main stream
-  // joins it at the first optical depth): no cross-stream hop before the first sweep kernel
-  // Streams.  The front end (inputs, layer maxima), the walks and everything that follows the
-  // LAST walk of the plan -- its combine, optical depth, the spectrum, the copies back -- sit on
-  // ONE queue: that chain is the critical path, and a hop between queues costs it ~30 us of
-  // signalling.  The combines and optical depths of the earlier steps go to a second queue, where
-  // they overlap the next step's walk.
-  hipStream_t st_sweep = st;
-  hipStream_t st_early = pipelined ? h->stream4 : st;
-  bool early_dirty = false;                    // work queued on st_early that st has not waited for
-  auto join_early = [&]() -> int {
-    if (!early_dirty) return TRX_OK;
-    if (hipEventRecord(h->ev_join, st_early) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) return fail(h, TRX_E_HIP, "event");
-    early_dirty = false;
-    return TRX_OK;
-  };
-  const auto t_host_prep = std::chrono::steady_clock::now();
-  const bool lap_on = log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG;
-  std::string laps; auto t_lap = t_host_prep;
-  auto lap = [&](const char *what) {
-    if (!lap_on) return;
-    const auto n = std::chrono::steady_clock::now();
-    char b[64]; std::snprintf(b, sizeof b, " %s %.0f", what, 1e3 * std::chrono::duration<double, std::milli>(n - t_lap).count());
-    laps += b; t_lap = n;
-  };
-  HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep));
-  lap("h2d");
-  // With lines, every element of e the path reads is written first (the accumulation kernels
-  // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
-  // in-range line (empty list, all lines outside the band, a CIA-only run) no kernel writes
-  // e, but the optical-depth kernels still read it: it must be zero then.
-  if (dbg || eager || (h->ngroups == 0 && !h->has_grid))
-    HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st_sweep));
-  if (dbg || eager)
-    HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st_sweep));
+  if ((rc = ensure(h, h->d_in, in_bytes)) || (rc = ensure_small(h, nr)) ||
+      (rc = ensure(h, h->d_last, sizeof(int) * nsh)) || (rc = ensure(h, h->d_acc, sizeof(double) * 2 * nsh)) ||
+      (rc = ensure(h, h->d_sticky, sizeof(int) * nli)))
+    return rc;
   // the layer maxima of consecutive runs alternate between two arrays: the run's start-up pass
   // (which rides along with k_layer_max) zeroes the NEXT run's
   {
@@ -1979,7 +1940,122 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   R.kmax = h->d_kmax.as<double>() + (size_t)(h->kmax_parity ^ 1) * nr; R.nkmax = nr;
   R.status = h->d_status.as<int>(); R.flags = h->d_flags.as<int>(); R.rays = (int)std::min<int64_t>(nsh, 0x7fffffff);
   h->kmax_parity ^= 1;
-  lap("init");
+  // an error return below must not leave work of this run in flight (the next run would overwrite its inputs underneath it)
+  struct Drain {
+    trx_handle *h; bool armed = true;
+    ~Drain() { if (armed) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->stream); } }
+  } drain{h};
+  // ---- the device's first kernel, ahead of the host's prologue.  The strongest line of every layer (k_layer_max) needs
+  // -c/T and SIGCTE*ratio/(m*Z) only: they go into the pinned block first, the kernel reads them THERE (a few hundred
+  // doubles over the host link, once per block) and runs while the host computes widths, table indices, frames and ray
+  // geometry -- 12 us that used to lie in front of the device's first instruction.  The rest of the block reaches device
+  // memory by extra blocks of the next kernel (k_sticky_index, which reads its own few inputs from the pinned block too):
+  // no copy engine, no wait of a kernel for a copy's completion signal.  (Opacity-grid runs and runs without lines have
+  // no such kernels: the block is copied as before.)
+  // (the start-up pass rides along with k_layer_max only where it is small next to it: a few
+  // thousand threads striding over 10^7 rays took 20 ms at configs[4])
+  const bool ride_along = nsh <= 65536;
+  const bool early_front = !h->has_grid && h->ngroups > 0 && h->h_in_dev != nullptr;
+  bool init_done = false;
+  if (early_front) {
+    double *hin = (double *)h->h_in;
+    for (int r = 0; r < nr; r++) {
+      if (!(a->temp[r] > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
+      hin[r] = layer_negct(a->temp[r]);
+      for (int i = 0; i < h->niso; i++) hin[(size_t)nr + (size_t)r * h->niso + i] = layer_strength(h, i, a->zpart[(size_t)i * nr + r]);
+    }
+    if (!ride_along) {
+      hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
+      init_done = true;
+    }
+    LayerDev Yp{}; Yp.negc_over_t = h->h_in_dev; Yp.strength_f = h->h_in_dev + nr;
+    bool rode = false;
+    if ((rc = launch_layer_max(h, Yp, nr, a->temp, 1, nullptr, st_sweep, kmax_run, ride_along ? &R : nullptr, &rode))) return rc;
+    init_done = init_done || rode;
+    lap("max");
+  }
+
+  // ---- layer prologue (extinction.c:364-395) --------------------------------
+  LayerHost LH(h->run_f64, h->run_i32);
+  if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
+  h->walk_temp_ok = true;
+  for (int r = 0; r < nr; r++) if (a->temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
+  std::vector<double> &f64 = LH.f64;
+  const int32_t *psmax = LH.psmax;
+  // Layers per step.  The walk (narrow profiles) takes up to 64 layers, one per lane; its cost
+  // hardly depends on how many lanes are busy, so its steps are as large as the plan allows.
+  // The two-kernel form keeps a strength buffer per layer in flight: at most kMaxChunk, and
+  // 8 where the profiles are wide (a tile only learns between steps that its rays stopped).
+  // Optical depths are integrated in sub-steps of at most tau_cap layers.
+  const int tau_cap = o->solution == TRX_SOL_TRANSIT ? kTauH : kMaxChunk;
+  const int user_chunk = o->layer_chunk > 0 ? std::max(3, o->layer_chunk) : 0;
+  std::vector<double> &geom = h->run_geom, &ipv = h->run_ipv;
+  run_host_inputs(h, a, LH, vertical, gstride, mw_doubles, n_geom_all, geom, ipv);
+  if (f64.size() != n_f64 || geom.size() != n_geom || ipv.size() != n_ip || LH.i32.size() != n_i32)
+    return fail(h, TRX_E_HIP, "internal: the input block's layout");
+
+  double ms_cia = 0;
+
+  // ---- workspaces -------------------------------------------------------------
+  // Two streams: the line sweep of step c+1 (saturates the machine) runs on stream4 while the
+  // optical depth of step c (a latency chain on a few waves) is integrated on the main stream.
+  const bool pipelined = !h->has_grid;
+  bool any_wide = false;                      // some layer needs the two-kernel form
+  for (int r = 0; r < nr && !any_wide; r++) any_wide = walk_frame_bins(h, psmax, r) == 0;
+  const size_t gr_b = (size_t)std::max<int64_t>(h->ngroups, 1);
+  const int sg_layers = any_wide ? (user_chunk ? std::min(user_chunk, kMaxChunk) : kMaxChunk) : 1;
+  if ((rc = ensure(h, h->d_SG, sizeof(double) * gr_b * sg_layers)) || (rc = ensure(h, h->d_idop8, gr_b * sg_layers)) ||
+      (rc = ensure(h, h->d_e, sizeof(double) * nr * nsh)) || (rc = ensure(h, h->d_er, sizeof(double) * nr * nsh)) ||
+      (rc = ensure(h, h->d_tau, sizeof(double) * nr * nsh)) ||
+      (rc = ensure(h, h->d_intens, sizeof(double) * kMaxAngles * nsh)) || (rc = ensure(h, h->d_spec, sizeof(double) * nsh)))
+    return rc;
+  if (pipelined)
+    while ((int)h->ev_ac.size() < nr + 1) {
+      hipEvent_t e1, e2;
+      if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+      h->ev_ac.push_back(e1); h->ev_cb.push_back(e2);
+    }
+  if (count && any_wide && (rc = ensure(h, h->d_part3, 24 * (size_t)kMaxChunk * ((((size_t)((nsh + kTileBins - 1) / kTileBins) + 3) / 4) + kXcds * kAccumXcdGroup))))
+    return rc;
+  if ((rc = ensure(h, h->d_ecs, sizeof(double) * (size_t)nr * nsh))) return rc;
+  {
+    double *hin = (double *)h->h_in;
+    // (-c/T and the strength factors are in place already where the layer maxima were launched from them -- the same
+    // values: they are not written a second time under a kernel that may be reading them)
+    const size_t skip = early_front ? (size_t)nr + nli : 0;
+    std::memcpy(hin + skip, f64.data() + skip, 8 * (n_f64 - skip));
+    std::memcpy(hin + off_geom, geom.data(), 8 * n_geom);
+    std::memcpy(hin + off_ip, ipv.data(), 8 * n_ip);
+    cia_densities(h, a, hin + off_cd);
+    std::memcpy(hin + off_i32, LH.i32.data(), 4 * n_i32);
+  }
+  // the whole front end of a run goes to the stream the line sweep runs on (the main stream
+  // joins it at the first optical depth): no cross-stream hop before the first sweep kernel
+  // Streams.  The front end (inputs, layer maxima), the walks and everything that follows the
+  // LAST walk of the plan -- its combine, optical depth, the spectrum, the copies back -- sit on
+  // ONE queue: that chain is the critical path, and a hop between queues costs it ~30 us of
+  // signalling.  The combines and optical depths of the earlier steps go to a second queue, where
+  // they overlap the next step's walk.
+  hipStream_t st_early = pipelined ? h->stream4 : st;
+  bool early_dirty = false;                    // work queued on st_early that st has not waited for
+  auto join_early = [&]() -> int {
+    if (!early_dirty) return TRX_OK;
+    if (hipEventRecord(h->ev_join, st_early) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) return fail(h, TRX_E_HIP, "event");
+    early_dirty = false;
+    return TRX_OK;
+  };
+  const auto t_host_prep = std::chrono::steady_clock::now();
+  lap("prep");
+  if (!early_front) { HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->h_in, in_bytes, hipMemcpyHostToDevice, st_sweep)); lap("h2d"); }
+  // With lines, every element of e the path reads is written first (the accumulation kernels
+  // store every bin of a swept layer) and zeros only matter in the dumps.  Without any
+  // in-range line (empty list, all lines outside the band, a CIA-only run) no kernel writes
+  // e, but the optical-depth kernels still read it: it must be zero then.
+  if (dbg || eager || (h->ngroups == 0 && !h->has_grid))
+    HIPCHK(h, hipMemsetAsync(h->d_e.p, 0, sizeof(double) * nr * nsh, st_sweep));
+  if (dbg || eager)
+    HIPCHK(h, hipMemsetAsync(h->d_tau.p, 0, sizeof(double) * nr * nsh, st_sweep));
 
   const double *df = h->d_in.as<double>();
   LayerDev Y{}; const double *d_wcut; const int32_t *d_npre;
@@ -1991,7 +2067,6 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const double *d_gw = vertical ? df + off_geom : h->d_geom.as<double>(), *d_gh0 = d_gw + (size_t)(nr + 1) * gstride,
                *d_mw = d_gh0 + (nr + 1), *d_mh0 = d_mw + mw_doubles, *d_pw = d_mh0 + (nr + 1);
   const double *d_ipv = df + off_ip, *d_ciadens = df + off_cd;
-  (void)nli;
 
   // ---- opacity grid: temperature bracket and weights per layer (extinction.c:549-574) ----
   std::vector<double> og_layer; std::vector<int> og_itemp;
@@ -2012,33 +2087,29 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if ((rc = upload(h, h->d_og_layer, og_layer)) || (rc = upload(h, h->d_og_itemp, og_itemp))) return rc;
   }
 
-  // an error return below must not leave work of this run in flight on the side streams
-  // (the next run would overwrite its inputs underneath it)
-  struct Drain {
-    trx_handle *h; bool armed = true;
-    ~Drain() { if (armed) { (void)hipStreamSynchronize(h->stream4); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->stream); } }
-  } drain{h};
-  // ---- inputs are on their way.  The event marks this place of the main queue (and sends the copy off); the CIA
-  // queue waits for it when its kernels are queued -- behind the first walk's launch, not on the host's way to the
-  // device's first kernel.  (The side queue needs no wait of its own: its first work waits for an event recorded
-  // behind a walk or a sweep of this run, which is behind the inputs.)
+  // ---- the sticky Doppler index of every layer (with the block's copy into device memory riding along), or -- no early
+  // front end -- both front kernels behind the copy command.  The event marks the place of the main queue behind which
+  // the inputs are in device memory: the CIA queue waits for it when its kernels are queued (behind the first walk's
+  // launch, not on the host's way to the device's first kernel), the side queue in front of its first work of the run.
+  if (early_front) {
+    // (what k_sticky_index itself reads of the block, it reads from the pinned copy: nothing of a grid can wait for the
+    // copy blocks of the same grid)
+    const double *pf = h->h_in_dev;
+    LayerDev Yp{}; const double *p_wcut; const int32_t *p_npre;
+    layer_dev(pf, (const int32_t *)(pf + off_i32), LH, nr, Yp, p_wcut, p_npre);
+    if ((rc = launch_sticky(h, Yp, p_npre, nr, 1, nullptr, o->ethresh, st_sweep, kmax_run, h->h_in_dev, h->d_in.p, in_bytes))) return rc;
+  } else {
+    if (!ride_along) {
+      hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
+      init_done = true;
+    }
+    bool rode = false;
+    if (!h->has_grid &&
+        (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, kmax_run, ride_along ? &R : nullptr, &rode))) return rc;
+    if (!init_done && !rode)               // no line kernel to ride along with (opacity-grid mode, no in-range line)
+      hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
+  }
   HIPCHK(h, hipEventRecord(h->ev_inputs, st_sweep));
-  // strongest line and sticky Doppler index of every layer: inputs only, ahead of all steps
-  bool init_done = false;
-  // (the start-up pass rides along with k_layer_max only where it is small next to it: a few
-  // thousand threads striding over 10^7 rays took 20 ms at configs[4])
-  const bool ride_along = nsh <= 65536;
-  {
-  if (!ride_along) {
-    hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
-    init_done = true;
-  }
-  bool rode = false;
-  if (!h->has_grid &&
-      (rc = layer_maxima_and_sticky(h, Y, d_npre, nr, a->temp, 1, nullptr, o->ethresh, st_sweep, kmax_run, ride_along ? &R : nullptr, &rode))) return rc;
-  if (!init_done && !rode)               // no line kernel to ride along with (opacity-grid mode, no in-range line)
-    hipLaunchKernelGGL(k_run_init, dim3((unsigned)std::min<long long>((std::max<long long>(nsh, 3LL * nr) + 255) / 256, 65536)), dim3(256), 0, st_sweep, R);
-  }
   lap("kmax");
   // CIA extinction (device), on a second stream: only the first optical-depth kernel needs
   // e_cs, so the (latency-bound) spline kernels overlap the first sweep step.  Queued right

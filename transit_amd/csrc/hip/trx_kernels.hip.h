@@ -432,8 +432,17 @@ void k_sticky_index(LinesDev L, LayerDev Y, int niso, int r_top, int nc,
                     const double *__restrict__ e2tab,    // 2^(j/64): the same exp as the sweep => the same decisions
                     const int *__restrict__ npre,        // [layer][iso] refreshing groups
                     int *__restrict__ sticky_idop,       // [layer][iso]
-                    const int *__restrict__ flags, int eager)
+                    const int *__restrict__ flags, int eager,
+                    const uint4 *__restrict__ copy_src = nullptr, uint4 *__restrict__ copy_dst = nullptr, long long copy_n = 0, int copy_from = 0)
 {
+  // blocks copy_from ...: the run's input block from the pinned host memory the kernels of the front end read it from
+  // (Y, npre here) into device memory, where every later kernel of the run reads it -- 16 bytes per lane and trip; no
+  // copy engine, no wait of a kernel for a copy's completion signal
+  if (copy_n > 0 && (int)blockIdx.x >= copy_from) {
+    const long long stride = (long long)(gridDim.x - copy_from) * 64;
+    for (long long i = (long long)((int)blockIdx.x - copy_from) * 64 + threadIdx.x; i < copy_n; i += stride) copy_dst[i] = copy_src[i];
+    return;
+  }
   if (!sweep_active(flags, eager)) return;
   __shared__ double s_e2[64];
   s_e2[threadIdx.x] = e2tab[threadIdx.x];
