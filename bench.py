@@ -448,6 +448,31 @@ def main():
     nlayer = P.nlayer
 
     extras = {"ms_create_first_in_process": 1e3 * M["t_first_create"]}
+    if world > 1:
+        # what every rank paid, so that a SCALE line explains itself: the event-timed kernels of ITS shard (walks, combine /
+        # accumulate, optical depth), the device time of a whole run and the host's time in the call, per spectrum
+        ev_r = M["stats"]["events"]; nr_ = max(ev_r["runs"], 1)
+        mine = {"rank": rank, "bins": int(hi - lo), "ms_k_walk": ev_r["ms_k_walk"] / nr_, "ms_k_accum": ev_r["ms_k_accum"] / nr_,
+                "ms_tau": ev_r["ms_tau"] / nr_, "ms_run_device": ev_r["ms_run_total"] / nr_,
+                "ms_per_step_with_events": ev_r["ms_per_step_with_events"], "walk_steps": int(M["stats"]["walk_steps"]),
+                "layers_swept": int(M["stats"]["layers_swept"])}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        extras["per_rank"] = per_rank
+        if args.rehearse and rank == 0:
+            # the multi-rank path's contract, checked where ranks can be rehearsed: the stitched spectrum of the N-way job
+            # IS the one-GPU spectrum, bit for bit (eclipse geometry: every sum of a bin has one order, whatever the shard)
+            P1 = Problem.from_cfg(os.path.join(d, "case.cfg"))
+            st1 = P1.static
+            st1.device = local
+            e1 = Engine(st1)
+            whole = e1.run(P1.atm, P1.opts)["spectrum"]
+            e1.close()
+            same = bool(np.array_equal(whole, full))
+            extras["rehearse_stitched_equals_one_gpu_bitwise"] = same
+            if not same and args.solution == "eclipse":
+                raise SystemExit("bench --rehearse: the stitched spectrum of %d ranks differs from the one-GPU spectrum (max rel %g)"
+                                 % (world, float(np.max(np.abs(full / whole - 1.0)))))
     if world == 1:
         # a handle made in a warm process (the first create of a process also pays for loading the
         # code object and the runtime's lazy initialisation), its first -- unhinted -- spectrum

@@ -43,6 +43,10 @@ def test_bench_multirank_code_path_rehearsal():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0      # BASELINE.json's metric: the one demo split N ways
     assert out["config"]["n_wn"] == 201 and out["config"]["n_lines"] == 30000
     assert {"roofline", "metric", "unit", "ms_per_step"} <= set(out)
+    # the rehearsal's own check (bench.py exits non-zero when it fails): the two ranks' stitched spectrum is the
+    # one-GPU spectrum bit for bit; and every rank's share of the time is in the line
+    assert out["config"]["rehearse_stitched_equals_one_gpu_bitwise"] is True
+    assert [r["rank"] for r in out["config"]["per_rank"]] == [0, 1] and sum(r["bins"] for r in out["config"]["per_rank"]) == 201
 
 
 @pytest.mark.gpu
