@@ -9,18 +9,18 @@
 // (~2-3 us each right behind a walk: plan, records, layer scalars, flags).  None of that work needs
 // more than the ray's own data:
 //
-//   k_ray_tail      block = 7 rays (coarse bins) = 7 waves + the chain wave
-//     waves 0..6   lanes = layers: the plan look-ups of BOTH steps side by side, then the partial
+//   k_ray_tail      block = 10 rays (coarse bins) = 10 waves + the chain wave
+//     waves 0..9   lanes = layers: the plan look-ups of BOTH steps side by side, then the partial
 //                  records of their bin added in line order (k_walk_combine's sums) -> e (global,
 //                  for dumps and saveext), e + e_cs -> LDS; the first step's before barrier X1,
 //                  the second's while the chain wave is on its way down the first step's layers
-//     wave 7       the layers' scalars (made by the host once per run: TauArgs.lay) and the rays'
+//     wave 10      the layers' scalars (made by the host once per run: TauArgs.lay) and the rays'
 //                  carried state -> LDS; then B1, one lane per ray: the chain of bottom-point
 //                  parabolas (eclipse.c:66), the only part of an optical depth that depends on
 //                  the layer above -- ~30 fp64 instructions per layer, one wave issuing
 //     all          B2 the Simpson terms, B4 the division and the stopping test: one (layer, ray)
-//                  pair per thread; B3 (wave 7) the running sums between them
-//     waves 0..6   emission_ray (k_emission's code; lanes = heights), this run's optical depths
+//                  pair per thread; B3 (chain wave) the running sums between them
+//     waves 0..9   emission_ray (k_emission's code; lanes = heights), this run's optical depths
 //                  from LDS, the flux straight into pinned host memory;  wave 7: last, the running
 //                  sums, the run's flags -- published by the last block to arrive, into device
 //                  memory as tau_publish leaves them AND into the pinned block the host reads:
@@ -38,7 +38,9 @@
 
 namespace trx {
 
-constexpr int kTailRays = 7;                                  // rays per block: one combine / emission wave each (7 + 1 waves: two to a SIMD, two blocks to a CU)
+constexpr int kTailRays = 10;                                 // rays per block: one combine / emission wave each.  10 + 1 waves: a demo-sized run is 251 blocks, ONE per CU, each
+                                                              // alone with its latency chains -- with 7 + 1 (358 blocks, two to a CU on 102 of the 256 CUs) the spectrum took 5 us longer
+                                                              // (0.2915 -> 0.2864 ms; 12 + 1: 0.2890; round 5)
 constexpr int kTailWaves = kTailRays + 1;                     // and the wave that runs the chain of parabolas
 constexpr int kTailThreads = 64 * kTailWaves;
 constexpr int kTailSteps = 2;
@@ -117,7 +119,7 @@ __device__ __forceinline__ double tail_add_records(const TailStep &S, const Tail
 }
 
 template <int NANG, bool EXTRAS>                            // angles of the emission (8: half the state of 16; 0: slant rays and the modulation of a transit); a scattering or cloud model is on
-__global__ __launch_bounds__(kTailThreads, 4)                // (two blocks per CU: a demo-sized run is 358 blocks on 256 CUs -- one round, not two)
+__global__ __launch_bounds__(kTailThreads, 4)                // (at most 128 registers: a block's 11 waves are 3 + 3 + 3 + 2 on a CU's SIMDs)
 void k_ray_tail(TailArgs A)
 {
   const TauArgs &T = A.T;
