@@ -21,7 +21,7 @@
 //     all          B2 the Simpson terms, B4 the division and the stopping test: one (layer, ray)
 //                  pair per thread; B3 (chain wave) the running sums between them
 //     waves 0..9   emission_ray (k_emission's code; lanes = heights), this run's optical depths
-//                  from LDS, the flux straight into pinned host memory;  wave 7: last, the running
+//                  from LDS, the flux straight into pinned host memory;  chain wave: last, the running
 //                  sums, the run's flags -- published by the last block to arrive, into device
 //                  memory as tau_publish leaves them AND into the pinned block the host reads:
 //                  no copy command behind the kernel
@@ -145,7 +145,7 @@ void k_ray_tail(TailArgs A)
   const bool chain_wave = wv == kTailRays;
 
   if (!chain_wave) {
-    // ---- waves 0..6: bin w0 + wv, lanes = layers.  The plan look-ups of both steps, the first
+    // ---- the ray waves: bin w0 + wv, lanes = layers.  The plan look-ups of both steps, the first
     // step's records, and -- while the chain wave goes down the first step's layers -- the second's.
     const long long j = T.lo + w0 + wv;
     const bool have = wv < nrays && !(A.skip && A.skip[w0 + wv] >= 0);
