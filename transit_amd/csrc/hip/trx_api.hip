@@ -1165,13 +1165,16 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     if (ns == 0) { A.nseg = 1; A.seg_w0[0] = 0; A.seg_cum[0] = 0; A.seg_cum[1] = 0; }     // nothing reaches: no wave does anything
   }
   // steps of few layers with wide frames on a dense list: lanes = lines for the strengths (trx_lanes.hip.h)
-  const bool lanes = nw > 0 && !M.prof && A.tabw != nullptr && nb >= 8 && nc <= kLanesMaxLayers && h->lanes_walk &&
-                     h->max_gcount <= kLanesMaxGroup && (h->ngroups >= 8 * h->nwn || h->lanes_force);
+  const bool lanes_prod = nw > 0 && A.tabw != nullptr && nb >= 8 && nc <= kLanesMaxLayers && h->lanes_walk &&
+                          h->max_gcount <= kLanesMaxGroup && (h->ngroups >= 8 * h->nwn || h->lanes_force);
   // steps of few layers: several ranges per wave (k_line_walk_packed: an instruction serves S lines)
-  const bool packed = !lanes && nw > 0 && !M.prof && A.tabw != nullptr && nc <= h->packed_max_layers && h->packed_walk;
-  const int form = lanes ? 1 : packed ? 2 : 0;
-  if (form_out) *form_out = form;
-  h->stats.walk_form_steps[form]++; h->stats.walk_form_layers[form] += nc; h->stats.walk_form_record_lanes[form] += pl->records * nc;
+  const bool packed_prod = !lanes_prod && nw > 0 && A.tabw != nullptr && nc <= h->packed_max_layers && h->packed_walk;
+  // (a counting run -- instrumented k_line_walk for every step -- books its layers under the form the production run
+  // takes for them: its per-layer counters are what prices each form's bytes, bench.py)
+  const bool lanes = lanes_prod && !M.prof, packed = packed_prod && !M.prof;
+  const int form_prod = lanes_prod ? 1 : packed_prod ? 2 : 0, form = lanes ? 1 : packed ? 2 : 0;
+  if (form_out) *form_out = form_prod;
+  h->stats.walk_form_steps[form_prod]++; h->stats.walk_form_layers[form_prod] += nc; h->stats.walk_form_record_lanes[form_prod] += pl->records * nc;
   if (sp && sp->begin(form == 1 ? Spans::kWalkLanes : form == 2 ? Spans::kWalkPacked : Spans::kWalk, st)) return fail(h, TRX_E_HIP, "event");
   if (lanes) {
     // one range per wave (round 4 measured 2, 3, 4 ranges per wave at the demo size: 0.257 / 0.283 / 0.276 ms for the
