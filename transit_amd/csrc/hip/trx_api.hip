@@ -1186,7 +1186,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
       log_msg(TRX_LOG_DEBUG, "walk: lanes = lines, " + std::to_string(nc) + " layers, " + std::to_string(nb) + "-bin frames");
     const dim3 grid((nw + kLanesWaves - 1) / kLanesWaves), block(64 * kLanesWaves);
     const size_t lds = lanes_lds_bytes(nc, h->ndop);
-    if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 4>), grid, block, lds, st, A, X);       // (blocks of 4 groups; 5: 101.2 us, 6: 103.6 against 102.2, round 5)
+    if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 5>), grid, block, lds, st, A, X);       // (blocks of 5 groups: a batch's ~28 are 6 blocks, an even number; 4: 102.2 us, 5: 101.2, 6: 103.6, round 5)
     else         hipLaunchKernelGGL((k_line_walk_lanes<16, 4>), grid, block, lds, st, A, X);
   }
   else if (packed) {

@@ -222,6 +222,7 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     return b;
   };
   Lines cur = fetch(l0);
+  int e0_prev = -1;                                          // row of the exp(ct * base point) table that holds the last base point of the batch before (-1: none)
   __builtin_amdgcn_wave_barrier();
   // set 1 starts as an empty block IN FLIGHT (weights 0): the state every later batch begins in -- the first batch's wait
   // for its line records then leaves these loads outstanding like any other's (one wait count for the loop, not "all")
@@ -272,20 +273,27 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     const bool e0_tab = nlead <= kLanesBases;
     const int bid = __builtin_popcount(leaders & (unsigned)((2ull << t1) - 1ull)) - 1;
     if (e0_tab) {
-      unsigned lm = leaders;
-      for (int j = 0; j < nlead; j++) {
+      unsigned lm = leaders; int j = 0;
+      if (e0_prev >= 0 && !(__builtin_amdgcn_readfirstlane(meta) & 4)) {
+        // the batch's first line goes on from the base point the batch before ended on: its row of the table is that one
+        if (e0_prev != 0 && lane < ne) s_E0[lane] = s_E0[e0_prev * ne + lane];
+        lm &= lm - 1u; j = 1;
+      }
+      for (; j < nlead; j++) {
         const int tl = __builtin_ctz(lm); lm &= lm - 1u;
         const double wbj = readlane_f64(wb, tl);
         if (lane < ne) s_E0[j * ne + lane] = exp_neg(LK[lane][0] * wbj, s_e2);
       }
-    }
+      e0_prev = nlead - 1;
+    } else e0_prev = -1;
     // does some layer's Doppler index step inside this batch?  (lines descend: the last line decides)
     bool step = false;
     { const double wl = readlane_f64(wavn, n - 1); if (lane < ne) step = LK[lane][5] * wl < LK[lane][6]; }
     const bool slow = __any(step);
     __builtin_amdgcn_wave_barrier();
-    auto layer = [&](int c2, auto E0TAB, auto SLOW) {
-      const int c = min(c2 + h1, ne - 1);                   // (sets past the last layer repeat it: the same values to the same places)
+    auto layer = [&](int c2, auto E0TAB, auto SLOW, auto CLAMP) {
+      // (two sets of layers -- a full batch -- never pass the last layer, ne is even; four or eight sets do: they repeat it, the same values to the same places)
+      const int c = decltype(CLAMP)::value ? min(c2 + h1, ne - 1) : c2 + h1;
       double *K = LK[c];
       struct alignas(16) D2 { double a, b; }; struct alignas(16) I4 { int x, y, z, w; };
       const D2 k01 = *(const D2 *)(K + 0), k23 = *(const D2 *)(K + 2);
@@ -337,9 +345,10 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       s_kk[rowk + c] = kk; s_at[rowk + c] = at;
     };
     using T = std::true_type; using F = std::false_type;
-    if (slow)        for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, F{}, T{});
-    else if (e0_tab) for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, T{}, F{});
-    else             for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, F{}, F{});
+    if (slow)             for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, F{}, T{}, T{});
+    else if (!e0_tab)     for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, F{}, F{}, T{});
+    else if (nsets != 2)  for (int c2 = 0; c2 < ne; c2 += nsets) layer(c2, T{}, F{}, T{});
+    else                  for (int c2 = 0; c2 < ne; c2 += 2)     layer(c2, T{}, F{}, F{});
     __builtin_amdgcn_wave_barrier();
 
     // ---- the next batch's lines: requested here, they arrive under phase 2
