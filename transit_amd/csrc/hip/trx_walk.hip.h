@@ -586,13 +586,12 @@ void k_line_walk(WalkArgs A)
   // (every slot takes part, a slot the line does not reach with a table value of 0: adding
   // kk * 0 leaves the sum as it is, and eight unconditional multiply-adds are fewer instructions
   // than eight scalar tests around six of them)
-  float pv_p[NS]; double kk_p = 0.0; bool pend = false;    // pend: wave-uniform
+  float pv_p[NS]; double kk_p = 0.0;                       // (before the first group: weight 0 on zeros -- settle() adds nothing, and needs no "is something pending" select around its multiply-adds)
 #pragma unroll
   for (int k = 0; k < NS; k++) pv_p[k] = 0.f;
   auto settle = [&]() {
 #pragma unroll
     for (int k = 0; k < NS; k++) acc[k] = __builtin_fma(kk_p, (double)pv_p[k], acc[k]);     // :507
-    pend = false;
   };
   // Slot k reads the table at (profile centre) + d, d = (k - Rc)*osamp - imod.  The part of d that
   // does not depend on the group goes into a per-slot base pointer (wave-uniform, set up once),
@@ -666,7 +665,7 @@ void k_line_walk(WalkArgs A)
         const int ps = own ? ps_cur : ps_st;
         const unsigned vo8 = own ? vo_cur : vo_st8;
         const bool act = valid && !below;
-        if (pend) settle();
+        settle();
         // ---- move the frame down to the group's cell
         if (cell != jc) {
           int sh = jc - cell;
@@ -689,7 +688,6 @@ void k_line_walk(WalkArgs A)
         }
         // ---- bins: slot k is bin jc - Rc + k at fine distance d = (k - Rc)*osamp - imod from the line
         // (a bin outside the shard may be accumulated too: it never leaves the frame, see flush)
-        pend = true;
         if constexpr (ROWS) {
           // one row of the lane's profile holds all the frame's bins: row ph = (ps - imod) mod osamp,
           // entry kk = (ps - imod) div osamp for the centre slot -- from the profile's ps = psq*osamp + psr
@@ -721,7 +719,7 @@ void k_line_walk(WalkArgs A)
     }
     L_wavn = N_wavn; L_elow = N_elow; L_gf = N_gf; L_meta = N_meta; L_cell = N_cell;
   }
-  if (pend) settle();
+  settle();
 #pragma unroll
   for (int k = 0; k < NS; k++) flush(k, acc[k]);
   fill_zero(blo, jc - Rc - 1);
