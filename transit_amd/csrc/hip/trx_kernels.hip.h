@@ -311,6 +311,24 @@ __device__ __forceinline__ double exp_neg(double x, const double *e2tab)
   return ldexp(t * p, ki >> 6);
 }
 
+// the same with the coefficient 1/24 handed in (a vector register the caller keeps: the first step of the
+// polynomial takes two constants, and only one operand of an instruction can come from the scalar side --
+// the compiler otherwise copies 1/24 into vector registers in front of every evaluation)
+__device__ __forceinline__ double exp_neg(double x, const double *e2tab, double c24)
+{
+  const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);           // 64/ln2
+  double r = __builtin_fma(-kd, 0x1.62e42fee00000p-7, x);               // ln2/64, high 32 bits: exact product
+  r = __builtin_fma(-kd, 0x1.a39ef35793c76p-39, r);                     // ln2/64, rest
+  const int ki = (int)kd;
+  const double t = e2tab[ki & 63];
+  double p = __builtin_fma(0x1.1111111111111p-7, r, c24);               // 1/120, 1/24
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);                        // 1/6
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(t * p, ki >> 6);
+}
+
 constexpr int kSweepIsoLds = 8;          // isotopes whose per-layer scalars are staged in LDS
 
 // The lines of every isotope block that can reach the shard (SweepWindow): one flat iteration space.

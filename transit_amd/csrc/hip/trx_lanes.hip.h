@@ -221,6 +221,8 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
     Lines b; b.wavn = lp->wavn; b.elow = lp->elow; b.gf = lp->gf; b.meta = in0 ? lp->meta : 0; b.cell = lp->cell; b.wb = X.wbase[at];
     return b;
   };
+  double c24 = 0x1.5555555555555p-5;                         // 1/24, kept in a vector register (exp_neg's note, trx_kernels.hip.h)
+  asm volatile("" : "+v"(c24));
   Lines cur = fetch(l0);
   int e0_prev = -1;                                          // row of the exp(ct * base point) table that holds the last base point of the batch before (-1: none)
   __builtin_amdgcn_wave_barrier();
@@ -300,11 +302,11 @@ void k_line_walk_lanes(WalkArgs A, LanesExtra X)
       const double ct = k01.a, f = k01.b, dens = k23.a, lim = k23.b, wc = K[4];
       I4 pc = *(const I4 *)(K + 8); const I4 ps = *(const I4 *)(K + 10);
       // ---- strength of the line in layer c (k_line_walk's arithmetic: same base points, same roundings)
-      const double e1 = exp_neg(ct * elow, s_e2);
+      const double e1 = exp_neg(ct * elow, s_e2, c24);
       const double t0 = ct * wb;
       double E0;
-      if constexpr (decltype(E0TAB)::value) E0 = s_E0[bid * ne + c]; else E0 = exp_neg(t0, s_e2);
-      const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, wavn, -t0)), 1.0);
+      if constexpr (decltype(E0TAB)::value) E0 = s_E0[bid * ne + c]; else E0 = exp_neg(t0, s_e2, c24);
+      const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, wavn, -t0), c24), 1.0);
       const double s = gf * e1 * q;
       // ---- the group's sum on its anchor's lane, members in line order (extinction.c:449-462).  The second member
       // through a multiply-add with 1 or 0 (s + sh in one rounding, or s): most batches have no longer group

@@ -474,6 +474,15 @@ struct WalkArgs {
   int nseg; int seg_w0[kWalkSegs]; int seg_cum[kWalkSegs + 1];
 };
 
+__device__ __forceinline__ double exp_small(double x, double c24)       // (c24 = 1/24 from a vector register: exp_neg's note)
+{
+  double p = __builtin_fma(0x1.1111111111111p-7, x, c24);
+  p = __builtin_fma(p, x, 0x1.5555555555555p-3);   // 1/6
+  p = __builtin_fma(p, x, 0.5);
+  p = __builtin_fma(p, x, 1.0);
+  p = __builtin_fma(p, x, 1.0);
+  return p;
+}
 __device__ __forceinline__ double exp_small(double x)
 {
   double p = 0x1.1111111111111p-7;                 // 1/120
@@ -578,6 +587,8 @@ void k_line_walk(WalkArgs A)
   };
 
   double pk = 0.0;                   // strength of the group so far (0 between groups)
+  double c24 = 0x1.5555555555555p-5;                       // 1/24, kept in a vector register (exp_neg's note)
+  asm volatile("" : "+v"(c24));
   int cell = jc, imod = 0;
   unsigned cand = 0u;                // slots of the frame (once it sits on the group's cell) that some
                                      // layer of this step can reach from the current group; 0: skip it
@@ -620,7 +631,7 @@ void k_line_walk(WalkArgs A)
     const int N_meta = ((ScalarI32)rp)[6], N_cell = ((ScalarI32)rp)[7];
     if (L_meta & 4) {                                      // base point of the rebased exponential
       const double t0 = ct * L_wavn;
-      E0 = exp_neg(t0, s_e2); c0 = -t0;
+      E0 = exp_neg(t0, s_e2, c24); c0 = -t0;
     }
     if (L_meta & 1) {
       // slots some layer of this step can reach from this group: |(k - Rc)*osamp - imod| <= psm_s
@@ -639,8 +650,8 @@ void k_line_walk(WalkArgs A)
     }
     if (cand) {
       // ---- strength of the line in every layer
-      const double e1 = exp_neg(ct * L_elow, s_e2);
-      const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, L_wavn, c0)), 1.0);
+      const double e1 = exp_neg(ct * L_elow, s_e2, c24);
+      const double q = __builtin_fma(-E0, exp_small(__builtin_fma(ct, L_wavn, c0), c24), 1.0);
       pk += L_gf * e1 * q;
       if (L_meta & 2) {
         // ---- the group is complete: threshold, density, profile, bins (extinction.c:464-509)
