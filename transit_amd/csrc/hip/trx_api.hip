@@ -1187,7 +1187,7 @@ int walk_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, int nb, i
     const dim3 grid((nw + kLanesWaves - 1) / kLanesWaves), block(64 * kLanesWaves);
     const size_t lds = lanes_lds_bytes(nc, h->ndop);
     if (nb == 8) hipLaunchKernelGGL((k_line_walk_lanes<8, 5>), grid, block, lds, st, A, X);       // (blocks of 5 groups: a batch's ~28 are 6 blocks, an even number; 4: 102.2 us, 5: 101.2, 6: 103.6, round 5)
-    else         hipLaunchKernelGGL((k_line_walk_lanes<16, 4>), grid, block, lds, st, A, X);
+    else         hipLaunchKernelGGL((k_line_walk_lanes<16, 2>), grid, block, lds, st, A, X);      // (blocks of 2 groups -- 8 floats per group and lane, 112 registers: 169.5 us; 3 / 4: 130 / 150 registers, 171.0 / 172.6, round 5)
   }
   else if (packed) {
     const int S = 64 / nc;
