@@ -78,6 +78,10 @@ struct trx_handle {
   // Voigt table
   int ndop = 0, nlor = 0;
   std::vector<double> adop, alor;                   // +1 sentinel
+  std::vector<int32_t> psizeT; bool psize_mono = false;   // psize as [nlor][ndop] (prep_layers); no profile narrower than the one a Doppler index below it
+  std::vector<double> dopthr;                       // steps of the nearest-index function on adop (build_table; dop_index)
+  std::vector<double> iso_sqrtm;                    // sqrt(iso_mass)
+  std::vector<double> dens_over_m;                  // [nmol] scratch of prep_layers
   std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
   DevBuf d_adop, d_dopthr, d_e2tab, d_psize, d_poff, d_tab, d_tabT, d_poffT, d_gimod, d_gidiv;
   // both tables carry kTabPad zero floats in front and behind: k_accumulate_wide reads whole
@@ -346,6 +350,13 @@ int build_table(trx_handle *h, const trx_static *s)
         return fail(h, TRX_E_ARG, "Doppler-width grid is not strictly increasing");
     }
     if ((rc = upload(h, h->d_dopthr, thr))) return rc;
+    h->dopthr = thr;
+    h->psizeT.resize((size_t)nd * h->nlor); h->psize_mono = true;
+    for (int d = 0; d < nd; d++)
+      for (int l = 0; l < h->nlor; l++) {
+        h->psizeT[(size_t)l * nd + d] = h->psize[(size_t)d * h->nlor + l];
+        if (d > 0 && h->psize[(size_t)d * h->nlor + l] < h->psize[(size_t)(d - 1) * h->nlor + l]) h->psize_mono = false;
+      }
     std::vector<double> e2(64);                       // 2^(j/64) for exp_neg (kernels)
     for (int j = 0; j < 64; j++) e2[j] = (double)exp2l((long double)j / 64.0L);
     if ((rc = upload(h, h->d_e2tab, e2))) return rc;
@@ -887,6 +898,21 @@ struct LayerHost {
 inline double layer_negct(double temp) { return -kExpCte * kTliEfct / temp; }
 inline double layer_strength(const trx_handle *h, int i, double z) { return kSigCte * h->iso_ratio[i] / (h->iso_mass[i] * z); }
 
+// nearest_index(adop, v, 0, ndop) by its exact steps (build_table), walked from a nearby index: the Doppler indices
+// one (layer, isotope) pair asks for lie a few steps apart, and a bisection each was most of prep_layers' time.
+inline int dop_index(const trx_handle *h, double v, int from)
+{
+  const double *thr = h->dopthr.data();      // thr[0] = -inf, thr[ndop] = +inf
+  while (from + 1 < h->ndop && v >= thr[from + 1]) from++;
+  while (v < thr[from]) from--;
+  return from;
+}
+inline int dop_index_far(const trx_handle *h, double v)
+{
+  const double *thr = h->dopthr.data();
+  return (int)(std::upper_bound(thr + 1, thr + h->ndop, v) - thr) - 1;      // (thr[1 .. ndop-1] <= v, counted)
+}
+
 int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *density /* [nmol][nr] */,
                 const double *zpart /* [niso][nr] */, size_t extra_doubles, LayerHost &LH)
 {
@@ -899,34 +925,45 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
          *alphal = alphad + nli, *wcut = alphal + nli;
   int32_t *idop0 = &LH.i32[0], *ilor = idop0 + nli, *psmax = ilor + nli, *npre = psmax + nli;
   LH.psmax = psmax;
+  h->dens_over_m.resize(nmol);
+  double *dm = h->dens_over_m.data();
+  int dguess = 0;
   for (int r = 0; r < nr; r++) {
     const double temp = temp_k[r];
     if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
     negct[r] = layer_negct(temp);
     const double fdoppler = std::sqrt(2 * kKb * temp / kAmu) * kSqrtLn2 / kLs;
     const double florentz = std::sqrt(2 * kKb * temp / kPi / kAmu) / (kAmu * kLs);
+    for (int j = 0; j < nmol; j++) dm[j] = density[(size_t)j * nr + r] / h->mol_mass[j];      // (the first factor of the sum's terms, for every isotope)
     for (int i = 0; i < niso; i++) {
       double al = 0.0;
       const double *csd_i = &h->pair_csd[(size_t)i * nmol], *sq_i = &h->pair_sqrt[(size_t)i * nmol];
       for (int j = 0; j < nmol; j++)       // (the collision diameter and the reduced-mass root of the pair: constants of the handle)
-        al += density[(size_t)j * nr + r] / h->mol_mass[j] * csd_i[j] * csd_i[j] * sq_i[j];
+        al += dm[j] * csd_i[j] * csd_i[j] * sq_i[j];
       al *= florentz;
-      const double ad = fdoppler / std::sqrt(h->iso_mass[i]);
+      const double ad = fdoppler / h->iso_sqrtm[i];
       const size_t k = (size_t)r * niso + i;
       alphal[k] = al; alphad[k] = ad;
-      idop0[k] = nearest_index(h->adop.data(), ad * h->wn_i, 0, h->ndop);
+      idop0[k] = dguess = dop_index(h, ad * h->wn_i, dguess);
       ilor[k]  = nearest_index(h->alor.data(), al, 0, h->nlor);
       strength[k] = layer_strength(h, i, zpart[(size_t)i * nr + r]);
       dens[k] = density[(size_t)h->iso_imol[i] * nr + r];
       wcut[k] = doppler_refresh_cut(ad, al);
-      int dlo = idop0[k], dhi = idop0[k];
-      if (h->iso_wmax[i] > 0) {
-        const int a0 = nearest_index(h->adop.data(), ad * h->iso_wmin[i], 0, h->ndop);
-        const int a1 = nearest_index(h->adop.data(), ad * h->iso_wmax[i], 0, h->ndop);
-        dlo = std::min(dlo, std::min(a0, a1)); dhi = std::max(dhi, std::max(a0, a1));
-      }
-      int32_t pm = 0;
-      for (int d = dlo; d <= dhi; d++) pm = std::max(pm, h->psize[(size_t)d * h->nlor + ilor[k]]);
+      // (Doppler indices at the ends of the isotope's lines, and the widest profile between two indices: asked for
+      // several times per pair -- each index is looked up once, and on a table whose profiles widen with the Doppler
+      // width, the usual case, the widest of a range is its last)
+      const bool has_lines = h->iso_wmax[i] > 0;
+      const int a0 = has_lines ? dop_index_far(h, ad * h->iso_wmin[i]) : idop0[k];
+      const int a1 = has_lines ? dop_index_far(h, ad * h->iso_wmax[i]) : idop0[k];
+      const int32_t *psl = &h->psizeT[(size_t)ilor[k] * h->ndop];
+      auto widest_of = [&](int i0, int i1) {
+        if (i0 > i1) std::swap(i0, i1);
+        if (h->psize_mono) return psl[i1];
+        int32_t m = 0;
+        for (int d = i0; d <= i1; d++) m = std::max(m, psl[d]);
+        return m;
+      };
+      int32_t pm = widest_of(std::min(idop0[k], std::min(a0, a1)), std::max(idop0[k], std::max(a0, a1)));
       // The bound is then tightened to the Doppler indices a line of this isotope can actually TAKE in
       // this layer, among the lines that can reach this handle's bins (all of the block, or -- a
       // shard -- those within the reach of the widest profile, pm, a cell to spare):
@@ -936,7 +973,7 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       // Doppler widths grow with the wavenumber: on a band that spans a factor of ten the widest
       // profile of the list is several times the widest one a low-wavenumber shard meets, and in the
       // deep layers (no anchor reaches wcut) every line takes the ONE profile of the index at wn_i.
-      if (h->shard_frames && h->iso_wmax[i] > 0) {
+      if (h->shard_frames && has_lines) {
         double lo_w = h->iso_wmin[i], hi_w = h->iso_wmax[i];
         if (h->windowed()) {
           const double reach = ((double)pm + h->osamp) * (h->wn_d / h->osamp) + h->wn_d;
@@ -944,18 +981,17 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
           hi_w = std::min(hi_w, h->wn_i + (double)(h->hi - 1) * h->wn_d + reach);
         }
         const double wc = wcut[k];
-        auto widest = [&](double wa, double wb) {
-          const int i0 = nearest_index(h->adop.data(), ad * wa, 0, h->ndop), i1 = nearest_index(h->adop.data(), ad * wb, 0, h->ndop);
-          int32_t m = 0;
-          for (int d = std::min(i0, i1); d <= std::max(i0, i1); d++) m = std::max(m, h->psize[(size_t)d * h->nlor + ilor[k]]);
-          return m;
-        };
+        auto didx = [&](double w) { return w == h->iso_wmin[i] ? a0 : w == h->iso_wmax[i] ? a1 : dop_index_far(h, ad * w); };
+        auto widest = [&](double wa, double wb) { return widest_of(didx(wa), didx(wb)); };
         int32_t pw = 0;
         if (lo_w <= hi_w) {
-          if (hi_w >= wc) pw = std::max(pw, widest(std::max(lo_w, wc), hi_w));                 // own indices of the lines in reach
+          const double own_lo = std::max(lo_w, wc), all_lo = std::max(h->iso_wmin[i], wc);
+          int32_t w_own = -1;
+          if (hi_w >= wc) pw = std::max(pw, w_own = widest(own_lo, hi_w));                      // own indices of the lines in reach
           if (lo_w < wc) {                                                                       // some line in reach takes the sticky index
-            pw = std::max(pw, h->psize[(size_t)idop0[k] * h->nlor + ilor[k]]);
-            if (h->iso_wmax[i] >= wc) pw = std::max(pw, widest(std::max(h->iso_wmin[i], wc), h->iso_wmax[i]));
+            pw = std::max(pw, psl[idop0[k]]);
+            if (h->iso_wmax[i] >= wc)
+              pw = std::max(pw, w_own >= 0 && own_lo == all_lo && hi_w == h->iso_wmax[i] ? w_own : widest(all_lo, h->iso_wmax[i]));
           }
         }
         pm = std::min(pm, pw);
@@ -1585,6 +1621,8 @@ int trx_create(const trx_static *s, trx_handle **out)
   h->comm = s->comm; h->nranks = s->comm ? std::max(1, s->nranks) : 1; h->rank = s->rank;
   if (h->comm && !rccl().ok()) return bail(TRX_E_UNSUPPORTED);
   h->iso_mass.assign(s->iso_mass, s->iso_mass + s->niso);
+  h->iso_sqrtm.resize(s->niso);
+  for (int i = 0; i < s->niso; i++) h->iso_sqrtm[i] = std::sqrt(h->iso_mass[i]);
   h->iso_ratio.assign(s->iso_ratio, s->iso_ratio + s->niso);
   h->iso_imol.assign(s->iso_imol, s->iso_imol + s->niso);
   h->mol_mass.assign(s->mol_mass, s->mol_mass + s->nmol);
