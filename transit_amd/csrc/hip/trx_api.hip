@@ -146,6 +146,8 @@ struct trx_handle {
   int hint_layers = 0;       // layers the previous run needed (deepest toomuch crossing + 1)
   DevBuf d_e_saved; std::vector<uint8_t> saved;          // trx_restore_extinction: [nlayer][nsh] and the flags (empty: none)
   void *h_spec = nullptr; size_t h_spec_bytes = 0;     // pinned staging of the spectrum (trx_run hands over pageable memory)
+  void *h_spec_dev = nullptr, *h_small_dev = nullptr;  // the device's addresses of the pinned blocks (asked for once per allocation, not per run)
+  void *h_tailblk = nullptr, *h_tailblk_dev = nullptr; size_t h_tailblk_bytes = 0;   // pinned: what each block of k_ray_tail adds to the run's flags (vertical rays: the host adds them up)
 };
 
 namespace {
@@ -204,6 +206,7 @@ int ensure_small(trx_handle *h, int nlay)
     h->h_small = nullptr; h->h_small_bytes = 0;
     HIPCHK(h, hipHostMalloc(&h->h_small, bytes, hipHostMallocDefault));
     h->h_small_bytes = bytes;
+    HIPCHK(h, hipHostGetDevicePointer(&h->h_small_dev, h->h_small, 0));
   }
   return TRX_OK;
 }
@@ -1710,6 +1713,7 @@ void trx_destroy(trx_handle *h)
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_in) (void)hipHostFree(h->h_in);
   if (h->h_spec) (void)hipHostFree(h->h_spec);
+  if (h->h_tailblk) (void)hipHostFree(h->h_tailblk);
   delete h;
 }
 
@@ -2365,7 +2369,23 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     h->h_spec = nullptr; h->h_spec_bytes = 0;
     HIPCHK(h, hipHostMalloc(&h->h_spec, sizeof(double) * (size_t)nsh, hipHostMallocDefault));
     h->h_spec_bytes = sizeof(double) * (size_t)nsh;
+    HIPCHK(h, hipHostGetDevicePointer(&h->h_spec_dev, h->h_spec, 0));
   }
+  // Vertical rays: what the blocks of the tail add to the run's flags -- rays still open, deepest layer reached -- goes
+  // into a pinned array, one entry per block, and the HOST adds it up behind the kernel.  The device-side sum was three
+  // dependent device-scope atomics per block and, for the last block to arrive, four more round trips and a system-scope
+  // fence: the kernel's last wave ended 5 us behind its last emission.  (Slant rays keep the device-side sum: their
+  // modulation can raise the run's status.)
+  const size_t tail_blocks = (size_t)((nsh + kTailRays - 1) / kTailRays);
+  const bool tail_hostsum = tail_direct && vertical;
+  if (tail_hostsum && h->h_tailblk_bytes < 8 * tail_blocks) {
+    if (h->h_tailblk) (void)hipHostFree(h->h_tailblk);
+    h->h_tailblk = nullptr; h->h_tailblk_bytes = 0;
+    HIPCHK(h, hipHostMalloc(&h->h_tailblk, 8 * tail_blocks, hipHostMallocDefault));
+    h->h_tailblk_bytes = 8 * tail_blocks;
+    HIPCHK(h, hipHostGetDevicePointer(&h->h_tailblk_dev, h->h_tailblk, 0));
+  }
+  int tail_nct = 0;
   for (;;) {
   {
   for (; r_top >= 0; ) {
@@ -2463,9 +2483,10 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     tau_args(TA.T, nr - 1, nct);
     if (vertical) emis_args(TA.E); else mod_args(TA.M);
     if (tail_direct) {              // spectrum and flags straight into pinned host memory: no copy commands behind the kernel
-      void *dp = nullptr;
-      if (tail_spec) { HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0)); (vertical ? TA.E.flux : TA.M.out) = (double *)dp; }
-      HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_small, 0)); TA.host_flags = (int *)dp;
+      if (tail_spec) (vertical ? TA.E.flux : TA.M.out) = (double *)h->h_spec_dev;
+      TA.host_flags = (int *)h->h_small_dev;
+      if (tail_hostsum) TA.host_blocks = (int *)h->h_tailblk_dev;
+      tail_nct = nct;
     }
     // Every address the tail reads or writes, checked on the host before the launch: a null or stale one
     // here is a wild access of a whole grid (round 3's one memory fault -- a work-in-progress tail storing
@@ -2475,7 +2496,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
                 TA.T.ecs && TA.T.er && TA.T.tau && TA.T.last && TA.T.flags && TA.T.status && TA.T.rad &&
                 (vertical ? (TA.T.acc && TA.T.lay && TA.T.gw && TA.E.flux && TA.E.intens && TA.E.temp && TA.E.e2tab)
                           : (TA.T.hrs && TA.T.hr0 && TA.T.gw && TA.M.out && TA.M.ip && TA.M.gw && TA.M.gh0 && TA.M.status)) &&
-                (!extras_on || (TA.T.xf_scat && TA.T.xf_cloud)) && (!tail_direct || TA.host_flags);
+                (!extras_on || (TA.T.xf_scat && TA.T.xf_cloud)) && (!tail_direct || TA.host_flags) && (!tail_hostsum || TA.host_blocks);
       for (int k = 0; k < TA.nsteps && ok; k++)
         ok = TA.S[k].part && TA.S[k].nc >= 1 && TA.S[k].nc <= kWalkLayers && TA.S[k].P.blo && TA.S[k].P.bhi && TA.S[k].P.off && TA.S[k].P.wbase;
       if (!ok) return fail(h, TRX_E_HIP, "internal: incomplete arguments for the ray tail (not launched)");
@@ -2524,6 +2545,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     const bool staged = tail_spec && spectrum && !resumed;       // the tail stored the spectrum into the handle's pinned buffer
     HIPCHK(h, hipStreamSynchronize(st));
     if (staged) std::memcpy(spectrum, h->h_spec, sizeof(double) * (size_t)nsh);
+    if (tail_hostsum && !resumed) {
+      // the flags as tau_publish leaves them after the plan's last step (all of them zero but the rays' number
+      // when the tail started: it covers the run from its first layer), from the blocks' entries
+      const int32_t *tb = (const int32_t *)h->h_tailblk;
+      int still = 0, deep = 0;
+      for (size_t b = 0; b < tail_blocks; b++) { still += tb[2 * b]; deep = std::max(deep, tb[2 * b + 1]); }
+      const int f[8] = {still, 0, tail_nct, 0, deep, 0, 0, 0};
+      std::memcpy(h->h_small, f, sizeof f);
+      std::memset((char *)h->h_small + 64, 0, 16);             // (vertical rays raise no status)
+    }
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));
     std::memcpy(status_host, (const char *)h->h_small + 64, sizeof(status_host));
     if (count) std::memcpy(counters.data(), (const char *)h->h_small + 128, 24 * (size_t)nr);
@@ -2531,6 +2562,8 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
   // rays still descending below the expected depth (the atmosphere changed): go on from there
   if (stop_at_hint && flags_host[0] > 0 && r_top >= 0) {
+    // (the step kernels that go on from here read the flags on the device: where the host has added them up, they go there first)
+    if (tail_hostsum && !resumed) HIPCHK(h, hipMemcpyAsync(h->d_flags.p, h->h_small, 32, hipMemcpyHostToDevice, st));
     stop_at_hint = false; resumed = true; h->hint_layers = 0; continue;
   }
   break;

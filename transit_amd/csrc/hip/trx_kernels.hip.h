@@ -78,10 +78,28 @@ __device__ __forceinline__ double lane_xor4(double v)
   hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xF, 0xA, false);
   return __hiloint2double(hi, lo);
 }
+// v[lane] + v[lane ^ 32] and v[lane] + v[lane ^ 16] in every lane without the LDS pipe: gfx950's v_permlane32_swap
+// exchanges the upper half of one register with the lower half of another (v_permlane16_swap: the odd rows of 16
+// with the even ones) -- two copies of v go in, (lower halves twice, upper halves twice) come out, and their sum is
+// the butterfly step.  (The upper lanes add their partner FIRST: the same bits, the addition commutes.)
+__device__ __forceinline__ double swap_sum32(double v)
+{
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double swap_sum16(double v)
+{
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
+  v = swap_sum32(v);           // lane ^ 32
+  v = swap_sum16(v);           // lane ^ 16
   v += dpp_f64<0x128>(v);      // row_ror:8 = lane ^ 8
   v += lane_xor4(v);
   v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]: lane ^ 2
@@ -1739,17 +1757,75 @@ __device__ __forceinline__ double planck_from(double num, double x, const double
 // exponentials: 38 us of pure latency at the end of every spectrum.)
 constexpr int kEmisWaves = 4;
 
-// one ray by one wavefront; tau_at(i): optical depth at height i of this ray; s_e2: 2^(j/64) in LDS
-// (NANG: the angles the instantiation holds state for -- 16 of them are 96 registers)
-template <int NANG = kMaxAngles, class TauAt>
-__device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
+// 2 h nu^3 c^2 of the Planck function (the cube as two products: the library's general power was 450 instructions
+// at the head of every ray's emission)
+__device__ __forceinline__ double planck_num(double wv) { return 2.0 * kH * (wv * wv * wv) * kLs * kLs; }
+
+// One ray by one wavefront; tau_at(i): optical depth at height i of this ray; s_e2: 2^(j/64) in LDS.
+// A lane adds the trapezoid terms of its heights (one per pass of 64) for itself; ONE butterfly sum per angle
+// behind the last pass.
+//
+// emission_ray_exact<N>: exactly N angles, every one with a checked reciprocal of its cosine -- no branch per angle
+// (the angles' chains of exponentials are issued side by side), no test of a lane's height inside the angle loop (a
+// lane past the ray's end computes exp(-0) and multiplies it with a zero weight).
+template <int N, class TauAt>
+__device__ __forceinline__ void emission_ray_exact(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
 {
   const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
-  const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
+  const double pl_num = planck_num(wv);
   const double pl_exp = kH * wv * kLs;
-  double sum[NANG], dt_c[NANG], dt_last[NANG];
+  double acc[N], dt[N], dt_c[N];
 #pragma unroll
-  for (int a = 0; a < NANG; a++) { sum[a] = 0.0; dt_c[a] = 0.0; dt_last[a] = 0.0; }
+  for (int a = 0; a < N; a++) { acc[a] = 0.0; dt[a] = 0.0; dt_c[a] = 0.0; }
+  double B = 0.0, B_c = 0.0;                  // B_c, dt_c: the previous pass's last height (wave-uniform)
+  int top = 0;
+  for (int i0 = 0; i0 <= last; i0 += 64) {
+    const int i = i0 + lane;
+    const bool have = i <= last;
+    double tv = 0.0;
+    B = 0.0;
+    if (have) {
+      tv = tau_at(i);
+      B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
+    }
+    double Bp = dpp_f64<0x138>(B);              // wave_shr:1 -- the lane before (lane 0: the carry)
+    if (lane == 0) Bp = B_c;
+    const double Bs = (have && i > 0) ? B + Bp : 0.0;
+    const double ntv = -tv;
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+      const double d = exp_neg(quotient_rn(ntv, E.cosang[a], E.rcos[a]), s_e2);
+      double dp = dpp_f64<0x138>(d);
+      if (lane == 0) dp = dt_c[a];
+      acc[a] += (d - dp) * Bs;
+      dt_c[a] = readlane_f64(d, 63);
+      dt[a] = d;
+    }
+    B_c = readlane_f64(B, 63);
+    top = min(63, last - i0);                   // lane of the ray's last height
+  }
+  const double B_last = readlane_f64(B, top);
+  double fl = 0.0;
+#pragma unroll
+  for (int a = 0; a < N; a++) {
+    const double I = B_last * readlane_f64(dt[a], top) - 0.5 * wave_sum(acc[a]);
+    if (lane == a) E.intens[(long long)a * E.nsh + w] = I;
+    fl += kPi * I * E.area[a];
+  }
+  if (lane == 0) E.flux[w] = fl;
+}
+
+// Any number of angles up to NMAX, a division where an angle has no checked reciprocal: the same terms and sums,
+// angle after angle.
+template <int NMAX, class TauAt>
+__device__ __forceinline__ void emission_ray_any(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
+{
+  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
+  const double pl_num = planck_num(wv);
+  const double pl_exp = kH * wv * kLs;
+  double acc[NMAX], dt_c[NMAX], dt_last[NMAX];
+#pragma unroll
+  for (int a = 0; a < NMAX; a++) { acc[a] = 0.0; dt_c[a] = 0.0; dt_last[a] = 0.0; }
   double B_c = 0.0, B_last = 0.0;             // carry: the previous pass's last height
   for (int i0 = 0; i0 <= last; i0 += 64) {
     const int i = i0 + lane;
@@ -1761,33 +1837,56 @@ __device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int
     }
     double Bp = dpp_f64<0x138>(B);              // wave_shr:1 -- the lane before (lane 0: set below)
     if (lane == 0) Bp = B_c;
+    const double Bs = (have && i > 0) ? B + Bp : 0.0;
     const int top = min(63, last - i0);        // lane of the pass's last height
 #pragma unroll
-    for (int a = 0; a < NANG; a++) {
+    for (int a = 0; a < NMAX; a++) {
       if (a < E.nang) {
-        const double dt = have ? exp_neg(slant_depth(E, a, tv), s_e2) : 0.0;
-        double dtp = dpp_f64<0x138>(dt);
-        if (lane == 0) dtp = dt_c[a];
-        const double term = (have && i > 0) ? (dt - dtp) * (B + Bp) : 0.0;
-        sum[a] += wave_sum(term);
-        dt_c[a] = readlane_f64(dt, 63);
-        dt_last[a] = readlane_f64(dt, top);
+        const double d = exp_neg(slant_depth(E, a, tv), s_e2);
+        double dp = dpp_f64<0x138>(d);
+        if (lane == 0) dp = dt_c[a];
+        acc[a] += (d - dp) * Bs;
+        dt_c[a] = readlane_f64(d, 63);
+        dt_last[a] = readlane_f64(d, top);
       }
     }
     B_c = readlane_f64(B, 63);
     B_last = readlane_f64(B, top);
   }
-  // sum, B_last and dt_last are wave-uniform: lane a writes angle a, lane 0 the flux in angle order
+  // B_last and dt_last are wave-uniform: lane a writes angle a, lane 0 the flux in angle order
   double fl = 0.0;
 #pragma unroll
-  for (int a = 0; a < NANG; a++) {
+  for (int a = 0; a < NMAX; a++) {
     if (a < E.nang) {
-      const double I = B_last * dt_last[a] - 0.5 * sum[a];
+      const double I = B_last * dt_last[a] - 0.5 * wave_sum(acc[a]);
       if (lane == a) E.intens[(long long)a * E.nsh + w] = I;
       fl += kPi * I * E.area[a];
     }
   }
   if (lane == 0) E.flux[w] = fl;
+}
+
+// (NMAX: the angles the general form holds state for -- 16 of them are 96 registers)
+template <int NMAX = kMaxAngles, class TauAt>
+__device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
+{
+  bool recip = E.nang <= 8;
+#pragma unroll
+  for (int a = 0; a < 8; a++) if (a < E.nang && E.rcos[a] == 0.0) recip = false;      // (wave-uniform: kernel arguments)
+  if (recip) {
+    switch (E.nang) {
+      case 1: return emission_ray_exact<1>(E, w, last, lane, s_e2, tau_at);
+      case 2: return emission_ray_exact<2>(E, w, last, lane, s_e2, tau_at);
+      case 3: return emission_ray_exact<3>(E, w, last, lane, s_e2, tau_at);
+      case 4: return emission_ray_exact<4>(E, w, last, lane, s_e2, tau_at);
+      case 5: return emission_ray_exact<5>(E, w, last, lane, s_e2, tau_at);
+      case 6: return emission_ray_exact<6>(E, w, last, lane, s_e2, tau_at);
+      case 7: return emission_ray_exact<7>(E, w, last, lane, s_e2, tau_at);
+      case 8: return emission_ray_exact<8>(E, w, last, lane, s_e2, tau_at);
+      default: break;
+    }
+  }
+  emission_ray_any<NMAX>(E, w, last, lane, s_e2, tau_at);
 }
 
 __global__ __launch_bounds__(64 * kEmisWaves)
@@ -1821,7 +1920,7 @@ void k_emission_rows(EmisArgs E)
   if (w >= E.nsh) return;
   const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
   const int last = E.last[w];                  // (< 0: the ray is still descending -- provisional spectrum, zero)
-  const double pl_num = 2.0 * kH * pow(wv, 3.0) * kLs * kLs;
+  const double pl_num = planck_num(wv);
   const double pl_exp = kH * wv * kLs;
   double sum[kMaxAngles], dtp[kMaxAngles];
 #pragma unroll

@@ -55,6 +55,7 @@ struct TailArgs {
   double *e;                                                  // [nr][nsh]
   const int *skip;                                            // null, or the rays' `last`: a closed ray's bins are not combined (zero)
   int *host_flags;                                            // null, or pinned host memory: the run's flags [0..7] and status [16..19] land there too (no copy command behind the kernel)
+  int *host_blocks;                                           // null, or pinned host memory [blocks][2]: (rays still open, deepest layer + 1) of each block -- the host adds them up, nothing is published on the device (vertical rays)
   TauArgs T;                                                  // r_top: the first step's; nc: all layers of the plan
   EmisArgs E;                                                 // eclipse geometry (NANG > 0)
   ModArgs M;                                                  // transit geometry (NANG == 0)
@@ -415,7 +416,10 @@ void k_ray_tail(TailArgs A)
       }
     }
   };
-  if (!SLANT && chain_wave && lane == 0) publish();
+  if (!SLANT && chain_wave && lane == 0) {
+    if (A.host_blocks) *(int2 *)(A.host_blocks + 2 * (long long)blockIdx.x) = make_int2(pub_still, pub_deep);
+    else publish();
+  }
   if (!chain_wave && wv < nrays) {
     const long long w = w0 + wv;
     int last, done; bool still;
