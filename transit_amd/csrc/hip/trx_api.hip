@@ -2374,15 +2374,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // Vertical rays: what the blocks of the tail add to the run's flags -- rays still open, deepest layer reached -- goes
   // into a pinned array, one entry per block, and the HOST adds it up behind the kernel.  The device-side sum was three
   // dependent device-scope atomics per block and, for the last block to arrive, four more round trips and a system-scope
-  // fence: the kernel's last wave ended 5 us behind its last emission.  (Slant rays keep the device-side sum: their
-  // modulation can raise the run's status.)
+  // fence: the kernel's last wave ended 5 us behind its last emission -- and every one of those fences writes back and
+  // invalidates the L2 under the emission waves (8 us of emission with them, 3 without).  The run's status (slant
+  // rays: what the reference exits on) goes into four slots behind the blocks' entries, one per code.
   const size_t tail_blocks = (size_t)((nsh + kTailRays - 1) / kTailRays);
-  const bool tail_hostsum = tail_direct && vertical;
-  if (tail_hostsum && h->h_tailblk_bytes < 8 * tail_blocks) {
+  const bool tail_hostsum = tail_direct;
+  if (tail_hostsum && h->h_tailblk_bytes < 8 * tail_blocks + 16) {
     if (h->h_tailblk) (void)hipHostFree(h->h_tailblk);
     h->h_tailblk = nullptr; h->h_tailblk_bytes = 0;
-    HIPCHK(h, hipHostMalloc(&h->h_tailblk, 8 * tail_blocks, hipHostMallocDefault));
-    h->h_tailblk_bytes = 8 * tail_blocks;
+    HIPCHK(h, hipHostMalloc(&h->h_tailblk, 8 * tail_blocks + 16, hipHostMallocDefault));
+    h->h_tailblk_bytes = 8 * tail_blocks + 16;
     HIPCHK(h, hipHostGetDevicePointer(&h->h_tailblk_dev, h->h_tailblk, 0));
   }
   int tail_nct = 0;
@@ -2485,7 +2486,11 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     if (tail_direct) {              // spectrum and flags straight into pinned host memory: no copy commands behind the kernel
       if (tail_spec) (vertical ? TA.E.flux : TA.M.out) = (double *)h->h_spec_dev;
       TA.host_flags = (int *)h->h_small_dev;
-      if (tail_hostsum) TA.host_blocks = (int *)h->h_tailblk_dev;
+      if (tail_hostsum) {
+        TA.host_blocks = (int *)h->h_tailblk_dev;
+        std::memset((char *)h->h_tailblk + 8 * tail_blocks, 0, 16);
+        if (!vertical) TA.M.status_slots = TA.host_blocks + 2 * tail_blocks;
+      }
       tail_nct = nct;
     }
     // Every address the tail reads or writes, checked on the host before the launch: a null or stale one
@@ -2553,7 +2558,9 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       for (size_t b = 0; b < tail_blocks; b++) { still += tb[2 * b]; deep = std::max(deep, tb[2 * b + 1]); }
       const int f[8] = {still, 0, tail_nct, 0, deep, 0, 0, 0};
       std::memcpy(h->h_small, f, sizeof f);
-      std::memset((char *)h->h_small + 64, 0, 16);             // (vertical rays raise no status)
+      int st4[4] = {0, 0, 0, 0};
+      for (int code = 1; code < 4; code++) if (tb[2 * tail_blocks + code]) st4[0] = code;      // (vertical rays raise none)
+      std::memcpy((char *)h->h_small + 64, st4, 16);
     }
     std::memcpy(flags_host, h->h_small, sizeof(flags_host));
     std::memcpy(status_host, (const char *)h->h_small + 64, sizeof(status_host));

@@ -1768,12 +1768,9 @@ __device__ __forceinline__ double planck_num(double wv) { return 2.0 * kH * (wv 
 // emission_ray_exact<N>: exactly N angles, every one with a checked reciprocal of its cosine -- no branch per angle
 // (the angles' chains of exponentials are issued side by side), no test of a lane's height inside the angle loop (a
 // lane past the ray's end computes exp(-0) and multiplies it with a zero weight).
-template <int N, class TauAt>
-__device__ __forceinline__ void emission_ray_exact(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
+template <int N, class TauAt, class PlanckAt>
+__device__ __forceinline__ void emission_ray_exact(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at, PlanckAt planck_at)
 {
-  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
-  const double pl_num = planck_num(wv);
-  const double pl_exp = kH * wv * kLs;
   double acc[N], dt[N], dt_c[N];
 #pragma unroll
   for (int a = 0; a < N; a++) { acc[a] = 0.0; dt[a] = 0.0; dt_c[a] = 0.0; }
@@ -1786,7 +1783,7 @@ __device__ __forceinline__ void emission_ray_exact(const EmisArgs &E, long long 
     B = 0.0;
     if (have) {
       tv = tau_at(i);
-      B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
+      B = planck_at(i0, i);
     }
     double Bp = dpp_f64<0x138>(B);              // wave_shr:1 -- the lane before (lane 0: the carry)
     if (lane == 0) Bp = B_c;
@@ -1817,12 +1814,9 @@ __device__ __forceinline__ void emission_ray_exact(const EmisArgs &E, long long 
 
 // Any number of angles up to NMAX, a division where an angle has no checked reciprocal: the same terms and sums,
 // angle after angle.
-template <int NMAX, class TauAt>
-__device__ __forceinline__ void emission_ray_any(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
+template <int NMAX, class TauAt, class PlanckAt>
+__device__ __forceinline__ void emission_ray_any(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at, PlanckAt planck_at)
 {
-  const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
-  const double pl_num = planck_num(wv);
-  const double pl_exp = kH * wv * kLs;
   double acc[NMAX], dt_c[NMAX], dt_last[NMAX];
 #pragma unroll
   for (int a = 0; a < NMAX; a++) { acc[a] = 0.0; dt_c[a] = 0.0; dt_last[a] = 0.0; }
@@ -1833,7 +1827,7 @@ __device__ __forceinline__ void emission_ray_any(const EmisArgs &E, long long w,
     double B = 0.0, tv = 0.0;
     if (have) {
       tv = tau_at(i);
-      B = planck_from(pl_num, pl_exp / (kKb * E.temp[E.nr - 1 - i]), s_e2);
+      B = planck_at(i0, i);
     }
     double Bp = dpp_f64<0x138>(B);              // wave_shr:1 -- the lane before (lane 0: set below)
     if (lane == 0) Bp = B_c;
@@ -1867,27 +1861,41 @@ __device__ __forceinline__ void emission_ray_any(const EmisArgs &E, long long w,
 }
 
 // (NMAX: the angles the general form holds state for -- 16 of them are 96 registers)
-template <int NMAX = kMaxAngles, class TauAt>
-__device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at)
+// (planck_at(i0, i): the Planck function of the ray's wavenumber at height i = i0 + lane -- ray_planck below, or
+// values the caller has made ahead of the optical depths, k_ray_tail)
+template <int NMAX = kMaxAngles, class TauAt, class PlanckAt>
+__device__ __forceinline__ void emission_ray(const EmisArgs &E, long long w, int last, int lane, const double *s_e2, TauAt tau_at, PlanckAt planck_at)
 {
   bool recip = E.nang <= 8;
 #pragma unroll
   for (int a = 0; a < 8; a++) if (a < E.nang && E.rcos[a] == 0.0) recip = false;      // (wave-uniform: kernel arguments)
   if (recip) {
     switch (E.nang) {
-      case 1: return emission_ray_exact<1>(E, w, last, lane, s_e2, tau_at);
-      case 2: return emission_ray_exact<2>(E, w, last, lane, s_e2, tau_at);
-      case 3: return emission_ray_exact<3>(E, w, last, lane, s_e2, tau_at);
-      case 4: return emission_ray_exact<4>(E, w, last, lane, s_e2, tau_at);
-      case 5: return emission_ray_exact<5>(E, w, last, lane, s_e2, tau_at);
-      case 6: return emission_ray_exact<6>(E, w, last, lane, s_e2, tau_at);
-      case 7: return emission_ray_exact<7>(E, w, last, lane, s_e2, tau_at);
-      case 8: return emission_ray_exact<8>(E, w, last, lane, s_e2, tau_at);
+      case 1: return emission_ray_exact<1>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 2: return emission_ray_exact<2>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 3: return emission_ray_exact<3>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 4: return emission_ray_exact<4>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 5: return emission_ray_exact<5>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 6: return emission_ray_exact<6>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 7: return emission_ray_exact<7>(E, w, last, lane, s_e2, tau_at, planck_at);
+      case 8: return emission_ray_exact<8>(E, w, last, lane, s_e2, tau_at, planck_at);
       default: break;
     }
   }
-  emission_ray_any<NMAX>(E, w, last, lane, s_e2, tau_at);
+  emission_ray_any<NMAX>(E, w, last, lane, s_e2, tau_at, planck_at);
 }
+
+// the Planck function of ray w at height i (eclipse.c:131-134)
+struct RayPlanck {
+  double num, ex; const double *temp; int nr; const double *e2;
+  __device__ __forceinline__ RayPlanck(const EmisArgs &E, long long w, const double *s_e2)
+  {
+    const double wv = (E.wn_i + (double)(E.lo + w) * E.wn_d) * E.wn_fct;
+    num = planck_num(wv); ex = kH * wv * kLs; temp = E.temp; nr = E.nr; e2 = s_e2;
+  }
+  __device__ __forceinline__ double at_temp(double tk) const { return planck_from(num, ex / (kKb * tk), e2); }
+  __device__ __forceinline__ double operator()(int, int i) const { return at_temp(temp[nr - 1 - i]); }
+};
 
 __global__ __launch_bounds__(64 * kEmisWaves)
 void k_emission(EmisArgs E)
@@ -1900,7 +1908,7 @@ void k_emission(EmisArgs E)
   const long long w = (long long)blockIdx.x * kEmisWaves + (threadIdx.x >> 6);     // wave-uniform
   if (w >= E.nsh) return;
   const int last = __builtin_amdgcn_readfirstlane(E.last[w]);      // (< 0: the ray is still descending -- provisional spectrum, zero)
-  emission_ray(E, w, last, lane, s_e2, [&](int i) { return E.tau[(long long)i * E.nsh + w]; });
+  emission_ray(E, w, last, lane, s_e2, [&](int i) { return E.tau[(long long)i * E.nsh + w]; }, RayPlanck(E, w, s_e2));
 }
 
 // The same for large grids (more than kEmisRowsAbove wavenumbers in the JOB's grid, so that every
@@ -1960,6 +1968,8 @@ struct ModArgs {
   const double *gw; int gstride; const double *gh0;
   double *out;                       // [nsh]
   int *status;                       // set to 1 when modlevel -1 cannot be evaluated
+  int *status_slots;                 // null, or [4] in pinned host memory: slot "code" is set instead of the atomic maximum on status (k_ray_tail with the host adding up; the host takes the highest slot set)
+  __device__ __forceinline__ void raise(int code) const { if (status_slots) status_slots[code] = 1; else atomicMax(status, code); }
 };
 
 // slantpath.c:351-436 (modulation1) and :447-473 (modulationm1).
@@ -1981,7 +1991,7 @@ __device__ __forceinline__ void modulation_ray(const ModArgs &M, long long w, in
   if (M.modlevel == -1) {
     if (lane != 0) return;
     const double tl = tau_at(last);
-    if (tl < M.toomuch) { M.out[w] = -1; atomicMax(M.status, 1); return; }
+    if (tl < M.toomuch) { M.out[w] = -1; M.raise(1); return; }
     int ini = last + 1 - 2; if (ini < 0) ini = 0;
     // interp_line(tau+ini, ipv, toomuch), numerical.c:202-211
     const double x0 = tau_at(ini), x1 = tau_at(ini + 1);
@@ -1995,7 +2005,7 @@ __device__ __forceinline__ void modulation_ray(const ModArgs &M, long long w, in
   // integrand on ascending radius: index q = 0..cnt-1 maps to height i = cnt-1-q
   int lastp = last + 1; if (lastp > nr - 1) lastp = nr - 1;
   const int cnt = lastp + 1;                               // points, including the zero pad
-  if (cnt < 3) { if (lane == 0) { M.out[w] = nan(""); atomicMax(M.status, 2); } return; }
+  if (cnt < 3) { if (lane == 0) { M.out[w] = nan(""); M.raise(2); } return; }
   const double *g = M.gw + (long long)cnt * M.gstride;
   auto val = [&](int q) -> double {
     const int i = cnt - 1 - q;

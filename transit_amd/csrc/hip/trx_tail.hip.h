@@ -55,7 +55,8 @@ struct TailArgs {
   double *e;                                                  // [nr][nsh]
   const int *skip;                                            // null, or the rays' `last`: a closed ray's bins are not combined (zero)
   int *host_flags;                                            // null, or pinned host memory: the run's flags [0..7] and status [16..19] land there too (no copy command behind the kernel)
-  int *host_blocks;                                           // null, or pinned host memory [blocks][2]: (rays still open, deepest layer + 1) of each block -- the host adds them up, nothing is published on the device (vertical rays)
+  int *host_blocks;                                           // null, or pinned host memory [blocks][2]: (rays still open, deepest layer + 1) of each block -- the host adds them up, nothing is published on the device
+                                                              // (slant rays: M.status_slots, behind the blocks' entries, takes what the device's status word would)
   TauArgs T;                                                  // r_top: the first step's; nc: all layers of the plan
   EmisArgs E;                                                 // eclipse geometry (NANG > 0)
   ModArgs M;                                                  // transit geometry (NANG == 0)
@@ -144,6 +145,7 @@ void k_ray_tail(TailArgs A)
   const int n0 = nr - T.r_top;                                // points of the ray that ends in the plan's first layer (layer c: n0 + c)
   const int nc0 = A.S[0].nc;                                  // layers of the first step
   const bool chain_wave = wv == kTailRays;
+  double bpre[2] = {0.0, 0.0};                                // (ray waves, vertical rays) Planck function at heights lane, lane + 64
 
   if (!chain_wave) {
     // ---- the ray waves: bin w0 + wv, lanes = layers.  The plan look-ups of both steps, the first
@@ -162,6 +164,11 @@ void k_ray_tail(TailArgs A)
     }
     // (what the emission needs of the inputs, requested here: used long after)
     const double r_e2 = (!SLANT && wv == 1) ? A.E.e2tab[lane] : 0.0;
+    double tk[2] = {1.0, 1.0};                                  // the temperatures at this lane's heights (height = lane, lane + 64 from the top)
+    if (!SLANT) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) if (lane + 64 * q < nr) tk[q] = A.E.temp[nr - 1 - lane - 64 * q];
+    }
     double xfs = 0.0, xfc = 0.0;                              // this ray's wavenumber factors of the two models
     if (EXTRAS && wv < nrays) { xfs = T.xf_scat[w0 + wv]; xfc = T.xf_cloud[w0 + wv]; }
     auto put = [&](int s, int c0) {                           // this bin's layers of step s: e to memory, the total extinction (tau.c:231-232) to the chain
@@ -193,6 +200,12 @@ void k_ray_tail(TailArgs A)
           else sum[1] = tail_add_records(A.S[1], B, 1, j, lane, sum[1]);
         }
       put(1, nc0);
+    }
+    // the Planck function at this ray's heights, while the chain wave is on its way: the emission's only part that
+    // does not wait for the optical depths (a division, an exponential and a division per height, eclipse.c:131-134)
+    if (!SLANT && wv < nrays) {
+      const RayPlanck PL(A.E, w0 + wv, s_e2);
+      bpre[0] = PL.at_temp(tk[0]); bpre[1] = PL.at_temp(tk[1]);
     }
     __syncthreads();                                            // X2: and the second's
   } else {
@@ -289,7 +302,7 @@ void k_ray_tail(TailArgs A)
       const int rs = (int)T.hrs[kl];
       double tv;
       if (rs == -1) tv = 0.0;                                    // slantpath.c:37-38: the outermost layer
-      else if (rs < 0) { tv = nan(""); atomicMax(T.status, 3); } // slantpath.c:39-44: the reference exits here
+      else if (rs < 0) { tv = nan(""); A.M.raise(3); }           // slantpath.c:39-44: the reference exits here (M.status is T.status)
       else tv = 2 * slant_integral(T, kl, rs, s_p[c][t], [&](int L) { return s_x[T.r_top - L][t]; });      // slantpath.c:107
       tv = T.rad_fct * tv;
       s_tau[c][t] = tv;
@@ -430,11 +443,19 @@ void k_ray_tail(TailArgs A)
     const double *tau_g = T.tau;
     auto tau_at = [&](int i) { return (i >= i_first && i < i_end) ? s_tau[i - i_first][wv] : tau_g[(long long)i * T.nsh + w]; };
     if constexpr (SLANT) modulation_ray(A.M, w, last, lane, tau_at);
-    else                 emission_ray<(NANG > 0 ? NANG : 1)>(A.E, w, last, lane, s_e2, tau_at);
+    else {
+      // (the tail covers a run from its first layer: at most kTailLayers = 128 heights, two passes of 64)
+      const RayPlanck PL(A.E, w, s_e2);
+      emission_ray<(NANG > 0 ? NANG : 1)>(A.E, w, last, lane, s_e2, tau_at,
+                                          [&](int i0, int i) { return i0 == 0 ? bpre[0] : i0 == 64 ? bpre[1] : PL(i0, i); });
+    }
   }
   if (SLANT) {
-    __syncthreads();
-    if (chain_wave && lane == 0) publish();
+    if (A.host_blocks) { if (chain_wave && lane == 0) *(int2 *)(A.host_blocks + 2 * (long long)blockIdx.x) = make_int2(pub_still, pub_deep); }
+    else {
+      __syncthreads();
+      if (chain_wave && lane == 0) publish();
+    }
   }
 }
 
