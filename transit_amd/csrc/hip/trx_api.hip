@@ -64,6 +64,7 @@ struct trx_handle {
   // step c; ev_ac[c] = extinction of step c complete
   hipStream_t stream4 = nullptr;
   std::vector<hipEvent_t> ev_ac, ev_cb;      // ev_cb[c] = partial records of step c consumed
+  hipEvent_t ev_walk1 = nullptr;                     // the first walk of a two-queue run (and the CIA kernels) are done
   hipEvent_t ev_inputs = nullptr, ev_cia = nullptr, ev_join = nullptr, ev_run_a = nullptr, ev_run_b = nullptr;
   std::string err;
 
@@ -94,6 +95,8 @@ struct trx_handle {
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
   bool shard_frames = true;                              // frames sized for the Doppler indices the lines in reach can take (TRX_SHARD_FRAMES=0: for the isotope's whole wavenumber range)
   bool cia_window = true;                                // the CIA spline solved for the table rows a run needs, not the whole table (TRX_CIA_WINDOW=0)
+  bool cia_segments = true;                              // k_cia_layers in pieces of 128 rows (TRX_CIA_SEGMENTS=0: one sweep per table; tests)
+  bool two_queues = true;                                // the second walk of such a run on a queue of its own, next to the first (TRX_TWO_QUEUES=0: behind it)
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
   bool ray_tail = true;                                  // hinted eclipse runs end in k_ray_tail (TRX_RAY_TAIL=0: the step kernels; tests, measurements)
   bool packed_walk = true; int packed_max_layers = 10;   // steps of few layers walk several ranges per wave (TRX_NO_PACKED_WALK, TRX_PACKED_MAX_LAYERS: tests, measurements)
@@ -306,6 +309,8 @@ void test_switches(trx_handle *h)
   h->no_binrec = std::getenv("TRX_NO_BINREC") != nullptr;
   if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }      // k_line_walk_lanes never / also on sparse lists (test_gpu_lanes)
   if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;            // the step kernels instead of k_ray_tail (test_gpu_tail)
+  if (const char *e = std::getenv("TRX_CIA_SEGMENTS")) h->cia_segments = std::atoi(e) != 0;  // the CIA splines' second derivatives in one sweep per table (test_gpu_cia_window)
+  if (const char *e = std::getenv("TRX_TWO_QUEUES")) h->two_queues = std::atoi(e) != 0;       // the walks of a hinted run one behind the other (A/B, tests)
   if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;      // ... copy commands instead of stores into pinned memory
   if (const char *e = std::getenv("TRX_CIA_WINDOW")) h->cia_window = std::atoi(e) != 0;        // the CIA spline over the whole table (test_gpu_cia_window)
   if (const char *e = std::getenv("TRX_SHARD_FRAMES")) h->shard_frames = std::atoi(e) != 0;    // a shard with the list's frames (test_gpu_shard_frames)
@@ -722,7 +727,13 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
   for (int i = 0; i < nr; i++)
     if (a->temp[i] < tmin || a->temp[i] > tmax) return fail(h, TRX_E_RANGE, "layer temperature outside the CIA tables");
   int rc;
-  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * 3 * nwmax * (size_t)nr * std::min<size_t>(kCiaBatch, h->cia.size())))) return rc;
+  // (per table of a batch: the table at the layers' temperatures, its second derivatives, and the sweeps' scratch -- one
+  // piece per segment of k_cia_layers, each with room for its rows and both margins)
+  const int seg_rows = h->cia_segments ? 128 : 1 << 30;
+  const size_t seg_vrows = h->cia_segments ? (size_t)seg_rows + 2 * kCiaMargin + 8 : nwmax;
+  const size_t seg_cap = h->cia_segments ? (nwmax + (size_t)seg_rows - 1) / (size_t)seg_rows : 1;
+  const size_t cia_job_doubles = (2 * nwmax + seg_cap * seg_vrows) * (size_t)nr;
+  if ((rc = ensure(h, h->d_cia_ws, sizeof(double) * cia_job_doubles * std::min<size_t>(kCiaBatch, h->cia.size())))) return rc;
   auto wn_at = [&](long long i) { return o->wn_fct * (h->wn_i + (double)(h->lo + i) * h->wn_d); };
   CiaBatch B{};
   bool first = true;             // the first batch writes the whole array (k_cia_eval), also when it is empty
@@ -738,7 +749,14 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     if (first) { fj0 = 0; lj1 = nr; fi0 = 0; li1 = nsh; }
     if (B.n > 0) {
       hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr, d_tlay);
-      hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((ljl - fjl + 63) / 64), (unsigned)B.n), dim3(64), 0, cst, B, nr);
+      unsigned nseg = 1;
+      for (int t = 0; t < B.n; t++) {
+        const long nw = B.J[t].C.nwave;
+        const long need_a = B.J[t].ia == 0 ? 0 : B.J[t].ia + kCiaMargin, need_b = B.J[t].iz == nw - 1 ? nw - 1 : B.J[t].iz - kCiaMargin;
+        if (h->cia_segments && need_b >= need_a) nseg = std::max<unsigned>(nseg, (unsigned)((need_b - need_a + seg_rows) / seg_rows));
+      }
+      hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((ljl - fjl + 63) / 64), (unsigned)B.n, nseg), dim3(64), 0, cst, B, nr, seg_rows,
+                         (long long)(seg_vrows * (size_t)nr));
     }
     if (nsh > 65536)
       hipLaunchKernelGGL(k_cia_eval<16>, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)((lj1 - fj0 + 15) / 16)), dim3(256), 0, cst,
@@ -780,7 +798,7 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
         if (iz <= nw - 4) J.iz = iz;
       }
     }
-    J.mid = h->d_cia_ws.as<double>() + 3 * nwmax * (size_t)nr * (size_t)B.n; J.z2 = J.mid + nwmax * nr; J.v = J.z2 + nwmax * nr;
+    J.mid = h->d_cia_ws.as<double>() + cia_job_doubles * (size_t)B.n; J.z2 = J.mid + nwmax * nr; J.v = J.z2 + nwmax * nr;
     J.dens = d_dens + n * nr;
     if (++B.n == kCiaBatch) flush(false);
   }
@@ -1615,7 +1633,8 @@ int trx_create(const trx_static *s, trx_handle **out)
     };
     if ((rc = concurrent_stream(&h->stream4, h->stream, nullptr)) || (rc = concurrent_stream(&h->stream2, h->stream, h->stream4))) return bail(rc);
   }
-  if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+  if (hipEventCreateWithFlags(&h->ev_walk1, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_cia, hipEventDisableTiming) != hipSuccess) return bail(TRX_E_HIP);
   h->wn_i = s->wn_i; h->wn_d = s->wn_d; h->osamp = s->osamp; h->odwn = s->wn_d / s->osamp;
@@ -1709,6 +1728,7 @@ void trx_destroy(trx_handle *h)
   if (h->ev_run_a) (void)hipEventDestroy(h->ev_run_a);
   if (h->ev_run_b) (void)hipEventDestroy(h->ev_run_b);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_walk1) (void)hipEventDestroy(h->ev_walk1);
   if (h->ev_cia) (void)hipEventDestroy(h->ev_cia);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_in) (void)hipHostFree(h->h_in);
@@ -2387,6 +2407,8 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     HIPCHK(h, hipHostGetDevicePointer(&h->h_tailblk_dev, h->h_tailblk, 0));
   }
   int tail_nct = 0;
+  const bool two_queues = h->two_queues && tail_direct && pipelined;      // (tail_direct: nothing behind the tail on the main queue)
+  bool tail_on_side = false, cia_queued = false;
   for (;;) {
   {
   for (; r_top >= 0; ) {
@@ -2419,6 +2441,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (h->ngroups > 0 && !all_saved) {
         if (nb && tail_mode && !resumed) {
           // (no combine of its own: its records wait for the tail, each step in its own buffer)
+          // Two walks of one run do not depend on each other, and a walk alone leaves a third of the device idle for
+          // the last third of its time: waves of one launch start together and end apart -- the oldest wave of a SIMD is
+          // served first, a step's ~13 600 ranges are under two generations of resident waves, and the kernel behind it
+          // on the queue cannot start before the last wave has ended (in-kernel clocks, round 5: 7168 waves in flight
+          // for the first 60 us of k_line_walk<2>, then 5000, 3900, 3000, 2200, 1200, 370 at 5 us steps).  The plan's
+          // second walk therefore goes to the side queue, behind the event that marks the inputs, and fills what the
+          // first one leaves; the tail follows it THERE (same queue: no signal between them) and waits for the first
+          // walk's event, long satisfied by then.  Demo: 0.269 -> 0.251 ms, the same bits.
+          const bool side_walk = two_queues && nchunks == 1;
+          if (side_walk) { HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0)); M.st = h->stream4; tail_on_side = true; }
           rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr, nwalks, nullptr, nullptr, nullptr, nullptr, &S.pc, &form);
           if (!rc) {
             TailStep &TS = TA.S[TA.nsteps++];
@@ -2446,8 +2478,16 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     }
     lap("sweep");
     if (tail_mode && !resumed) {
-      // the CIA kernels go to their queue behind the first walk (what the device is waiting for)
-      if (nchunks == 0) { if ((rc = queue_cia())) return rc; lap("cia"); }
+      // the CIA kernels go to their queue behind the first walk (what the device is waiting for) -- ahead of a second
+      // walk on the side queue too: next to TWO walks they take three times as long, and configs[3]'s two tables then
+      // end after the walks.  With two queues the main one waits for them behind its walk and marks the place: one
+      // event for the tail to wait for.
+      if (!cia_queued) {
+        if ((rc = queue_cia())) return rc;
+        cia_queued = true;
+        if (two_queues && !last_step) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0)); HIPCHK(h, hipEventRecord(h->ev_walk1, st)); }
+        lap("cia");
+      }
       r_top -= nc; nchunks++;
       if (nr - 1 - r_top >= h->hint_layers) break;
       continue;
@@ -2475,8 +2515,13 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // ---- spectrum ---------------------------------------------------------------
   if ((rc = join_early())) return rc;
   if (resumed) HIPCHK(h, hipMemsetAsync(h->d_status.p, 0, 16, st));       // (a resumed run computes the spectrum a second time)
+  hipStream_t tst = st;                          // the tail's queue
   if (tail_mode && !resumed) {
-    HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+    if (tail_on_side) { tst = h->stream4; HIPCHK(h, hipStreamWaitEvent(tst, h->ev_walk1, 0)); }
+    else {
+      if (!cia_queued) { if ((rc = queue_cia())) return rc; cia_queued = true; }
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_cia, 0));
+    }
     TA.niso = h->niso; TA.gblock = h->d_gblock.as<int32_t>(); TA.e = h->d_e.as<double>();
     for (int b = 0; b < h->niso && b < 64; b++) if (h->h_gblock[b] != h->h_gblock[b + 1]) TA.blocks |= 1ull << b;
     int nct = 0;
@@ -2508,14 +2553,14 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     }
     const dim3 tgrid((unsigned)((nsh + kTailRays - 1) / kTailRays)), tblock(kTailThreads);
     if (!vertical) {
-      if (extras_on) hipLaunchKernelGGL((k_ray_tail<0, true>), tgrid, tblock, 0, st, TA);
-      else           hipLaunchKernelGGL((k_ray_tail<0, false>), tgrid, tblock, 0, st, TA);
+      if (extras_on) hipLaunchKernelGGL((k_ray_tail<0, true>), tgrid, tblock, 0, tst, TA);
+      else           hipLaunchKernelGGL((k_ray_tail<0, false>), tgrid, tblock, 0, tst, TA);
     } else if (extras_on) {
-      if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, true>), tgrid, tblock, 0, st, TA);
-      else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, true>), tgrid, tblock, 0, st, TA);
+      if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, true>), tgrid, tblock, 0, tst, TA);
+      else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, true>), tgrid, tblock, 0, tst, TA);
     } else {
-      if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, false>), tgrid, tblock, 0, st, TA);
-      else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, false>), tgrid, tblock, 0, st, TA);
+      if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, false>), tgrid, tblock, 0, tst, TA);
+      else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, false>), tgrid, tblock, 0, tst, TA);
     }
     if (lap_on) log_msg(TRX_LOG_DEBUG, "run: ray tail over " + std::to_string(TA.nsteps) + " walk steps, " + std::to_string(nct) + " layers");
   }
@@ -2548,6 +2593,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
   {
     const bool staged = tail_spec && spectrum && !resumed;       // the tail stored the spectrum into the handle's pinned buffer
+    if (tail_on_side && !resumed) HIPCHK(h, hipStreamSynchronize(h->stream4));      // (the tail has waited for the main queue's walk: nothing is left there)
     HIPCHK(h, hipStreamSynchronize(st));
     if (staged) std::memcpy(spectrum, h->h_spec, sizeof(double) * (size_t)nsh);
     if (tail_hostsum && !resumed) {

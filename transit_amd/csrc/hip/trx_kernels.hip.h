@@ -1028,6 +1028,7 @@ void k_cia_rows(CiaBatch B, int nr, const double *__restrict__ tlay)
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int i = ia + (int)(t / nr), j = (int)(t % nr);
   if (i > iz || j < fj || j >= lj) return;
+  latency_critical();
   const long long idx = (long long)i * nr + j;
   mid[idx] = spline_eval_pt(C.zt + (long long)i * C.ntemp, C.ntemp, C.temp, C.cs + (long long)i * C.ntemp, tlay[j]);
 }
@@ -1044,16 +1045,20 @@ void k_cia_rows(CiaBatch B, int nr, const double *__restrict__ tlay)
 constexpr int kCiaChunk = 16;
 constexpr int kCiaMargin = 128;          // rows solved beyond the ones a run's wavenumbers bracket (k_cia_layers)
 
+// Segments (blockIdx.z): the rows a run needs, cut into pieces of seg_rows, each piece a window of its own -- the
+// same margins, the same argument, the same doubles -- with its own scratch for v (the pieces' margins overlap) and
+// storing the second derivatives of ITS rows only.  Two sweeps of ~1700 dependent steps on two waves were 50 us of
+// latency next to one walk and 80 next to two, the longest thing on the CIA queue; pieces of 128 rows are sweeps of
+// 384 + 256 steps (tests/test_gpu_cia_window.py: bit for bit against one segment).
 __global__ __launch_bounds__(64)
-void k_cia_layers(CiaBatch B, int nr)
+void k_cia_layers(CiaBatch B, int nr, int seg_rows, long long seg_vstride)
 {
   const CiaDev &C = B.J[blockIdx.y].C;
   const int fj = B.J[blockIdx.y].fj, lj = B.J[blockIdx.y].lj;
   const double *__restrict__ mid = B.J[blockIdx.y].mid;
-  double *__restrict__ z2 = B.J[blockIdx.y].z2, *__restrict__ v = B.J[blockIdx.y].v;
+  double *__restrict__ z2 = B.J[blockIdx.y].z2, *__restrict__ v = B.J[blockIdx.y].v + (long long)blockIdx.z * seg_vstride;
   const int j = fj + blockIdx.x * 64 + threadIdx.x;
   if (j >= lj) return;
-  latency_critical();
   const long n = C.nwave;
   // The rows ia..iz of the table: all of them, or -- where the run's wavenumbers lie inside a small
   // part of a long table (a shard of a wide band; a band inside a 20-10000 cm-1 table) -- the rows
@@ -1061,9 +1066,19 @@ void k_cia_layers(CiaBatch B, int nr)
   // a sweep carries from row to row shrinks by the pivots' ratio (< 0.3) every row: after the margin
   // a different start is 10^-60 of the value, the doubles inside are those of the whole table's
   // sweeps (tests/test_gpu_cia_window.py: bit for bit against them).
-  const long ia = B.J[blockIdx.y].ia, iz = B.J[blockIdx.y].iz;
+  const long ja = B.J[blockIdx.y].ia, jz = B.J[blockIdx.y].iz;        // the job's window (trx_api.hip)
+  const long need_a = ja == 0 ? 0 : ja + kCiaMargin, need_b = jz == n - 1 ? n - 1 : jz - kCiaMargin;      // the rows it is solved for
+  const long sa = need_a + (long)blockIdx.z * seg_rows;              // this segment's rows sa..sb, its window ia..iz
+  if (sa > need_b) return;
+  const long sb = min(need_b, sa + (long)seg_rows - 1);
+  long ia = sa - kCiaMargin, iz = sb + kCiaMargin;
+  if (ia < 3) ia = 0;
+  if (iz > n - 4) iz = n - 1;
+  latency_critical();
   const double *__restrict__ x = C.wn, *__restrict__ ru = C.ruw, *__restrict__ rh = C.rh;
-  const double *y = mid + j; double *z = z2 + j, *vv = v + j;
+  const double *y = mid + j; double *z = z2 + j, *vs = v + j;
+#define TRX_CIA_V(i) vs[((i) - ia) * nr]
+  auto own = [&](long i) { return i >= sa && i <= sb; };
   double vp = 0;
   long i0 = 2;                                             // first row of the forward recurrence
   double yi, bim;
@@ -1072,13 +1087,13 @@ void k_cia_layers(CiaBatch B, int nr)
       const double h0 = x[1] - x[0], h1 = x[2] - x[1];
       const double b0 = (y[1L*nr] - y[0]) / h0, b1 = (y[2L*nr] - y[1L*nr]) / h1;
       vp = 6 * (b1 - b0);
-      vv[1L*nr] = vp;
+      TRX_CIA_V(1L) = vp;
     }
     yi = n > 2 ? y[2L*nr] : 0.0; bim = n > 2 ? (yi - y[1L*nr]) / (x[2] - x[1]) : 0.0;
   } else {
-    i0 = ia + 1;                                           // (ia >= 3: trx_api.hip)
+    i0 = ia + 1;                                           // (ia >= 3)
     yi = y[i0 * nr]; bim = (yi - y[(i0 - 1) * nr]) * rh[i0 - 1];
-    vv[ia * nr] = 0.0;
+    TRX_CIA_V(ia) = 0.0;
   }
   const long iend = iz == n - 1 ? n - 1 : iz;              // the recurrence runs for rows i0 .. iend-1
   if (n > 3) {
@@ -1097,11 +1112,11 @@ void k_cia_layers(CiaBatch B, int nr)
         }
       }
 #pragma unroll
-      for (int k = 0; k < kCiaChunk; k++) if (base + k < iend) vv[(base + k) * nr] = vo[k];
+      for (int k = 0; k < kCiaChunk; k++) if (base + k < iend) TRX_CIA_V(base + k) = vo[k];
     }
   }
-  if (ia == 0) z[0] = 0;
-  z[iz * nr] = 0;                                          // (row n-1 of the table, or the window's pretended end)
+  if (ia == 0 && own(0)) z[0] = 0;
+  if (own(iz)) z[iz * nr] = 0;                             // (row n-1 of the table; a window's pretended end is nobody's row)
   if (n > 2) {
     // backward: z[i] = (v[i] - h[i] z[i+1]) / u[i]
     double zn = 0;
@@ -1109,7 +1124,7 @@ void k_cia_layers(CiaBatch B, int nr)
     for (long top = iz - 1; top >= ibot; top -= kCiaChunk) {
       double vb[kCiaChunk], zo[kCiaChunk];
 #pragma unroll
-      for (int k = 0; k < kCiaChunk; k++) { const long i = top - k; vb[k] = vv[(i >= ibot ? i : ibot) * nr]; }
+      for (int k = 0; k < kCiaChunk; k++) { const long i = top - k; vb[k] = TRX_CIA_V(i >= ibot ? i : ibot); }
 #pragma unroll
       for (int k = 0; k < kCiaChunk; k++) {
         const long i = top - k;
@@ -1119,10 +1134,10 @@ void k_cia_layers(CiaBatch B, int nr)
         }
       }
 #pragma unroll
-      for (int k = 0; k < kCiaChunk; k++) if (top - k >= ibot) z[(top - k) * nr] = zo[k];
+      for (int k = 0; k < kCiaChunk; k++) if (top - k >= ibot && own(top - k)) z[(top - k) * nr] = zo[k];
     }
-    if (ia != 0) z[ia * nr] = 0.0;
   }
+#undef TRX_CIA_V
 }
 
 // one lane per (wavenumber, layer): evaluate every table of the batch, scale by its density
@@ -1140,6 +1155,7 @@ void k_cia_eval(CiaBatch B, int nr, long long nsh, long long lo, double wn_i, do
   const long long w = fi0 + (long long)blockIdx.x * 256 + threadIdx.x;
   const int j0 = fj0 + blockIdx.y * G, nj = min(G, lj1 - j0);
   if (w >= li1) return;
+  latency_critical();
   const double xo = wn_fct * (wn_i + (double)(lo + w) * wn_d);
   double sum[G];
   unsigned any = first ? 0xffffu : 0u;
@@ -1358,6 +1374,7 @@ __global__ __launch_bounds__(64)
 void k_slant_geometry(SlantGeomArgs G)
 {
   const int nr = G.nr, lane = threadIdx.x;
+  latency_critical();
   if ((int)blockIdx.x < nr) {                              // ---- height k
     const int k = blockIdx.x;
     const double recip = 1.0 / G.fct;
