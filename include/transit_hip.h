@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRX_ABI_VERSION 4
+#define TRX_ABI_VERSION 5
 
 typedef enum {
   TRX_OK            =  0,
@@ -171,7 +171,8 @@ typedef struct {
                              reached is split into equal steps                          */
   int32_t eager;          /* 1 = sweep every layer (debug dumps of all layers) */
   int32_t profile;        /* 1 = bracket the production kernels with HIP events on their own
-                             streams (trx_stats ms_* timings); 2 = also count evaluated /
+                             streams (trx_stats ms_* timings: the run's own plan, queues and kernels,
+                             with the events' packets between them); 2 = also count evaluated /
                              skipped groups and bins with the instrumented kernel variants
                              (trx_stats neval/nskip/sum_bins; those kernels run slower)   */
 } trx_opts;
@@ -233,6 +234,8 @@ typedef struct {
   int64_t walk_form_record_lanes[3]; /* their share of walk_record_lanes                                        */
   int64_t walk_form_bins[3];         /* their share of sum_bins_walk (counting runs)                            */
   double  ms_k_walk_form[3];         /* their share of ms_k_walk (profile >= 1)                                 */
+  double  ms_walk_span;              /* (ABI 5) first walk's start to last walk's end of the last run: where the walks of a hinted run share
+                                        the device on two queues, less than ms_k_walk, the sum of their own durations (profile >= 1) */
 } trx_stats;
 
 typedef struct trx_handle trx_handle;

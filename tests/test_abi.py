@@ -35,7 +35,7 @@ def test_hip_library_exports():
     for n in names:
         assert hasattr(lib, n), n
     lib.trx_abi_version.restype = ctypes.c_int
-    assert lib.trx_abi_version() == 4
+    assert lib.trx_abi_version() == 5
     lib.trx_strerror.restype = ctypes.c_char_p
     lib.trx_strerror.argtypes = [ctypes.c_int]
     assert b"sorted" in lib.trx_strerror(-7)

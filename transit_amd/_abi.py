@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_double_p = C.POINTER(C.c_double)
 c_int16_p = C.POINTER(C.c_int16)
@@ -87,7 +87,7 @@ class TrxStats(C.Structure):
         ("ms_spectrum", C.c_double), ("ncandidates", C.c_int64), ("walk_steps", C.c_int64), ("walk_records", C.c_int64), ("walk_record_lanes", C.c_int64),
         ("walk_layers", C.c_int64), ("sum_bins_walk", C.c_int64),
         ("walk_form_steps", C.c_int64 * 3), ("walk_form_layers", C.c_int64 * 3), ("walk_form_record_lanes", C.c_int64 * 3),
-        ("walk_form_bins", C.c_int64 * 3), ("ms_k_walk_form", C.c_double * 3),
+        ("walk_form_bins", C.c_int64 * 3), ("ms_k_walk_form", C.c_double * 3), ("ms_walk_span", C.c_double),
     ]
 
     def as_dict(self):

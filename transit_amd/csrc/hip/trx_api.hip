@@ -1059,6 +1059,14 @@ struct Spans {
   void sum(double out[kKinds]) const {
     for (const Span &sp : v) { float t = 0; if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) out[sp.kind] += t; }
   }
+  static bool is_walk(int k) { return k == kWalk || k == kWalkLanes || k == kWalkPacked; }
+  // first walk's start to last walk's end (the walks of one run may share the device on two queues)
+  double walk_span() const {
+    double best = 0;
+    for (const Span &x : v) if (is_walk(x.kind))
+      for (const Span &y : v) if (is_walk(y.kind)) { float t = 0; if (hipEventElapsedTime(&t, x.a, y.b) == hipSuccess && t > best) best = t; }
+    return best;
+  }
   ~Spans() { for (Span &sp : v) { if (sp.a) (void)hipEventDestroy(sp.a); if (sp.b) (void)hipEventDestroy(sp.b); } }
 };
 
@@ -1886,7 +1894,7 @@ static int run_finish(trx_handle *h, const trx_atm *a, const trx_opts *o, trx_de
     log_msg(TRX_LOG_DEBUG, std::string(b) + "; queueing by phase (us):" + *Q.laps);
   }
   S.ms_k_sweep = S.ms_k_walk = S.ms_k_accum = S.ms_tau = S.ms_sweep = 0; S.sweep_launches = 0;
-  S.ms_k_walk_form[0] = S.ms_k_walk_form[1] = S.ms_k_walk_form[2] = 0;
+  S.ms_k_walk_form[0] = S.ms_k_walk_form[1] = S.ms_k_walk_form[2] = 0; S.ms_walk_span = 0;
   if (Q.spans) {
     // every launch counts (also the ~4 us gated ones after all rays stopped), so that
     // sum / launches is the average a kernel trace reports
@@ -1896,6 +1904,7 @@ static int run_finish(trx_handle *h, const trx_atm *a, const trx_opts *o, trx_de
     S.ms_k_sweep = t[Spans::kSweep]; S.ms_k_walk = t[Spans::kWalk] + t[Spans::kWalkLanes] + t[Spans::kWalkPacked]; S.ms_k_accum = t[Spans::kAccum]; S.ms_tau = t[Spans::kTau];
     S.sweep_launches = Q.nchunks;
     S.ms_sweep = S.ms_k_sweep + S.ms_k_walk + S.ms_k_accum;
+    S.ms_walk_span = Q.spans->walk_span();
   }
 
   if (dbg) {
@@ -2370,7 +2379,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // emission launches.  Decided from the plan, which a hinted run knows beforehand.
   bool tail_mode = false;
   TailArgs TA{};
-  if (h->ray_tail && stop_at_hint_ok && !prof && h->ngroups > 0 && h->saved.empty() &&
+  if (h->ray_tail && stop_at_hint_ok && !count && h->ngroups > 0 && h->saved.empty() &&      // (profile 1: the same plan with events around its kernels)
       nsh <= 65536 && h->nwn <= kEmisRowsAbove && nsh < 0x7fffffffLL / kTailRays) {
     int r = nr - 1, steps = 0; bool ok = true;
     for (; r >= 0 && ok; ) {
@@ -2451,7 +2460,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
           // walk's event, long satisfied by then.  Demo: 0.269 -> 0.251 ms, the same bits.
           const bool side_walk = two_queues && nchunks == 1;
           if (side_walk) { HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_inputs, 0)); M.st = h->stream4; tail_on_side = true; }
-          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, nullptr, nwalks, nullptr, nullptr, nullptr, nullptr, &S.pc, &form);
+          rc = walk_chunk(h, Y, d_wcut, nb, r_top, nc, M, prof ? &spans : nullptr, nwalks, nullptr, nullptr, nullptr, nullptr, &S.pc, &form);
           if (!rc) {
             TailStep &TS = TA.S[TA.nsteps++];
             TS.P = S.pc.C.P; TS.part = S.pc.C.part; TS.nc = nc;
@@ -2552,6 +2561,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (!ok) return fail(h, TRX_E_HIP, "internal: incomplete arguments for the ray tail (not launched)");
     }
     const dim3 tgrid((unsigned)((nsh + kTailRays - 1) / kTailRays)), tblock(kTailThreads);
+    if (prof && spans.begin(Spans::kTau, tst)) return fail(h, TRX_E_HIP, "event");
     if (!vertical) {
       if (extras_on) hipLaunchKernelGGL((k_ray_tail<0, true>), tgrid, tblock, 0, tst, TA);
       else           hipLaunchKernelGGL((k_ray_tail<0, false>), tgrid, tblock, 0, tst, TA);
@@ -2562,6 +2572,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       if (o->nangles <= 8) hipLaunchKernelGGL((k_ray_tail<8, false>), tgrid, tblock, 0, tst, TA);
       else                 hipLaunchKernelGGL((k_ray_tail<kMaxAngles, false>), tgrid, tblock, 0, tst, TA);
     }
+    if (prof && spans.end(tst)) return fail(h, TRX_E_HIP, "event");
     if (lap_on) log_msg(TRX_LOG_DEBUG, "run: ray tail over " + std::to_string(TA.nsteps) + " walk steps, " + std::to_string(nct) + " layers");
   }
   else if (o->solution == TRX_SOL_ECLIPSE) {
@@ -2580,7 +2591,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
       hipLaunchKernelGGL(k_modulation, dim3((unsigned)((nsh + kModWaves - 1) / kModWaves)), dim3(64 * kModWaves), 0, st, M);
   }
   HIPCHK(h, hipGetLastError());
-  if (prof) HIPCHK(h, hipEventRecord(ev.b, st));
+  if (prof) HIPCHK(h, hipEventRecord(ev.b, tst));
 
   // ---- results back -----------------------------------------------------------
   {   // one copy into pinned memory: flags, status and (profiled runs) the counters
