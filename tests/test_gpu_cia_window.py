@@ -1,13 +1,15 @@
-"""The CIA wavenumber spline solved for the table rows a run's wavenumbers bracket (128 rows to
-spare on either side) instead of the whole table (k_cia_layers): what the tridiagonal sweeps carry
-from row to row shrinks by the pivots' ratio every row, so inside the margin the second derivatives
-are the whole table's doubles -- e_cs and the spectrum of a shard of a wide band must be the same
-BITS as with TRX_CIA_WINDOW=0, in both geometries, on shards at the start, in the middle and at the
-end of the table, with one and with two tables.  The same argument cuts the rows of a window into
-segments of 128 that are solved side by side, each with margins of its own (the sweeps are a chain
-of dependent steps on two waves: the longest kernel of the CIA queue): the default engine here has
-windows AND segments, the one it is compared with (TRX_CIA_WINDOW=0, TRX_CIA_SEGMENTS=0) solves
-every table whole in one sweep, as the reference does."""
+"""The CIA wavenumber spline (second derivatives of every layer's column, crosssec.c:354-428) on the device.
+
+Sweeps (k_cia_layers, the reference's two recurrences): solved for the table rows a run's wavenumbers bracket
+(128 rows to spare on either side) instead of the whole table -- what the sweeps carry from row to row shrinks
+by the pivots' ratio every row, so inside the margin the second derivatives are the whole table's doubles --
+and, by the same argument, in segments of 128 rows side by side.  e_cs and the spectrum of a shard of a wide
+band must be the same BITS as with TRX_CIA_WINDOW=0 TRX_CIA_SEGMENTS=0.
+
+Sums (k_cia_v, k_cia_z, the default): every row a sum of 48 terms with table-constant weights -- no chain.  A
+row depends on its neighbours only, so windows change nothing by construction (bit for bit again); against the
+sweeps the rounding differs in the last place: 1e-13 of the largest value, the tolerance e_cs has against the
+oracle."""
 import os
 
 import numpy as np
@@ -21,6 +23,19 @@ from transit_amd.shard import all_bounds
 pytestmark = pytest.mark.gpu
 
 
+def _engine(static, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Engine(static)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("solution,ncia", [("eclipse", 1), ("transit", 2)])
 def test_windowed_cia_spline_is_the_whole_table_s(tmp_path, solution, ncia):
     d = str(tmp_path / "w")
@@ -32,31 +47,29 @@ def test_windowed_cia_spline_is_the_whole_table_s(tmp_path, solution, ncia):
         if k in (2, 4, 5):
             continue
         P.set_shard(lo, hi)
+        engines = []
         try:
-            a = Engine(P.static)
-            os.environ["TRX_CIA_WINDOW"] = "0"
-            os.environ["TRX_CIA_SEGMENTS"] = "0"
-            try:
-                b = Engine(P.static)
-                os.environ.pop("TRX_CIA_WINDOW", None)
-                c = Engine(P.static)                  # windows, one segment each
-            finally:
-                os.environ.pop("TRX_CIA_WINDOW", None)
-                os.environ.pop("TRX_CIA_SEGMENTS", None)
-            try:
-                for rep in range(2):
-                    ra = a.run(P.atm, P.opts, debug=("e_cs", "last", "tau"))
-                    rb = b.run(P.atm, P.opts, debug=("e_cs", "last", "tau"))
-                    rc = c.run(P.atm, P.opts, debug=("e_cs", "last", "tau"))
-                    assert np.array_equal(ra["e_cs"], rb["e_cs"]), (k, rep)
-                    assert np.array_equal(rc["e_cs"], rb["e_cs"]), (k, rep)
-                    assert np.array_equal(ra["last"], rb["last"]), (k, rep)
-                    assert np.array_equal(ra["spectrum"], rb["spectrum"]), (k, rep)
-                    assert np.all(np.isfinite(ra["e_cs"])) and ra["e_cs"].max() > 0
-                windows += 1
-            finally:
-                a.close(); b.close(); c.close()
+            a = _engine(P.static); engines.append(a)                                           # sums, windows
+            a2 = _engine(P.static, TRX_CIA_WINDOW=0); engines.append(a2)                        # sums, whole tables
+            b = _engine(P.static, TRX_CIA_SUMS=0, TRX_CIA_WINDOW=0, TRX_CIA_SEGMENTS=0); engines.append(b)      # the reference's sweeps over whole tables
+            c = _engine(P.static, TRX_CIA_SUMS=0); engines.append(c)                            # sweeps: windows, segments
+            c1 = _engine(P.static, TRX_CIA_SUMS=0, TRX_CIA_SEGMENTS=0); engines.append(c1)      # sweeps: windows, one segment each
+            for rep in range(2):
+                ra, ra2, rb, rc, rc1 = (e.run(P.atm, P.opts, debug=("e_cs", "last", "tau")) for e in (a, a2, b, c, c1))
+                for r in (rc, rc1):                                  # the sweeps, however cut: the same bits
+                    assert np.array_equal(r["e_cs"], rb["e_cs"]), (k, rep)
+                    assert np.array_equal(r["spectrum"], rb["spectrum"]), (k, rep)
+                assert np.array_equal(ra["e_cs"], ra2["e_cs"]), (k, rep)        # the sums: windows change nothing
+                assert np.array_equal(ra["spectrum"], ra2["spectrum"]), (k, rep)
+                scale = np.abs(rb["e_cs"]).max()
+                assert np.abs(ra["e_cs"] - rb["e_cs"]).max() <= 1e-13 * scale, (k, rep)     # sums against sweeps
+                assert np.array_equal(ra["last"], rb["last"]), (k, rep)
+                np.testing.assert_allclose(ra["spectrum"], rb["spectrum"], rtol=1e-11, atol=0)
+                assert np.all(np.isfinite(ra["e_cs"])) and ra["e_cs"].max() > 0
+            windows += 1
         finally:
+            for e in engines:
+                e.close()
             P.set_shard(0, P.nwn)
     assert windows == 4
 
@@ -64,22 +77,22 @@ def test_windowed_cia_spline_is_the_whole_table_s(tmp_path, solution, ncia):
 @pytest.mark.parametrize("solution,ncia", [("eclipse", 1), ("transit", 2)])
 def test_segmented_cia_spline_on_the_whole_grid(tmp_path, solution, ncia):
     """No shard, no window to speak of (the run's wavenumbers cover most of the table): the segments alone
-    against one sweep per table."""
+    against one sweep per table, and the sums against both."""
     d = str(tmp_path / "s")
     synth.make_case(d, nlines=30_000, wnlow=2000, wnhigh=12000, wndelt=1.0, wnosamp=2160, nlayers=40,
                     solution=solution, toomuch=10.0, ethresh=1e-50, seed=8, ncia=ncia)
     P = Problem.from_cfg(os.path.join(d, "case.cfg"))
-    a = Engine(P.static)
-    os.environ["TRX_CIA_SEGMENTS"] = "0"
-    try:
-        b = Engine(P.static)
-    finally:
-        os.environ.pop("TRX_CIA_SEGMENTS", None)
+    a = _engine(P.static, TRX_CIA_SUMS=0)
+    b = _engine(P.static, TRX_CIA_SUMS=0, TRX_CIA_SEGMENTS=0)
+    c = _engine(P.static)
     try:
         ra = a.run(P.atm, P.opts, debug=("e_cs", "last"))
         rb = b.run(P.atm, P.opts, debug=("e_cs", "last"))
+        rc = c.run(P.atm, P.opts, debug=("e_cs", "last"))
         assert np.array_equal(ra["e_cs"], rb["e_cs"])
         assert np.array_equal(ra["spectrum"], rb["spectrum"])
+        assert np.abs(rc["e_cs"] - rb["e_cs"]).max() <= 1e-13 * np.abs(rb["e_cs"]).max()
+        assert np.array_equal(rc["last"], rb["last"])
         assert np.all(np.isfinite(ra["e_cs"])) and ra["e_cs"].max() > 0
     finally:
-        a.close(); b.close()
+        a.close(); b.close(); c.close()

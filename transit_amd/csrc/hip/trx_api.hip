@@ -95,6 +95,7 @@ struct trx_handle {
   std::vector<std::pair<double, double>> recip_ok;     // divisors whose reciprocal quotient_rn may use (checked_reciprocal)
   bool shard_frames = true;                              // frames sized for the Doppler indices the lines in reach can take (TRX_SHARD_FRAMES=0: for the isotope's whole wavenumber range)
   bool cia_window = true;                                // the CIA spline solved for the table rows a run needs, not the whole table (TRX_CIA_WINDOW=0)
+  bool cia_sums = true;                                  // the CIA splines' second derivatives as sums per row (TRX_CIA_SUMS=0: the sweeps of k_cia_layers; tests)
   bool cia_segments = true;                              // k_cia_layers in pieces of 128 rows (TRX_CIA_SEGMENTS=0: one sweep per table; tests)
   bool two_queues = true;                                // the second walk of such a run on a queue of its own, next to the first (TRX_TWO_QUEUES=0: behind it)
   bool tail_direct = true;                               // ... which writes spectrum and flags straight into pinned host memory (TRX_TAIL_DIRECT=0: copy commands)
@@ -126,7 +127,7 @@ struct trx_handle {
   struct Plan { bool built = false; DevBuf blo, bhi, off, binw, binrec; int64_t records = 0; };
   Plan plan[4];                                             // NB = 2, 4, 8, 16 bins per frame
   // CIA (host copies)
-  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw, ruw, rh; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw, d_ruw, d_rh; };
+  struct Cia { int nspec; int mol[2]; std::vector<double> wn, temp, cs, zt, uw, ruw, rh, wf, wb; DevBuf d_wn, d_temp, d_cs, d_zt, d_uw, d_ruw, d_rh, d_wf, d_wb; };      // wf, wb: weights of k_cia_v / k_cia_z (empty: the sweeps)
   std::vector<Cia> cia;
   DevBuf d_cia_ws;
   // per-run workspaces (grown on demand)
@@ -309,6 +310,7 @@ void test_switches(trx_handle *h)
   h->no_binrec = std::getenv("TRX_NO_BINREC") != nullptr;
   if (const char *e = std::getenv("TRX_LANES_WALK")) { h->lanes_walk = std::atoi(e) != 0; h->lanes_force = std::atoi(e) == 2; }      // k_line_walk_lanes never / also on sparse lists (test_gpu_lanes)
   if (const char *e = std::getenv("TRX_RAY_TAIL")) h->ray_tail = std::atoi(e) != 0;            // the step kernels instead of k_ray_tail (test_gpu_tail)
+  if (const char *e = std::getenv("TRX_CIA_SUMS")) h->cia_sums = std::atoi(e) != 0;
   if (const char *e = std::getenv("TRX_CIA_SEGMENTS")) h->cia_segments = std::atoi(e) != 0;  // the CIA splines' second derivatives in one sweep per table (test_gpu_cia_window)
   if (const char *e = std::getenv("TRX_TWO_QUEUES")) h->two_queues = std::atoi(e) != 0;       // the walks of a hinted run one behind the other (A/B, tests)
   if (const char *e = std::getenv("TRX_TAIL_DIRECT")) h->tail_direct = std::atoi(e) != 0;      // ... copy commands instead of stores into pinned memory
@@ -749,14 +751,21 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     if (first) { fj0 = 0; lj1 = nr; fi0 = 0; li1 = nsh; }
     if (B.n > 0) {
       hipLaunchKernelGGL(k_cia_rows, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr, d_tlay);
+      bool sums = true;                    // every table of the batch has its weights: two sums per row instead of the sweeps
+      for (int t = 0; t < B.n; t++) sums = sums && B.J[t].C.wf != nullptr;
+      if (sums) {
+        hipLaunchKernelGGL(k_cia_v, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr);
+        hipLaunchKernelGGL(k_cia_z, dim3((unsigned)(((long long)nwave * nr + 255) / 256), (unsigned)B.n), dim3(256), 0, cst, B, nr);
+      }
       unsigned nseg = 1;
-      for (int t = 0; t < B.n; t++) {
+      for (int t = 0; t < B.n && !sums; t++) {
         const long nw = B.J[t].C.nwave;
         const long need_a = B.J[t].ia == 0 ? 0 : B.J[t].ia + kCiaMargin, need_b = B.J[t].iz == nw - 1 ? nw - 1 : B.J[t].iz - kCiaMargin;
         if (h->cia_segments && need_b >= need_a) nseg = std::max<unsigned>(nseg, (unsigned)((need_b - need_a + seg_rows) / seg_rows));
       }
-      hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((ljl - fjl + 63) / 64), (unsigned)B.n, nseg), dim3(64), 0, cst, B, nr, seg_rows,
-                         (long long)(seg_vrows * (size_t)nr));
+      if (!sums)
+        hipLaunchKernelGGL(k_cia_layers, dim3((unsigned)((ljl - fjl + 63) / 64), (unsigned)B.n, nseg), dim3(64), 0, cst, B, nr, seg_rows,
+                           (long long)(seg_vrows * (size_t)nr));
     }
     if (nsh > 65536)
       hipLaunchKernelGGL(k_cia_eval<16>, dim3((unsigned)((li1 - fi0 + 255) / 256), (unsigned)((lj1 - fj0 + 15) / 16)), dim3(256), 0, cst,
@@ -784,7 +793,8 @@ int cia_device(trx_handle *h, const trx_atm *a, const trx_opts *o, const double 
     if (fi >= li || fj >= lj) continue;
     CiaJob &J = B.J[B.n];
     J.C = CiaDev{(int)c.wn.size(), (int)c.temp.size(), c.d_wn.as<double>(), c.d_temp.as<double>(), c.d_cs.as<double>(),
-                 c.d_zt.as<double>(), c.d_uw.as<double>(), c.d_ruw.as<double>(), c.d_rh.as<double>()};
+                 c.d_zt.as<double>(), c.d_uw.as<double>(), c.d_ruw.as<double>(), c.d_rh.as<double>(),
+                 (h->cia_sums && !c.wf.empty()) ? c.d_wf.as<double>() : nullptr, (h->cia_sums && !c.wf.empty()) ? c.d_wb.as<double>() : nullptr};
     J.fj = fj; J.lj = lj; J.fi = fi; J.li = li;
     {   // table rows the wavenumber spline is solved for: those the run's wavenumbers bracket, a margin to spare (k_cia_layers)
       const int nw = (int)c.wn.size();
@@ -1687,6 +1697,31 @@ int trx_create(const trx_static *s, trx_handle **out)
       for (size_t i = 0; i < (size_t)nw; i++) if (t.uw[i] != 0.0) t.ruw[i] = 1.0 / t.uw[i];
       t.rh.assign(nw, 0.0);                  // reciprocal spacings 1/(wn[i+1]-wn[i])
       for (size_t i = 0; i + 1 < (size_t)nw; i++) t.rh[i] = 1.0 / (t.wn[i + 1] - t.wn[i]);
+      // weights of the sums that stand for the two sweeps (k_cia_v, k_cia_z): products of the sweeps' row-to-row factors,
+      // kept where kCiaTerms of them leave less than 2^-60 everywhere in the table
+      if (nw >= 8) {
+        const size_t K = kCiaTerms;
+        std::vector<double> wf(nw * K, 0.0), wb(nw * K, 0.0);
+        double worst = 0.0;
+        for (size_t i = 1; i + 1 < nw; i++) {
+          double p = 1.0;                                   // forward: (-1)^k c[i] c[i-1] .. c[i-k+1], c[m] = h[m-1] / u[m-1] (m >= 2)
+          for (size_t k = 0; k <= K; k++) {
+            if (i < 1 + k) break;                           // row i - k < 1
+            if (k < K) wf[i * K + k] = p; else worst = std::fmax(worst, std::fabs(p));
+            const size_t m = i - k;                         // next factor: -c[m]
+            if (m < 2) break;
+            p *= -((t.wn[m] - t.wn[m - 1]) * t.ruw[m - 1]);
+          }
+          p = 1.0;                                          // backward: (-1)^k d[i] .. d[i+k-1] / u[i+k], d[m] = h[m] / u[m]
+          for (size_t k = 0; k <= K; k++) {
+            const size_t m = i + k;
+            if (m + 1 >= nw) break;                         // row i + k > n - 2
+            if (k < K) wb[i * K + k] = p * t.ruw[m]; else worst = std::fmax(worst, std::fabs(p));
+            p *= -((t.wn[m + 1] - t.wn[m]) * t.ruw[m]);
+          }
+        }
+        if (worst < 0x1p-60) { t.wf = std::move(wf); t.wb = std::move(wb); }
+      }
     }
     h->cia.push_back(std::move(t));
   }
@@ -1703,7 +1738,8 @@ int trx_create(const trx_static *s, trx_handle **out)
   }
   for (auto &c : h->cia)
     if ((rc = upload(h, c.d_wn, c.wn)) || (rc = upload(h, c.d_temp, c.temp)) || (rc = upload(h, c.d_cs, c.cs)) ||
-        (rc = upload(h, c.d_zt, c.zt)) || (rc = upload(h, c.d_uw, c.uw)) || (rc = upload(h, c.d_ruw, c.ruw)) || (rc = upload(h, c.d_rh, c.rh))) return bail(rc);
+        (rc = upload(h, c.d_zt, c.zt)) || (rc = upload(h, c.d_uw, c.uw)) || (rc = upload(h, c.d_ruw, c.ruw)) || (rc = upload(h, c.d_rh, c.rh)) ||
+        (!c.wf.empty() && ((rc = upload(h, c.d_wf, c.wf)) || (rc = upload(h, c.d_wb, c.wb))))) return bail(rc);
   // the handle does not survive a failed create, so its error text cannot be asked for later:
   // without a message callback it goes to stderr
   auto say = [&]() { if (!log_sink().fn) std::fprintf(stderr, "trx_create: %s\n", h->err.c_str()); };

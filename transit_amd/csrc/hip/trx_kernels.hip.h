@@ -1001,7 +1001,7 @@ void k_grid_extinction(GridArgs G)
 // The table-only halves of both splines are computed once at trx_create
 // (zt = second derivatives along T of every table row, uw = the tridiagonal
 // pivots u[] of the wavenumber spline, which depend on the wn grid alone).
-struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs, *zt, *uw, *ruw, *rh; };
+struct CiaDev { int nwave, ntemp; const double *wn, *temp, *cs, *zt, *uw, *ruw, *rh; const double *wf, *wb; };      // wf, wb: [nwave][kCiaTerms] weights of k_cia_v / k_cia_z, or null
 
 // one lane per (table row, layer): the T spline evaluated at the layer temperature.
 // mid is [nwave][nr] so that the next kernel walks it with unit stride per lane.
@@ -1138,6 +1138,76 @@ void k_cia_layers(CiaBatch B, int nr, int seg_rows, long long seg_vstride)
     }
   }
 #undef TRX_CIA_V
+}
+
+// The same second derivatives without a sweep.  The forward recurrence v[i] = g[i] - c[i] v[i-1] (g[i] = 6 (b[i] - b[i-1]),
+// c[i] = h[i-1] / u[i-1]) is v[i] = g[i] - c[i] g[i-1] + c[i] c[i-1] g[i-2] - ..., and c < 0.3 on any sensible grid: after
+// kCiaTerms terms the products are below 2^-60 (trx_create checks that on the table's own pivots and leaves the weights
+// out otherwise: the sweeps then run).  Likewise backwards, z[i] = v[i]/u[i] - d[i] v[i+1]/u[i+1] + ..., d[i] = h[i] / u[i].
+// The products are table constants (weights wf, wb, made at create); every (row, layer) pair is then a sum of
+// kCiaTerms terms on its own, smallest first: two launches of a few microseconds instead of two chains of a thousand
+// dependent steps on two waves (50 us next to one walk, 80 next to two, and proportional to the table's rows).  A row
+// depends on its 2 x 48 neighbours only: a shard's window, a segment, the whole table give the same doubles by
+// construction.  Rounding differs from the sweeps' (and the oracle's) in the last place; e_cs agrees with the oracle
+// to 1e-13 as before (tests/test_gpu_cia_window.py compares the two forms).
+constexpr int kCiaTerms = 48;
+
+__device__ __forceinline__ void cia_need(const CiaJob &J, long n, long &need_a, long &need_b)
+{
+  need_a = J.ia == 0 ? 0 : J.ia + kCiaMargin; need_b = J.iz == n - 1 ? n - 1 : J.iz - kCiaMargin;
+}
+
+__global__ __launch_bounds__(256)
+void k_cia_v(CiaBatch B, int nr)
+{
+  const CiaJob &J = B.J[blockIdx.y];
+  const CiaDev &C = J.C;
+  const long n = C.nwave;
+  long need_a, need_b;
+  cia_need(J, n, need_a, need_b);
+  const long va = max(1L, need_a), vb = min(n - 2, need_b + kCiaTerms - 1);          // rows of v that k_cia_z reads
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long i = va + (long)(t / nr); const int j = (int)(t % nr);
+  if (i > vb || j < J.fj || j >= J.lj) return;
+  latency_critical();
+  const double *__restrict__ y = J.mid + j, *__restrict__ rh = C.rh, *__restrict__ w = C.wf + i * kCiaTerms;
+  // rows i - kCiaTerms .. i + 1 go by once, eight at a time (the kernel runs next to the walks: few registers, or its
+  // waves wait for a SIMD with room); a row outside the window or the table: the nearest one inside -- its weight is zero
+  auto yrow = [&](long r) { return y[min(max(r, (long)J.ia), (long)J.iz) * nr]; };
+  double acc = 0.0;
+  double y0 = yrow(i - kCiaTerms), y1 = yrow(i - kCiaTerms + 1);
+  double bm = (y1 - y0) * rh[min(max(i - kCiaTerms, 0L), n - 2)];      // b of the row before the first term's
+#pragma unroll 8
+  for (int q = 1; q <= kCiaTerms; q++) {                     // row m = i - kCiaTerms + q: the term k = kCiaTerms - q, smallest first
+    const long m = i - kCiaTerms + q;
+    const double y2 = yrow(m + 1);
+    const double b = (y2 - y1) * rh[min(max(m, 0L), n - 2)];
+    acc = __builtin_fma(w[kCiaTerms - q], 6 * (b - bm), acc);
+    bm = b; y1 = y2;
+  }
+  J.v[i * nr + j] = acc;
+}
+
+__global__ __launch_bounds__(256)
+void k_cia_z(CiaBatch B, int nr)
+{
+  const CiaJob &J = B.J[blockIdx.y];
+  const CiaDev &C = J.C;
+  const long n = C.nwave;
+  long need_a, need_b;
+  cia_need(J, n, need_a, need_b);
+  const long va = max(1L, need_a), vb = min(n - 2, need_b + kCiaTerms - 1);
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long i = need_a + (long)(t / nr); const int j = (int)(t % nr);
+  if (i > need_b || j < J.fj || j >= J.lj) return;
+  latency_critical();
+  double acc = 0.0;
+  if (i >= 1 && i <= n - 2) {
+    const double *__restrict__ v = J.v + j, *__restrict__ w = C.wb + i * kCiaTerms;
+#pragma unroll 8
+    for (int k = kCiaTerms - 1; k >= 0; k--) acc = __builtin_fma(w[k], v[min(max(i + k, va), vb) * nr], acc);
+  }
+  J.z2[i * nr + j] = acc;                                   // (rows 0 and n - 1: the natural spline's zeros)
 }
 
 // one lane per (wavenumber, layer): evaluate every table of the batch, scale by its density
