@@ -145,6 +145,51 @@ def test_tail_with_copy_commands_instead_of_pinned_outputs(tmp_path):
         t.close(); r.close(); c.close()
 
 
+@pytest.mark.parametrize("solution,ncia", [("eclipse", 1), ("transit", 2)])
+def test_two_queues_against_one(tmp_path, solution, ncia):
+    """A hinted run of two walk steps puts its second walk on the side queue next to the first and the tail
+    behind it there (TRX_TWO_QUEUES=0: one queue, the walks one behind the other): the same bits, the same
+    depth hint, also when the atmosphere moves under the remembered depth (rays go deeper: the pass is resumed
+    by the step kernels with the flags the host has added up) -- and with the kernels bracketed by events
+    (trx_opts.profile 1: the same plan and the same bits; one queue: the walks' span is at least the sum of their durations)."""
+    d = str(tmp_path / "q")
+    synth.make_case(d, nlines=120_000, wnlow=2500, wnhigh=2800, wndelt=1.0, wnosamp=2160, nlayers=100,
+                    solution=solution, toomuch=10.0, ethresh=1e-50, seed=11, ncia=ncia)
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    os.environ["TRX_TWO_QUEUES"] = "0"
+    try:
+        one = Engine(P.static)
+    finally:
+        os.environ.pop("TRX_TWO_QUEUES", None)
+    two, ref = engines(P)
+    dens = np.ctypeslib.as_array(P.atm.density, shape=(P.static.nmol * P.nlayer,))
+    base = dens.copy()
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    spans = 0
+    try:
+        for k, sc in enumerate([1.0, 1.0, 1.0, 0.05, 0.05, 1.0, 1.0, 3.0, 3.0]):
+            dens[:] = base * sc
+            P.opts.profile = 1 if k in (2, 6) else 0
+            a, b, x = two.run(P.atm, P.opts), one.run(P.atm, P.opts), ref.run(P.atm, P.opts)
+            assert np.array_equal(a["spectrum"], x["spectrum"]) and np.array_equal(b["spectrum"], x["spectrum"]), (k, sc)
+            sa, sb, sx = two.stats(), one.stats(), ref.stats()
+            # (the tail has swept both steps of its plan when it looks at the rays; the step kernels of a plan whose first
+            # step closes every ray -- the atmosphere got denser -- gate the second step off and do not count it)
+            assert sa["layers_swept"] == sb["layers_swept"] >= sx["layers_swept"], (k, sc)
+            if P.opts.profile and sa["walk_steps"] == 2:
+                assert sa["ms_walk_span"] > 0 and sa["ms_k_walk"] > 0, (k, sa["ms_walk_span"], sa["ms_k_walk"])      # (short walks: the second may start after the first has ended)
+                assert sb["ms_walk_span"] >= 0.999 * sb["ms_k_walk"] > 0, (k, sb["ms_walk_span"], sb["ms_k_walk"])     # one queue: one behind the other
+                spans += 1
+    finally:
+        P.opts.profile = 0
+        dens[:] = base
+        engine.set_log(None)
+        two.close(); one.close(); ref.close()
+    assert tail_runs(msgs) >= 8
+    assert spans >= 1
+
+
 @pytest.mark.parametrize("solution", ["eclipse", "transit"])
 def test_tail_without_the_per_bin_record_table(tmp_path, solution):
     """TRX_NO_BINREC: the tail finds a bin's records through the ranges' numbers (blo, off) instead of the plan's
