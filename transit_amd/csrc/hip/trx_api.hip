@@ -2088,6 +2088,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   // ---- layer prologue (extinction.c:364-395) --------------------------------
   LayerHost LH(h->run_f64, h->run_i32);
   if ((rc = prep_layers(h, nr, a->temp, a->density, a->zpart, 8 * (size_t)nr, LH))) return rc;
+  lap("layers");
   h->walk_temp_ok = true;
   for (int r = 0; r < nr; r++) if (a->temp[r] < kWalkMinTemp) h->walk_temp_ok = false;
   std::vector<double> &f64 = LH.f64;
@@ -2101,6 +2102,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   const int user_chunk = o->layer_chunk > 0 ? std::max(3, o->layer_chunk) : 0;
   std::vector<double> &geom = h->run_geom, &ipv = h->run_ipv;
   run_host_inputs(h, a, LH, vertical, gstride, mw_doubles, n_geom_all, geom, ipv);
+  lap("rays");
   if (f64.size() != n_f64 || geom.size() != n_geom || ipv.size() != n_ip || LH.i32.size() != n_i32)
     return fail(h, TRX_E_HIP, "internal: the input block's layout");
 
@@ -2140,6 +2142,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     cia_densities(h, a, hin + off_cd);
     std::memcpy(hin + off_i32, LH.i32.data(), 4 * n_i32);
   }
+  lap("block");
   // the whole front end of a run goes to the stream the line sweep runs on (the main stream
   // joins it at the first optical depth): no cross-stream hop before the first sweep kernel
   // Streams.  The front end (inputs, layer maxima), the walks and everything that follows the
@@ -2429,7 +2432,10 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   }
   // (flags into the pinned block the host reads; the spectrum into pinned memory too when the caller wants it on the host)
   const bool tail_direct = tail_mode && h->tail_direct, tail_spec = tail_direct && spectrum && !d_spectrum;
-  if (tail_spec && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
+  // (any run that hands its spectrum to pageable host memory stages it in the handle's pinned buffer when it is small:
+  // the copy command into pageable memory is staged by the runtime anyway, 25 us behind the copy of the flags at configs[2])
+  const bool stage_spec = spectrum && !d_spectrum && nsh <= (1 << 20);
+  if ((tail_spec || stage_spec) && h->h_spec_bytes < sizeof(double) * (size_t)nsh) {
     if (h->h_spec) (void)hipHostFree(h->h_spec);
     h->h_spec = nullptr; h->h_spec_bytes = 0;
     HIPCHK(h, hipHostMalloc(&h->h_spec, sizeof(double) * (size_t)nsh, hipHostMallocDefault));
@@ -2633,13 +2639,13 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
   {   // one copy into pinned memory: flags, status and (profiled runs) the counters
     const size_t nb = count ? 128 + 24 * (size_t)nr : 128;
     if (!(tail_direct && !resumed)) HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small.p, nb, hipMemcpyDeviceToHost, st));
-    if (spectrum && !(tail_spec && !resumed)) HIPCHK(h, hipMemcpyAsync((void *)spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
+    if (spectrum && !(tail_spec && !resumed)) HIPCHK(h, hipMemcpyAsync(stage_spec ? h->h_spec : (void *)spectrum, d_out, sizeof(double) * nsh, hipMemcpyDeviceToHost, st));
     lap("spectrum+copies");
   }
   t_host_queued = std::chrono::steady_clock::now();
   }
   {
-    const bool staged = tail_spec && spectrum && !resumed;       // the tail stored the spectrum into the handle's pinned buffer
+    const bool staged = spectrum && ((tail_spec && !resumed) || stage_spec);       // the tail stored the spectrum into the handle's pinned buffer, or the copy command did
     if (tail_on_side && !resumed) HIPCHK(h, hipStreamSynchronize(h->stream4));      // (the tail has waited for the main queue's walk: nothing is left there)
     HIPCHK(h, hipStreamSynchronize(st));
     if (staged) std::memcpy(spectrum, h->h_spec, sizeof(double) * (size_t)nsh);

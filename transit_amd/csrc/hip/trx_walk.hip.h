@@ -935,7 +935,7 @@ struct CombineArgs {
   const int *flags; const int *last; int eager;
 };
 
-constexpr int kCombineBins = 8;
+constexpr int kCombineBins = 4;
 
 __global__ __launch_bounds__(64 * kCombineBins)
 void k_walk_combine(CombineArgs C)
