@@ -20,19 +20,23 @@
 //                  the layer above -- ~30 fp64 instructions per layer, one wave issuing
 //     all          B2 the Simpson terms, B4 the division and the stopping test: one (layer, ray)
 //                  pair per thread; B3 (chain wave) the running sums between them
-//     waves 0..9   emission_ray (k_emission's code; lanes = heights), this run's optical depths
-//                  from LDS, the flux straight into pinned host memory;  chain wave: last, the running
-//                  sums, the run's flags -- published by the last block to arrive, into device
-//                  memory as tau_publish leaves them AND into the pinned block the host reads:
-//                  no copy command behind the kernel
+//     waves 0..9   emission_ray (k_emission's code; lanes = heights; the Planck function of the
+//                  ray's heights was made while the chain wave was on its way), this run's optical
+//                  depths from LDS, the flux straight into pinned host memory;  chain wave: last, the
+//                  running sums, and what the block adds to the run's flags -- rays still open, deepest
+//                  layer -- as ONE store into a pinned array (host_blocks): the host adds the blocks
+//                  up.  No atomic, no fence, no copy command behind the kernel.  (TRX_TAIL_DIRECT=0:
+//                  the flags are summed on the device as tau_publish does, the last block to arrive
+//                  publishes them, and copy commands bring flags and spectrum back.)
 //
 // Same operations in the same order on the same values as the kernels it stands for: the same
 // bits (tests/test_gpu_tail.py compares every output with TRX_RAY_TAIL=0).  The side queue, its
-// events and the waits on them disappear from a hinted run -- the kernels from k_layer_max to the
-// tail then follow each other without a gap; the CIA kernels' event is the one wait left.  Not
-// covered (the step kernels run as before): unhinted and resumed runs, transit geometry,
-// plans of more than two steps or with two-kernel steps, shards of
-// more than 65 536 rays, profiled runs, restored extinction.
+// events and the waits on them disappear from a hinted run; a plan's second walk runs NEXT to the
+// first on the side queue with the tail behind it there (trx_api.hip, "two queues"), and the one
+// wait in front of the tail is for an event the main queue records behind its walk and the CIA
+// kernels.  Not covered (the step kernels run as before): unhinted and resumed runs, plans of more
+// than two steps or with two-kernel steps, shards of more than 65 536 rays, counting runs
+// (trx_opts.profile 2), restored extinction.
 #pragma once
 #include "trx_walk.hip.h"
 
