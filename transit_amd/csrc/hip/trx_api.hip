@@ -81,6 +81,9 @@ struct trx_handle {
   std::vector<double> adop, alor;                   // +1 sentinel
   std::vector<int32_t> psizeT; bool psize_mono = false;   // psize as [nlor][ndop] (prep_layers); no profile narrower than the one a Doppler index below it
   std::vector<double> dopthr;                       // steps of the nearest-index function on adop (build_table; dop_index)
+  std::vector<double> lorthr;                       // the same on alor (empty: the grid did not pass the check -- nearest_index is called)
+  std::vector<int> guess_dop, guess_lor, guess_a0, guess_a1;      // [niso] where prep_layers found the layer above (its walks start there)
+  std::vector<long> guess_npre;                     // [niso] and the layer above's count of groups at or above the refresh cut
   std::vector<double> iso_sqrtm;                    // sqrt(iso_mass)
   std::vector<double> dens_over_m;                  // [nmol] scratch of prep_layers
   std::vector<int32_t> psize; std::vector<long long> poff; int64_t tab_n = 0;
@@ -361,6 +364,26 @@ int build_table(trx_handle *h, const trx_static *s)
     }
     if ((rc = upload(h, h->d_dopthr, thr))) return rc;
     h->dopthr = thr;
+    {   // the Lorentz grid's steps, for the host's prologue (prep_layers): the same bisection; a grid that fails the check keeps nearest_index
+      const int nl = s->nlor;
+      std::vector<double> lt((size_t)nl + 1);
+      lt[0] = -HUGE_VAL; lt[nl] = HUGE_VAL;
+      auto lidx = [&](double v) { return nearest_index(h->alor.data(), v, 0, nl); };
+      bool ok = true;
+      for (int k = 1; k < nl && ok; k++) {
+        uint64_t a, b; double x;
+        if (!(h->alor[k - 1] > 0) || !(h->alor[k] > h->alor[k - 1])) { ok = false; break; }
+        std::memcpy(&a, &h->alor[k - 1], 8); std::memcpy(&b, &h->alor[k], 8);
+        while (b - a > 1) {
+          const uint64_t m = a + (b - a) / 2;
+          std::memcpy(&x, &m, 8);
+          if (lidx(x) >= k) b = m; else a = m;
+        }
+        std::memcpy(&lt[k], &b, 8);
+        ok = lidx(lt[k]) == k && lidx(std::nextafter(lt[k], 0.0)) == k - 1;
+      }
+      if (ok) h->lorthr = lt; else h->lorthr.clear();
+    }
     h->psizeT.resize((size_t)nd * h->nlor); h->psize_mono = true;
     for (int d = 0; d < nd; d++)
       for (int l = 0; l < h->nlor; l++) {
@@ -877,9 +900,14 @@ double doppler_refresh_cut(double alphad, double alphal)
   }
   double w = 1e-1 * alphal / alphad;
   if (!std::isfinite(w)) return HUGE_VAL;
-  while (!cond(w)) w = std::nextafter(w, HUGE_VAL);
+  // (the neighbours of a positive finite double are its bit pattern +- 1: std::nextafter, a library call, was a
+  // quarter of the prologue's time per (layer, isotope) pair)
+  auto up = [](double x) { uint64_t u; std::memcpy(&u, &x, 8); u++; std::memcpy(&x, &u, 8); return x; };            // x > 0 finite -> next above (inf after DBL_MAX)
+  auto down = [](double x) { uint64_t u; std::memcpy(&u, &x, 8); u--; std::memcpy(&x, &u, 8); return x; };          // x > 0 -> next below (+0 after the smallest denormal)
+  if (!(w > 0)) w = std::nextafter(0.0, 1.0);
+  while (!cond(w)) { w = up(w); if (!std::isfinite(w)) return HUGE_VAL; }
   for (;;) {
-    const double p = std::nextafter(w, 0.0);
+    const double p = down(w);
     if (p > 0 && cond(p)) w = p; else break;
   }
   return w;
@@ -938,6 +966,14 @@ inline int dop_index(const trx_handle *h, double v, int from)
   while (v < thr[from]) from--;
   return from;
 }
+inline int lor_index(const trx_handle *h, double v, int from)
+{
+  if (h->lorthr.empty()) return nearest_index(h->alor.data(), v, 0, h->nlor);
+  const double *thr = h->lorthr.data();      // thr[0] = -inf, thr[nlor] = +inf
+  while (from + 1 < h->nlor && v >= thr[from + 1]) from++;
+  while (v < thr[from]) from--;
+  return from;
+}
 inline int dop_index_far(const trx_handle *h, double v)
 {
   const double *thr = h->dopthr.data();
@@ -958,7 +994,10 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
   LH.psmax = psmax;
   h->dens_over_m.resize(nmol);
   double *dm = h->dens_over_m.data();
-  int dguess = 0;
+  // (the indices of an isotope change by a step or two from a layer to the next: each isotope's walks start where the
+  // layer above ended -- a bisection per pair and grid was a third of the prologue's time)
+  h->guess_dop.assign((size_t)std::max(niso, 1), 0); h->guess_lor.assign((size_t)std::max(niso, 1), 0);
+  h->guess_a0.assign((size_t)std::max(niso, 1), 0); h->guess_a1.assign((size_t)std::max(niso, 1), 0); h->guess_npre.assign((size_t)std::max(niso, 1), -1);
   for (int r = 0; r < nr; r++) {
     const double temp = temp_k[r];
     if (!(temp > 0)) return fail(h, TRX_E_ARG, "non-positive layer temperature");
@@ -975,8 +1014,8 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       const double ad = fdoppler / h->iso_sqrtm[i];
       const size_t k = (size_t)r * niso + i;
       alphal[k] = al; alphad[k] = ad;
-      idop0[k] = dguess = dop_index(h, ad * h->wn_i, dguess);
-      ilor[k]  = nearest_index(h->alor.data(), al, 0, h->nlor);
+      idop0[k] = h->guess_dop[i] = dop_index(h, ad * h->wn_i, h->guess_dop[i]);
+      ilor[k]  = h->guess_lor[i] = lor_index(h, al, h->guess_lor[i]);
       strength[k] = layer_strength(h, i, zpart[(size_t)i * nr + r]);
       dens[k] = density[(size_t)h->iso_imol[i] * nr + r];
       wcut[k] = doppler_refresh_cut(ad, al);
@@ -984,8 +1023,8 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
       // several times per pair -- each index is looked up once, and on a table whose profiles widen with the Doppler
       // width, the usual case, the widest of a range is its last)
       const bool has_lines = h->iso_wmax[i] > 0;
-      const int a0 = has_lines ? dop_index_far(h, ad * h->iso_wmin[i]) : idop0[k];
-      const int a1 = has_lines ? dop_index_far(h, ad * h->iso_wmax[i]) : idop0[k];
+      const int a0 = has_lines ? (h->guess_a0[i] = dop_index(h, ad * h->iso_wmin[i], h->guess_a0[i])) : idop0[k];
+      const int a1 = has_lines ? (h->guess_a1[i] = dop_index(h, ad * h->iso_wmax[i], h->guess_a1[i])) : idop0[k];
       const int32_t *psl = &h->psizeT[(size_t)ilor[k] * h->ndop];
       auto widest_of = [&](int i0, int i1) {
         if (i0 > i1) std::swap(i0, i1);
@@ -1039,7 +1078,23 @@ int prep_layers(trx_handle *h, int nr, const double *temp_k, const double *densi
         const long long kc = kcd < -4 ? -4 : kcd > (double)h->nwn + 4 ? h->nwn + 4 : (long long)kcd;
         const double *pa = gb + cg[std::min<long long>(std::max<long long>(kc + 2, 0), h->nwn)];
         const double *pz = gb + cg[std::min<long long>(std::max<long long>(kc - 2, 0), h->nwn)];
-        npre[k] = (int32_t)(std::partition_point(pa, pz, [wc](double w) { return w >= wc; }) - gb);
+        // (the cut moves a little from a layer to the next: the search starts at the layer above's answer and doubles its
+        // step -- the lines it touches are the ones the layer above left in the cache; the same partition point)
+        const double *lo = pa, *hi = pz;                       // [lo, hi): all of [gb, lo) >= wc, all of [hi, ..) < wc
+        const long g0 = h->guess_npre[i];
+        if (g0 >= 0 && gb + g0 >= pa && gb + g0 <= pz) {
+          const double *p = gb + g0;
+          long stepw = 1;
+          if (p < pz && *p >= wc) {                            // the answer lies above p
+            lo = p + 1;
+            while (lo < hi) { const double *q = lo + stepw - 1; if (q >= hi) break; if (*q >= wc) { lo = q + 1; stepw *= 2; } else { hi = q; break; } }
+          } else {                                             // at or below p
+            hi = p;
+            while (lo < hi) { const double *q = hi - stepw; if (q < lo) break; if (*q >= wc) { lo = q + 1; break; } else { hi = q; stepw *= 2; } }
+          }
+        }
+        const long np = (long)(std::partition_point(lo, hi, [wc](double w) { return w >= wc; }) - gb);
+        npre[k] = (int32_t)np; h->guess_npre[i] = np;
       }
     }
   }
