@@ -96,3 +96,44 @@ def test_segmented_cia_spline_on_the_whole_grid(tmp_path, solution, ncia):
         assert np.all(np.isfinite(ra["e_cs"])) and ra["e_cs"].max() > 0
     finally:
         a.close(); b.close(); c.close()
+
+
+def test_irregular_cia_grid(tmp_path):
+    """A table whose wavenumber spacing jumps by factors of a hundred (clusters of close rows far apart): the sweeps'
+    row-to-row factors stay below 0.3 there too -- trx_create's check of the 48th term passes (said in the debug log;
+    a table that failed it would keep the two sweeps) -- and e_cs agrees with the oracle and with the sweeps as on a
+    regular grid."""
+    import oracle_lib as ol
+    from cases import rel_err
+    from transit_amd import engine
+    d = str(tmp_path / "i")
+    synth.make_case(d, nlines=20_000, wnlow=2500, wnhigh=3500, wndelt=1.0, wnosamp=2160, nlayers=30,
+                    solution="eclipse", toomuch=10.0, ethresh=1e-50, seed=13, ncia=2)
+    # the second table on an irregular grid: clusters of close rows far apart
+    wn, t, cs = synth.synth_cia(2400.0, 3600.0)
+    rng = np.random.default_rng(3)
+    parts = [c + np.sort(rng.uniform(0.0, 0.5, 6)) for c in np.arange(2400.0, 3600.0, 60.0)]
+    wi = np.unique(np.concatenate(parts))
+    ci = np.stack([np.interp(wi, wn, cs[:, k]) for k in range(cs.shape[1])], axis=1)
+    synth.write_cia(os.path.join(d, "cia_h2he.dat"), ["H2", "He"], wi, t[4:], 0.3 * ci[:, 4:])
+    P = Problem.from_cfg(os.path.join(d, "case.cfg"))
+    msgs = []
+    engine.set_log(lambda lvl, m: msgs.append(m), 5)
+    try:
+        a = _engine(P.static)
+    finally:
+        engine.set_log(None)
+    b = _engine(P.static, TRX_CIA_SUMS=0)
+    ora = ol.OracleEngine(P.static)
+    try:
+        how = [m for m in msgs if "second derivatives by" in m]
+        assert len(how) == 2 and all("sums per row" in m for m in how), how
+        ra = a.run(P.atm, P.opts, debug=("e_cs", "last"))
+        rb = b.run(P.atm, P.opts, debug=("e_cs", "last"))
+        ro = ora.run(P.atm, P.opts, debug=("e_cs", "last"))
+        assert rel_err(ra["e_cs"], ro["e_cs"]) < 1e-13 and rel_err(rb["e_cs"], ro["e_cs"]) < 1e-13
+        assert rel_err(ra["e_cs"], rb["e_cs"]) < 1e-13
+        assert np.array_equal(ra["last"], ro["last"])
+        assert np.all(np.isfinite(ra["e_cs"])) and ra["e_cs"].max() > 0
+    finally:
+        a.close(); b.close(); ora.close()

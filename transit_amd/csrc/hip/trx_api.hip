@@ -1778,6 +1778,12 @@ int trx_create(const trx_static *s, trx_handle **out)
           }
         }
         if (worst < 0x1p-60) { t.wf = std::move(wf); t.wb = std::move(wb); }
+        if (log_sink().fn && log_sink().max_level >= TRX_LOG_DEBUG) {
+          char msg[160];
+          std::snprintf(msg, sizeof msg, "create: CIA table %d (%zu rows): second derivatives by %s (term %d of the row sums at most %.1e of the first)",
+                        k, nw, t.wf.empty() ? "the two sweeps" : "sums per row", kCiaTerms, worst);
+          log_msg(TRX_LOG_DEBUG, msg);
+        }
       }
     }
     h->cia.push_back(std::move(t));
