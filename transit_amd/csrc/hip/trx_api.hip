@@ -1384,11 +1384,9 @@ int sweep_chunk(trx_handle *h, const LayerDev &Y, const double *d_wcut, const in
   const unsigned tblocks = (unsigned)(((ntiles + 3) / 4 + kSpan - 1) / kSpan * kSpan);   // multiple of 8*G: xcd_grouped_x()
   if (sp && sp->begin(Spans::kSweep, st)) return fail(h, TRX_E_HIP, "event");
   if (seg_lines > 0) {
-    // (chunks of 256 lines; at most 16 blocks per CU, each taking every gridDim-th chunk: the block's tables and runs once)
-    const long long nchunks = (seg_lines + 255) / 256;
-    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)std::min<long long>(nchunks, 256 * 16)), dim3(256), sizeof(long long) * (2 * (size_t)niso + 1), st,
+    hipLaunchKernelGGL(k_group_sweep, dim3((unsigned)((seg_lines + 255) / 256)), dim3(256), sizeof(long long) * (2 * (size_t)niso + 1), st,
                        h->L, Y, Wn, niso, r_top, nc, h->d_dopthr.as<double>(), h->ndop, h->d_e2tab.as<double>(), d_wcut,
-                       d_SG, d_idop8, h->d_flags.as<int>(), (int)M.eager, nchunks);
+                       d_SG, d_idop8, h->d_flags.as<int>(), (int)M.eager);
   }
   if (sp && (sp->end(st) || sp->begin(Spans::kAccum, st))) return fail(h, TRX_E_HIP, "event");
   if (h->ngroups > 0) {

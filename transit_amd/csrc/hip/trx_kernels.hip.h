@@ -356,7 +356,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
                    const double *__restrict__ e2tab,            // 2^(j/64), j = 0..63
                    const double *__restrict__ wcut,     // [layer][iso] refresh <=> wavn >= wcut
                    double *__restrict__ SG, uint8_t *__restrict__ idop8,
-                   const int *__restrict__ flags, int eager, long long nchunks)
+                   const int *__restrict__ flags, int eager)
 {
   if (!sweep_active(flags, eager)) return;
   __shared__ double s_thr[kMaxDop + 1];
@@ -375,6 +375,7 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
     s_f[c][b] = Y.strength_f[ri]; s_wc[c][b] = wcut[ri]; s_ad[c][b] = Y.alphad[ri];
   }
   // the runs of lines: block b -> [la, lz) (the same arithmetic as the host's launch size, sweep_chunk)
+  const long long t0 = (long long)blockIdx.x * 256;
   for (int b = threadIdx.x; b < niso; b += 256) {
     const int gb0 = L.gblock[b], gb1 = L.gblock[b + 1];
     long long la = 0, lz = 0;
@@ -401,11 +402,6 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
     s_base[niso] = tot;
   }
   __syncthreads();
-  // A block takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ... of 256 lines: what stands above -- the tables in
-  // LDS, the runs -- is four dependent round trips, and with one chunk per block (39 000 blocks at configs[4]) a block
-  // lived 35 us of which it issued for one: two thirds of the kernel's wave-cycles were waits.
-  for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-  const long long t0 = chunk * 256;
   const long long ln = niso > 0 ? seg_index(s_start, s_base, niso, t0 + threadIdx.x) : -1;
   const bool ok = ln >= 0;
   int g = -1, cnt = 0, iso = 0;
@@ -454,8 +450,6 @@ void k_group_sweep(LinesDev L, LayerDev Y, SweepWindow Wn, int niso, int r_top, 
       SG[(long long)c * L.ngroups + g] = pk;
       idop8[(long long)c * L.ngroups + g] = id;
     }
-  }
-  __syncthreads();                                          // (the next chunk's first layer writes the buffer an odd number of layers ended on)
   }
 }
 
