@@ -2357,6 +2357,7 @@ static int run_once(trx_handle *h, const trx_atm *a, const trx_opts *o, double *
     T.wn_i = h->wn_i; T.wn_d = h->wn_d; T.wn_fct = o->wn_fct; T.rad_fct = a->rad_fct; T.toomuch = o->toomuch;
     T.r_top = r_top_; T.nc = nc_; T.rad = d_rad; T.e = h->d_e.as<double>(); T.ecs = h->d_ecs.as<double>();
     T.er = h->d_er.as<double>(); T.tau = h->d_tau.as<double>(); T.last = h->d_last.as<int>();
+    T.er_all = (dbg != nullptr || eager) ? 1 : 0;
     T.gw = d_gw; T.gstride = gstride; T.gh0 = d_gh0;
     model_args(T);
     T.flags = h->d_flags.as<int>(); T.eager = eager;

@@ -1259,6 +1259,8 @@ struct TauArgs {
   const double *rad;                 // [nr]
   const double *e, *ecs;             // [nr][nsh]
   double *er;                        // [nr][nsh] total extinction, edited in place (eclipse.c:65-66)
+  int er_all;                        // vertical rays: 1 = every layer's bottom-point value goes to er (dumps); 0 = only a launch's last two layers, which
+                                     // the next launch's parabolas start from -- nothing else reads them, and they were a fifth of the kernel's bytes
   double *tau;                       // [nr(height)][nsh]
   int *last;                         // [nsh], -1 while the ray is still descending
   // Simpson weights per start layer rs: row rs holds, per interval pair,
@@ -1786,7 +1788,7 @@ void k_optical_depth_vertical(TauArgs T)
       if (!alive) { T.last[w] = nr - 1 - (T.r_top - (done - 1)); still = false; }
       for (int d = 0; d < done; d++) {
         const int rs = T.r_top - d;
-        T.er[(long long)rs * T.nsh + w] = s_out[(2 * d) * 64 + threadIdx.x];
+        if (T.er_all || d >= T.nc - 2) T.er[(long long)rs * T.nsh + w] = s_out[(2 * d) * 64 + threadIdx.x];
         T.tau[(long long)(nr - 1 - rs) * T.nsh + w] = s_out[(2 * d + 1) * 64 + threadIdx.x];
       }
     } else {
@@ -1796,7 +1798,8 @@ void k_optical_depth_vertical(TauArgs T)
         q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = total_ext(c + 6);
         double y0, tv;
         vertical_layer<true>(T, s_rad, s_lay, c, yraw, ybelow, R, y0, tv);
-        T.er[(long long)rs * T.nsh + w] = y0; T.tau[(long long)ri * T.nsh + w] = tv;
+        if (T.er_all || c >= T.nc - 2) T.er[(long long)rs * T.nsh + w] = y0;
+        T.tau[(long long)ri * T.nsh + w] = tv;
         if (tv > T.toomuch || ri == nr - 1) { T.last[w] = ri; still = false; break; }   // tau.c:277-287, 299-304
       }
     }
